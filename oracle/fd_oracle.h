@@ -1,0 +1,92 @@
+/*
+ * fd_oracle.h -- CPU restatement (plain C, fp64) of the RBF deformation hot path
+ * of symek/facedeform's SOP_FaceDeform::cookMySop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and there only as the checker / the timed CPU baseline.  The shipped path
+ * (facedeform_amd/, include/facedeform_hip.h) never links or calls this file.
+ *
+ * PARITY UNPINNED against the reference: the reference has no tests, fixtures
+ * or golden vectors, and its RBF arithmetic lives in ALGLIB, an un-vendored,
+ * un-pinned third-party dependency (reference CMakeLists.txt:9-19) that is not
+ * present here, so the reference path cannot be compiled or run (needs the
+ * Houdini HDK as well).  What pins this oracle instead: (1) golden vectors
+ * generated in the build container by an independent implementation of the
+ * same dense system, SciPy 1.15.3 scipy.interpolate.RBFInterpolator
+ * (tests/golden/make_golden.py, fixtures committed under tests/golden/),
+ * (2) closed-form known answers, (3) one known-answer test per reference
+ * epilogue behaviour.
+ *
+ * What is restated, and from where (paths relative to /root/reference):
+ *   fdo_control_table      src/SOP_FaceDeform.cpp:268-287  (M x 6 table, fp32 delta)
+ *   fdo_build              src/SOP_FaceDeform.cpp:331-368  (model config + solve; dense
+ *                          formulation of north_star instead of ALGLIB QNN/ML)
+ *   fdo_deform             src/SOP_FaceDeform.cpp:396-439  (gate, evaluate, tangent,
+ *                          fall-off, write-back -- in the reference's order)
+ *   fdo_project_to_tangents src/SOP_FaceDeform.hpp:28-41
+ */
+#ifndef FD_ORACLE_H
+#define FD_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Radial kernels.  d2 = squared distance to centre j.
+ * GAUSSIAN      exp(-d2 / R^2), one radius R for all centres   params: {R[, lambda]}
+ * GAUSSIAN_QNN  exp(-d2 / R_j^2), R_j = min(q*nn_j, z*median_k(q*nn_k)), nn_j = distance
+ *               to the nearest other centre   params: {q, z[, lambda]}
+ * THIN_PLATE    r^2 ln r = 0.5 * d2 * ln d2, 0 at d2 = 0       params: {[lambda]}
+ * BIHARMONIC    -r   (SciPy 'linear' sign convention)          params: {[lambda]}
+ * CUBIC         r^3                                             params: {[lambda]}
+ */
+enum {
+    FDO_KERNEL_GAUSSIAN = 0,
+    FDO_KERNEL_GAUSSIAN_QNN = 1,
+    FDO_KERNEL_THIN_PLATE = 2,
+    FDO_KERNEL_BIHARMONIC = 3,
+    FDO_KERNEL_CUBIC = 4
+};
+
+/* Same integers as ALGLIB_TERM_* in src/SOP_FaceDeform.hpp:16-18. */
+enum { FDO_TERM_LINEAR = 0, FDO_TERM_CONST = 1, FDO_TERM_ZERO = 2 };
+
+/* A2: table[i] = (rest_i.xyz, float(deform_i - rest_i).xyz) widened to fp64. */
+void fdo_control_table(const float *rest_xyz, const float *deform_xyz, int M, double *table);
+
+/* Per-centre Gaussian radii for `kind`; radii[M].  Non-Gaussian kinds get 1.0. */
+int fdo_radii(const double *table, int M, int kind, const double *params, int nparams,
+              double *radii);
+
+/* A3-A6: dense assemble + LU (partial pivoting) solve.
+ * W is (M+4) x 3 row-major: rows 0..M-1 RBF weights, row M the constant
+ * coefficient, rows M+1..M+3 the x,y,z linear coefficients (zero when the
+ * term does not carry them).  radii_out[M] receives the Gaussian radii.
+ * Returns 0 and *terminationtype = 1 on success; *terminationtype = -5 for
+ * coincident centres, -4 for a singular system (then returns nonzero). */
+int fdo_build(const double *table, int M, int kind, const double *params, int nparams,
+              int term, double *W, double *radii_out, int *terminationtype);
+
+/* A8 alone: delta_out[i] = RBF(x_i) in fp64 (no epilogue). */
+void fdo_eval(const double *table, int M, int kind, const double *radii, const double *W,
+              int64_t N, const double *x_xyz, double *delta_out);
+
+/* A9. u, v, n must already be normalised by the caller, as in the reference. */
+void fdo_project_to_tangents(const float u[3], const float v[3], const float n[3],
+                             float disp[3]);
+
+/* A7-A10: the evaluation loop.  P_out may alias P_in.  dist2 / falloff_out /
+ * (tu, tv, nrm) may be NULL.  nthreads <= 1 runs on the calling thread (the
+ * reference is single-threaded: src/SOP_FaceDeform.hpp:11). */
+int fdo_deform(const double *table, int M, int kind, const double *radii, const double *W,
+               int64_t N, const float *P_in, float *P_out, const float *dist2,
+               float *falloff_out, const float *tu, const float *tv, const float *nrm,
+               float radius2, float falloffrate, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

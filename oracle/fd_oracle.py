@@ -1,0 +1,126 @@
+"""ctypes loader for the CPU oracle (oracle/fd_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED against the reference (see
+fd_oracle.h).  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg only; the product package facedeform_amd never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT_SO = os.path.join(_HERE, "libfd_oracle.so")
+
+KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC = range(5)
+TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/libfd_oracle.so with the committed Makefile (gcc)."""
+    if force or not os.path.exists(_DEFAULT_SO) or (
+        os.path.getmtime(_DEFAULT_SO) < os.path.getmtime(os.path.join(_HERE, "fd_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libfd_oracle.so"])
+    return _DEFAULT_SO
+
+
+def build_native(out_path: str) -> str:
+    """-O3 -march=native build for timing the CPU baseline on the current host."""
+    subprocess.check_call(["make", "-C", _HERE, "-s", "native", f"OUT={out_path}"])
+    return out_path
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+class Oracle:
+    def __init__(self, so_path: str | None = None):
+        path = so_path or _DEFAULT_SO
+        if not os.path.exists(path):
+            build()
+        self.lib = L = C.CDLL(path)
+        L.fdo_control_table.argtypes = [_f32p, _f32p, C.c_int, _f64p]
+        L.fdo_control_table.restype = None
+        L.fdo_radii.argtypes = [_f64p, C.c_int, C.c_int, _f64p, C.c_int, _f64p]
+        L.fdo_radii.restype = C.c_int
+        L.fdo_build.argtypes = [_f64p, C.c_int, C.c_int, _f64p, C.c_int, C.c_int, _f64p, _f64p,
+                                C.POINTER(C.c_int)]
+        L.fdo_build.restype = C.c_int
+        L.fdo_eval.argtypes = [_f64p, C.c_int, C.c_int, _f64p, _f64p, C.c_int64, _f64p, _f64p]
+        L.fdo_eval.restype = None
+        L.fdo_project_to_tangents.argtypes = [_f32p, _f32p, _f32p, _f32p]
+        L.fdo_project_to_tangents.restype = None
+        L.fdo_deform.argtypes = [_f64p, C.c_int, C.c_int, _f64p, _f64p, C.c_int64, _f32p, _f32p,
+                                 _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_int]
+        L.fdo_deform.restype = C.c_int
+
+    # -- A2
+    def control_table(self, rest, deform):
+        rest = np.ascontiguousarray(rest, np.float32).reshape(-1, 3)
+        deform = np.ascontiguousarray(deform, np.float32).reshape(-1, 3)
+        assert rest.shape == deform.shape
+        table = np.empty((rest.shape[0], 6), np.float64)
+        self.lib.fdo_control_table(_ptr(rest, _f32p), _ptr(deform, _f32p), rest.shape[0],
+                                   _ptr(table, _f64p))
+        return table
+
+    # -- A3-A6
+    def build(self, table, kind, params=(), term=TERM_LINEAR):
+        table = np.ascontiguousarray(table, np.float64)
+        M = table.shape[0]
+        params = np.ascontiguousarray(np.asarray(params, np.float64).reshape(-1))
+        W = np.zeros((M + 4, 3), np.float64)
+        radii = np.ones(max(M, 1), np.float64)
+        tt = C.c_int(0)
+        rc = self.lib.fdo_build(_ptr(table, _f64p), M, kind, _ptr(params, _f64p) if params.size else None,
+                                params.size, term, _ptr(W, _f64p), _ptr(radii, _f64p), C.byref(tt))
+        return rc, tt.value, W, radii[:M]
+
+    # -- A8
+    def eval(self, table, kind, radii, W, x):
+        table = np.ascontiguousarray(table, np.float64)
+        x = np.ascontiguousarray(x, np.float64).reshape(-1, 3)
+        radii = np.ascontiguousarray(radii, np.float64)
+        W = np.ascontiguousarray(W, np.float64)
+        out = np.empty_like(x)
+        self.lib.fdo_eval(_ptr(table, _f64p), table.shape[0], kind, _ptr(radii, _f64p),
+                          _ptr(W, _f64p), x.shape[0], _ptr(x, _f64p), _ptr(out, _f64p))
+        return out
+
+    # -- A9
+    def project_to_tangents(self, u, v, n, disp):
+        u, v, n = (np.ascontiguousarray(a, np.float32) for a in (u, v, n))
+        d = np.array(disp, np.float32)
+        self.lib.fdo_project_to_tangents(_ptr(u, _f32p), _ptr(v, _f32p), _ptr(n, _f32p), _ptr(d, _f32p))
+        return d
+
+    # -- A7-A10
+    def deform(self, table, kind, radii, W, P, dist2=None, tangents=None, radius2=1.0,
+               falloffrate=1.0, want_falloff=True, nthreads=1, out=None):
+        table = np.ascontiguousarray(table, np.float64)
+        radii = np.ascontiguousarray(radii, np.float64)
+        W = np.ascontiguousarray(W, np.float64)
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+        N = P.shape[0]
+        P_out = np.empty_like(P) if out is None else out
+        d2 = None if dist2 is None else np.ascontiguousarray(dist2, np.float32)
+        fall = np.zeros(N, np.float32) if want_falloff else None
+        tu = tv = nr = None
+        if tangents is not None:
+            tu, tv, nr = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in tangents)
+        rc = self.lib.fdo_deform(_ptr(table, _f64p), table.shape[0], kind, _ptr(radii, _f64p),
+                                 _ptr(W, _f64p), N, _ptr(P, _f32p), _ptr(P_out, _f32p),
+                                 _ptr(d2, _f32p), _ptr(fall, _f32p), _ptr(tu, _f32p),
+                                 _ptr(tv, _f32p), _ptr(nr, _f32p), float(radius2),
+                                 float(falloffrate), int(nthreads))
+        if rc != 0:
+            raise RuntimeError(f"fdo_deform failed: {rc}")
+        return P_out, fall
