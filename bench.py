@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the RBF deformation hot path on MI355X.
+
+One "step" = one cook of the hot path on one frame, inputs resident in HBM:
+control table upload (device-to-device) + kernel-matrix assembly + dense fp64
+solve + per-vertex evaluation with the reference's epilogue.  The model is
+rebuilt every step, as the reference does every cook.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: independent frames are sharded one per GPU at a time (BASELINE config 4),
+no data-path collective, weak scaling.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n_verts, n_ctrl, mesh, description)
+    "c1": (10_000, 32, "sphere", "C1: 10k-vert sphere, 32 control points"),
+    "c2": (1_000_000, 256, "head", "C2: 1M-vert head mesh, 256 control points"),
+    "c3": (1_000_000, 2048, "head", "C3: 1M-vert head mesh, 2048 control points (solve-bound)"),
+}
+METRIC = "deformed Mverts/sec at 256 ctrl pts, 1/2/4/8 MI355X vs host-CPU ref"
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA dense peak
+PEAK_HBM_GBS = 8000.0      # HBM3E spec
+FLOPS_PER_PAIR = 17        # thin-plate: SURVEY.md 8d
+FLOPS_PER_VERTEX_AFFINE = 24
+BYTES_PER_VERTEX = 24      # read P 12 + write P 12 (the conservative figure)
+N_FRAMES = 64
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--variant", type=int, default=0, help="evaluation kernel variant (0 = auto)")
+    ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=float, default=3.0e8,
+                    help="bound on (vertex, centre) pairs in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_name, P, rest, deform, max_pairs):
+    """Time the oracle (CPU restatement, kind 'port') on this host.  Test infrastructure
+    used as the timed baseline only; never part of the GPU path."""
+    from oracle import fd_oracle as fo
+    so = None
+    try:
+        so = fo.build_native(os.path.join(tempfile.mkdtemp(prefix="fdo_"), "libfd_oracle_native.so"))
+    except Exception:
+        fo.build()
+    orc = fo.Oracle(so)
+    M = rest.shape[0]
+    n_sample = int(min(P.shape[0], max(1000, max_pairs // M)))
+    Ps = np.ascontiguousarray(P[:n_sample])
+    table = orc.control_table(rest, deform)
+    t0 = time.perf_counter()
+    rc, tt, W, radii = orc.build(table, fo.KERNEL_THIN_PLATE, [], fo.TERM_LINEAR)
+    t_build = time.perf_counter() - t0
+    assert tt == 1
+    out = np.empty_like(Ps)
+    t0 = time.perf_counter()
+    orc.deform(table, fo.KERNEL_THIN_PLATE, radii, W, Ps, nthreads=1, out=out)
+    t_eval1 = time.perf_counter() - t0
+    ncores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    orc.deform(table, fo.KERNEL_THIN_PLATE, radii, W, Ps, nthreads=ncores, out=out)
+    t_evaln = time.perf_counter() - t0
+    # whole cook on the full mesh = one solve + evaluation scaled from the sample
+    scale = P.shape[0] / n_sample
+    cook1 = t_build + t_eval1 * scale
+    cookn = t_build + t_evaln * scale
+    sample = (f"{n_sample} of {P.shape[0]} vertices x {M} centres, fp64 dense restatement "
+              f"(oracle/fd_oracle.c, {'-O3 -march=native' if so else '-O2 portable'}), "
+              f"1 solve ({t_build * 1e3:.1f} ms) + single-thread evaluation ({t_eval1:.2f} s on the sample)")
+    return {
+        "value": P.shape[0] / cook1 / 1e6, "unit": "Mverts/s", "cores": 1, "kind": "port", "sample": sample,
+        "all_cores": {"value": P.shape[0] / cookn / 1e6, "unit": "Mverts/s", "cores": ncores,
+                      "eval_s_on_sample": t_evaln},
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from facedeform_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_verts, n_ctrl, mesh_kind, desc = CONFIGS[args.config]
+    P_host = synth.sphere_mesh(n_verts) if mesh_kind == "sphere" else synth.head_mesh(n_verts)
+    rest_host = synth.control_points(n_ctrl, mesh_kind)
+    deltas_host = np.stack([synth.smooth_deltas(rest_host, f) for f in range(N_FRAMES)])
+
+    d_P = torch.from_numpy(P_host).to(dev)
+    d_out = torch.empty_like(d_P)
+    d_fall = torch.zeros(n_verts, device=dev, dtype=torch.float32)
+    d_rest = torch.from_numpy(rest_host).to(dev)
+    d_deltas = torch.from_numpy(deltas_host).to(dev)
+
+    precision = capi.EVAL_FP64 if args.precision == "fp64" else capi.EVAL_FP32
+    eng = capi.Engine(device=local_rank, precision=precision, variant=args.variant)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    eng.set_kernel(capi.KERNEL_THIN_PLATE)
+    eng.set_term(capi.TERM_LINEAR)
+
+    delta_stride = n_ctrl * 3 * 4
+
+    def step(i, ev=None):
+        frame = (i * world + rank) % N_FRAMES
+        eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr() + frame * delta_stride, n_ctrl)
+        if ev:
+            ev[0].record(stream)
+        eng.build_async()
+        if ev:
+            ev[1].record(stream)
+        eng.deform_dev(n_verts, d_P.data_ptr(), d_out.data_ptr(), d_falloff=d_fall.data_ptr())
+        if ev:
+            ev[2].record(stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    rep = eng.build_result()
+    if rep.terminationtype != 1:
+        raise SystemExit(f"build failed: terminationtype {rep.terminationtype}")
+
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, events[i])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    rep = eng.build_result()
+    if rep.terminationtype != 1:
+        raise SystemExit(f"build failed in timed region: terminationtype {rep.terminationtype}")
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    build_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    eval_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+
+    if rank == 0:
+        total_verts = world * args.steps * n_verts
+        flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_verts
+        achieved_tflops = flops / (eval_ms * 1e-3) / 1e12
+        achieved_gbs = BYTES_PER_VERTEX * n_verts / (eval_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": METRIC,
+            "value": total_verts / elapsed / 1e6,
+            "unit": "Mverts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if precision == capi.EVAL_FP32 else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{desc}, thin-plate kernel, linear term, {args.precision} evaluation, "
+                            "fp64 dense solve rebuilt every step (assemble + LU + evaluate), one frame per step per GPU",
+                "n_verts": n_verts, "n_ctrl": n_ctrl,
+                "parallelism": f"frames sharded one per GPU x{world}, no collective",
+            },
+            "roofline": {
+                # the evaluation kernel is compute-bound at this M (intensity ~182 flop/B vs ridge ~20):
+                # its roof is the fp32 rate, 157.3 TFLOP/s for VALU and MFMA alike on gfx950
+                "bound": "mfma", "kernel": "k_deform32",
+                "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
+                "flops_per_launch": flops, "avg_launch_ms": eval_ms,
+                "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_launch": BYTES_PER_VERTEX * n_verts},
+            },
+            "phases_ms": {"build": build_ms, "evaluate": eval_ms},
+            "eval_only_mverts_s": n_verts / (eval_ms * 1e-3) / 1e6,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config, P_host, rest_host,
+                                                (rest_host + deltas_host[0]).astype(np.float32), args.cpu_pairs)
+        print(json.dumps(line), flush=True)
+
+    eng.set_stream(None)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

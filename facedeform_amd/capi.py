@@ -1,0 +1,248 @@
+"""ctypes binding of include/facedeform_hip.h.
+
+Plumbing only: it loads the in-tree libfacedeform_hip.so and forwards calls.
+There is no fallback: a missing library raises, and fd_create without a
+gfx950 device fails with the library's own message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+FD_OK = 0
+FD_E_INVALID, FD_E_NOMEM, FD_E_DEVICE, FD_E_SINGULAR, FD_E_DUPLICATE, FD_E_NOT_BUILT, FD_E_NO_DEVICE = (
+    -1, -2, -3, -4, -5, -6, -7)
+KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC = range(5)
+TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
+EVAL_FP32, EVAL_FP64 = 0, 1
+FDSOP_OK, FDSOP_MESSAGE, FDSOP_WARNING, FDSOP_ERROR = range(4)
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+
+class FdConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("eval_precision", C.c_int),
+                ("eval_variant", C.c_int), ("reserved", C.c_int * 4)]
+
+
+class FdReport(C.Structure):
+    _fields_ = [("terminationtype", C.c_int), ("iterationscount", C.c_int), ("n", C.c_int),
+                ("reserved", C.c_int), ("pivot_ratio", C.c_double), ("t_assemble_ms", C.c_float),
+                ("t_solve_ms", C.c_float)]
+
+
+class FdsopGeo(C.Structure):
+    _fields_ = [("npoints", C.c_int64), ("P", _f32p), ("tangentu", _f32p), ("tangentv", _f32p),
+                ("N", _f32p), ("dist2", _f32p), ("rest_npoints", C.c_int64),
+                ("deform_npoints", C.c_int64), ("rest_P", _f32p), ("deform_P", _f32p),
+                ("P_out", _f32p), ("fd_falloff", _f32p), ("Cd", _f32p)]
+
+
+# every symbol include/facedeform_hip.h declares
+EXPORTS = [
+    "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_points",
+    "fd_set_points_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
+    "fd_build_result", "fd_deform", "fd_deform_dev", "fd_get_weights", "fd_model_bytes",
+    "fd_export_model", "fd_import_model", "fd_synchronize",
+    "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
+    "fdsop_get_float", "fdsop_get_int", "fdsop_parm_count", "fdsop_parm_token", "fdsop_cook",
+    "fdsop_messages", "fdsop_effective_float", "fdsop_engine",
+]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.environ.get("FACEDEFORM_HIP_LIB", _build.LIB_PATH)
+
+
+def load() -> C.CDLL:
+    """Load the shared library (built by facedeform_amd._build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(needs hipcc). The engine has no CPU fallback.")
+    L = C.CDLL(path)
+    vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+    L.fd_create.argtypes = [C.POINTER(FdConfig)]; L.fd_create.restype = vp
+    L.fd_destroy.argtypes = [vp]; L.fd_destroy.restype = None
+    L.fd_last_error.argtypes = [vp]; L.fd_last_error.restype = C.c_char_p
+    L.fd_abi_version.argtypes = []; L.fd_abi_version.restype = i32
+    L.fd_set_stream.argtypes = [vp, vp]; L.fd_set_stream.restype = i32
+    L.fd_set_points.argtypes = [vp, vp, vp, i32]; L.fd_set_points.restype = i32
+    L.fd_set_points_dev.argtypes = [vp, vp, vp, i32]; L.fd_set_points_dev.restype = i32
+    L.fd_set_kernel.argtypes = [vp, i32, _f64p, i32]; L.fd_set_kernel.restype = i32
+    L.fd_set_term.argtypes = [vp, i32]; L.fd_set_term.restype = i32
+    L.fd_build.argtypes = [vp, C.POINTER(FdReport)]; L.fd_build.restype = i32
+    L.fd_build_async.argtypes = [vp]; L.fd_build_async.restype = i32
+    L.fd_build_result.argtypes = [vp, C.POINTER(FdReport)]; L.fd_build_result.restype = i32
+    L.fd_deform.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float]
+    L.fd_deform.restype = i32
+    L.fd_deform_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float]
+    L.fd_deform_dev.restype = i32
+    L.fd_get_weights.argtypes = [vp, _f64p, _f64p]; L.fd_get_weights.restype = i32
+    L.fd_model_bytes.argtypes = [vp]; L.fd_model_bytes.restype = sz
+    L.fd_export_model.argtypes = [vp, vp, sz, i32]; L.fd_export_model.restype = i32
+    L.fd_import_model.argtypes = [vp, vp, sz, i32]; L.fd_import_model.restype = i32
+    L.fd_synchronize.argtypes = [vp]; L.fd_synchronize.restype = i32
+    L.fdsop_create.argtypes = [C.POINTER(FdConfig)]; L.fdsop_create.restype = vp
+    L.fdsop_destroy.argtypes = [vp]; L.fdsop_destroy.restype = None
+    L.fdsop_set_float.argtypes = [vp, C.c_char_p, i32, C.c_double]; L.fdsop_set_float.restype = i32
+    L.fdsop_set_int.argtypes = [vp, C.c_char_p, i32]; L.fdsop_set_int.restype = i32
+    L.fdsop_set_string.argtypes = [vp, C.c_char_p, C.c_char_p]; L.fdsop_set_string.restype = i32
+    L.fdsop_get_float.argtypes = [vp, C.c_char_p, i32, _f64p]; L.fdsop_get_float.restype = i32
+    L.fdsop_get_int.argtypes = [vp, C.c_char_p, C.POINTER(i32)]; L.fdsop_get_int.restype = i32
+    L.fdsop_parm_count.argtypes = []; L.fdsop_parm_count.restype = i32
+    L.fdsop_parm_token.argtypes = [i32]; L.fdsop_parm_token.restype = C.c_char_p
+    L.fdsop_cook.argtypes = [vp, C.POINTER(FdsopGeo)]; L.fdsop_cook.restype = i32
+    L.fdsop_messages.argtypes = [vp]; L.fdsop_messages.restype = C.c_char_p
+    L.fdsop_effective_float.argtypes = [vp, C.c_char_p, _f64p]; L.fdsop_effective_float.restype = i32
+    L.fdsop_engine.argtypes = [vp]; L.fdsop_engine.restype = vp
+    _lib = L
+    return L
+
+
+class FdError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"facedeform_hip error {code}: {text}")
+        self.code = code
+        self.text = text
+
+
+def _np_ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    """Thin object wrapper over fd_ctx.  Host arrays are numpy; device pointers are ints."""
+
+    def __init__(self, device: int = -1, precision: int = EVAL_FP32, variant: int = 0, _borrowed=None):
+        self.L = load()
+        self._own = _borrowed is None
+        if _borrowed is not None:
+            self.ctx = _borrowed
+            return
+        cfg = FdConfig(C.sizeof(FdConfig), device, precision, variant)
+        self.ctx = self.L.fd_create(C.byref(cfg))
+        if not self.ctx:
+            raise FdError(FD_E_NO_DEVICE, self.L.fd_last_error(None).decode())
+        self.M = 0
+
+    def close(self):
+        if getattr(self, "ctx", None) and self._own:
+            self.L.fd_destroy(self.ctx)
+        self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != FD_OK:
+            raise FdError(rc, self.L.fd_last_error(self.ctx).decode())
+
+    def last_error(self) -> str:
+        return self.L.fd_last_error(self.ctx).decode()
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self.L.fd_set_stream(self.ctx, C.c_void_p(stream_ptr or 0)))
+
+    def set_points(self, rest, delta):
+        rest = np.ascontiguousarray(rest, np.float32).reshape(-1, 3)
+        delta = np.ascontiguousarray(delta, np.float32).reshape(-1, 3)
+        if rest.shape != delta.shape:
+            raise ValueError("rest and delta must have the same shape")
+        self.M = rest.shape[0]
+        self._check(self.L.fd_set_points(self.ctx, _np_ptr(rest), _np_ptr(delta), self.M))
+
+    def set_points_dev(self, d_rest: int, d_delta: int, M: int):
+        self.M = M
+        self._check(self.L.fd_set_points_dev(self.ctx, C.c_void_p(d_rest), C.c_void_p(d_delta), M))
+
+    def set_kernel(self, kind: int, params=()):
+        p = np.ascontiguousarray(np.asarray(params, np.float64).reshape(-1))
+        ptr = p.ctypes.data_as(_f64p) if p.size else None
+        self._check(self.L.fd_set_kernel(self.ctx, kind, ptr, p.size))
+
+    def set_term(self, term: int):
+        self._check(self.L.fd_set_term(self.ctx, term))
+
+    def build(self, check: bool = True) -> FdReport:
+        rep = FdReport()
+        rc = self.L.fd_build(self.ctx, C.byref(rep))
+        if check:
+            self._check(rc)
+        rep.rc = rc
+        return rep
+
+    def build_async(self):
+        self._check(self.L.fd_build_async(self.ctx))
+
+    def build_result(self, check: bool = True) -> FdReport:
+        rep = FdReport()
+        rc = self.L.fd_build_result(self.ctx, C.byref(rep))
+        if check:
+            self._check(rc)
+        rep.rc = rc
+        return rep
+
+    def deform(self, P, dist2=None, tangents=None, radius2=1.0, falloffrate=1.0, want_falloff=True):
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+        N = P.shape[0]
+        out = P.copy()
+        d2 = None if dist2 is None else np.ascontiguousarray(dist2, np.float32)
+        fall = np.zeros(N, np.float32) if want_falloff else None
+        tu = tv = nr = None
+        if tangents is not None:
+            tu, tv, nr = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in tangents)
+        self._check(self.L.fd_deform(self.ctx, N, _np_ptr(out), _np_ptr(out), _np_ptr(d2), _np_ptr(fall),
+                                     _np_ptr(tu), _np_ptr(tv), _np_ptr(nr), float(radius2),
+                                     float(falloffrate)))
+        return out, fall
+
+    def deform_dev(self, N: int, d_P_in: int, d_P_out: int, d_dist2: int = 0, d_falloff: int = 0,
+                   d_tu: int = 0, d_tv: int = 0, d_nrm: int = 0, radius2=1.0, falloffrate=1.0):
+        vp = C.c_void_p
+        self._check(self.L.fd_deform_dev(self.ctx, N, vp(d_P_in), vp(d_P_out), vp(d_dist2 or None),
+                                         vp(d_falloff or None), vp(d_tu or None), vp(d_tv or None),
+                                         vp(d_nrm or None), float(radius2), float(falloffrate)))
+
+    def get_weights(self):
+        W = np.zeros((self.M + 4, 3), np.float64)
+        radii = np.zeros(max(self.M, 1), np.float64)
+        self._check(self.L.fd_get_weights(self.ctx, W.ctypes.data_as(_f64p), radii.ctypes.data_as(_f64p)))
+        return W, radii[: self.M]
+
+    def model_bytes(self) -> int:
+        return int(self.L.fd_model_bytes(self.ctx))
+
+    def export_model(self) -> np.ndarray:
+        buf = np.zeros(self.model_bytes(), np.uint8)
+        self._check(self.L.fd_export_model(self.ctx, _np_ptr(buf), buf.size, 0))
+        return buf
+
+    def import_model(self, blob: np.ndarray):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        self._check(self.L.fd_import_model(self.ctx, _np_ptr(blob), blob.size, 0))
+        self.M = int(np.frombuffer(blob[:8].tobytes(), np.int32)[1])
+
+    def export_model_dev(self, d_buf: int, capacity: int):
+        self._check(self.L.fd_export_model(self.ctx, C.c_void_p(d_buf), capacity, 1))
+
+    def import_model_dev(self, d_buf: int, nbytes: int, M: int):
+        self._check(self.L.fd_import_model(self.ctx, C.c_void_p(d_buf), nbytes, 1))
+        self.M = M
+
+    def synchronize(self):
+        self._check(self.L.fd_synchronize(self.ctx))

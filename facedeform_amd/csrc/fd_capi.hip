@@ -1,0 +1,563 @@
+// fd_capi.hip -- the C ABI of include/facedeform_hip.h over the HIP kernels.
+// No CPU fallback anywhere: without a gfx950 device fd_create fails loudly.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "fd_internal.h"
+
+using namespace fd;
+
+struct fd_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int eval_precision = FD_EVAL_FP32;
+    int eval_variant = 0;
+
+    // model configuration
+    int M = 0, kind = FD_KERNEL_GAUSSIAN_QNN, term = FD_TERM_LINEAR, nparams = 0;
+    double params[4] = {1.0, 5.0, 0.0, 0.0};
+    bool points_set = false;
+    bool build_pending = false;   // enqueued, status not read back yet
+    bool built = false;           // status read back and == 1
+    bool have_report = false;
+    fd_report report{};
+
+    // device buffers (grow-only)
+    int cap_M = 0;                // capacity in centres
+    int cap_npad = 0;
+    float *d_rest = nullptr, *d_delta = nullptr;
+    double *d_centres = nullptr, *d_radii = nullptr, *d_W = nullptr;
+    double *d_A = nullptr, *d_X = nullptr;
+    int *d_ipiv = nullptr, *d_moves = nullptr;
+    Rec32 *d_rec32 = nullptr;
+    Rec64 *d_rec64 = nullptr;
+    DevModel *d_model = nullptr;
+    DevModel *h_model = nullptr;  // pinned mirror
+    ModelHeader *h_header = nullptr;  // pinned, for device-side export
+
+    // staging for the host-pointer deform
+    int64_t cap_N = 0;
+    float *d_P = nullptr, *d_dist2 = nullptr, *d_fall = nullptr;
+    float *d_tu = nullptr, *d_tv = nullptr, *d_nrm = nullptr;
+
+    hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
+    char err[512] = {0};
+};
+
+static thread_local char g_err[512] = {0};
+
+static void set_err(fd_ctx *ctx, const char *fmt, ...)
+{
+    char *dst = ctx ? ctx->err : g_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+}
+
+#define FD_HIP(ctx, call)                                                               \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            set_err(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FD_E_DEVICE;                                                         \
+        }                                                                               \
+    } while (0)
+
+static int use_device(fd_ctx *ctx)
+{
+    int cur = -1;
+    FD_HIP(ctx, hipGetDevice(&cur));
+    if (cur != ctx->device) FD_HIP(ctx, hipSetDevice(ctx->device));
+    return FD_OK;
+}
+
+template <typename T>
+static int dev_alloc(fd_ctx *ctx, T **p, size_t count)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        set_err(ctx, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return FD_E_NOMEM;
+    }
+    return FD_OK;
+}
+
+static int order_of(const fd_ctx *ctx) { return ctx->M + term_cols(ctx->term); }
+
+static int ensure_model_capacity(fd_ctx *ctx, int M)
+{
+    int rc;
+    if (M > ctx->cap_M) {
+        const int Mpad = round_up(M, kRecPad);
+        if ((rc = dev_alloc(ctx, &ctx->d_rest, (size_t)M * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_delta, (size_t)M * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_centres, (size_t)M * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_radii, (size_t)M))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_W, (size_t)(M + 4) * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_rec32, (size_t)Mpad))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_rec64, (size_t)Mpad))) return rc;
+        ctx->cap_M = M;
+    }
+    return FD_OK;
+}
+
+static int ensure_solver_capacity(fd_ctx *ctx, int npad)
+{
+    int rc;
+    if (npad > ctx->cap_npad) {
+        const size_t cols = (size_t)npad + kRhsCols + 16;  // + 16 zero columns (block overrun)
+        if ((rc = dev_alloc(ctx, &ctx->d_A, (size_t)npad * cols))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_X, (size_t)npad * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_ipiv, (size_t)npad))) return rc;
+        if (!ctx->d_moves && (rc = dev_alloc(ctx, &ctx->d_moves, (size_t)512))) return rc;
+        ctx->cap_npad = npad;
+    }
+    return FD_OK;
+}
+
+extern "C" {
+
+int fd_abi_version(void) { return FD_ABI_VERSION; }
+
+const char *fd_last_error(const fd_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+fd_ctx *fd_create(const fd_config *cfg)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_err(nullptr, "fd_create: no HIP device visible (%s); this engine has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+        return nullptr;
+    }
+    fd_ctx *ctx = new (std::nothrow) fd_ctx();
+    if (!ctx) { set_err(nullptr, "fd_create: out of host memory"); return nullptr; }
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) {
+        set_err(nullptr, "fd_create: device %d out of range (%d visible)", dev, ndev);
+        delete ctx;
+        return nullptr;
+    }
+    ctx->device = dev;
+    if (cfg) {
+        ctx->eval_precision = cfg->eval_precision == FD_EVAL_FP64 ? FD_EVAL_FP64 : FD_EVAL_FP32;
+        ctx->eval_variant = cfg->eval_variant;
+    }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        set_err(nullptr, "fd_create: cannot query device %d", dev);
+        delete ctx;
+        return nullptr;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(nullptr, "fd_create: device %d is %s; kernels are built for gfx950 (MI355X) only",
+                dev, prop.gcnArchName);
+        delete ctx;
+        return nullptr;
+    }
+    bool ok = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev_mid) == hipSuccess &&
+         hipEventCreate(&ctx->ev1) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_model, sizeof(DevModel)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_model, sizeof(DevModel), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_header, sizeof(ModelHeader), hipHostMallocDefault) == hipSuccess;
+    if (ok) ok = hipMemset(ctx->d_model, 0, sizeof(DevModel)) == hipSuccess;
+    if (!ok) {
+        set_err(nullptr, "fd_create: device resource allocation failed: %s",
+                hipGetErrorString(hipGetLastError()));
+        fd_destroy(ctx);
+        return nullptr;
+    }
+    ctx->stream = ctx->own_stream;
+    return ctx;
+}
+
+void fd_destroy(fd_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void *bufs[] = {ctx->d_rest, ctx->d_delta, ctx->d_centres, ctx->d_radii, ctx->d_W, ctx->d_A,
+                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_model,
+                    ctx->d_P, ctx->d_dist2, ctx->d_fall, ctx->d_tu, ctx->d_tv, ctx->d_nrm};
+    for (void *p : bufs) if (p) (void)hipFree(p);
+    if (ctx->h_model) (void)hipHostFree(ctx->h_model);
+    if (ctx->h_header) (void)hipHostFree(ctx->h_header);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int fd_set_stream(fd_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return FD_E_INVALID;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return FD_OK;
+}
+
+int fd_synchronize(fd_ctx *ctx)
+{
+    if (!ctx) return FD_E_INVALID;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FD_OK;
+}
+
+static int set_points_common(fd_ctx *ctx, const float *rest, const float *delta, int M, bool on_device)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (!rest || !delta || M <= 0) { set_err(ctx, "fd_set_points: need M > 0 and both arrays"); return FD_E_INVALID; }
+    if (M + 4 > kMaxOrder) { set_err(ctx, "fd_set_points: M = %d exceeds the supported %d", M, kMaxOrder - 4); return FD_E_INVALID; }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if ((rc = ensure_model_capacity(ctx, M))) return rc;
+    const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_rest, rest, sizeof(float) * 3 * (size_t)M, k, ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_delta, delta, sizeof(float) * 3 * (size_t)M, k, ctx->stream));
+    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its arrays
+    ctx->M = M;
+    ctx->points_set = true;
+    ctx->built = false;
+    ctx->build_pending = false;
+    return FD_OK;
+}
+
+int fd_set_points(fd_ctx *ctx, const float *rest_xyz, const float *delta_xyz, int M)
+{
+    return set_points_common(ctx, rest_xyz, delta_xyz, M, false);
+}
+
+int fd_set_points_dev(fd_ctx *ctx, const float *d_rest_xyz, const float *d_delta_xyz, int M)
+{
+    return set_points_common(ctx, d_rest_xyz, d_delta_xyz, M, true);
+}
+
+int fd_set_kernel(fd_ctx *ctx, int kind, const double *params, int nparams)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (kind < FD_KERNEL_GAUSSIAN || kind > FD_KERNEL_CUBIC || nparams < 0 || nparams > 4 ||
+        (nparams > 0 && !params)) {
+        set_err(ctx, "fd_set_kernel: bad kind %d / nparams %d", kind, nparams);
+        return FD_E_INVALID;
+    }
+    double p[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nparams; ++i) p[i] = params[i];
+    if (kind == FD_KERNEL_GAUSSIAN) {
+        if (nparams < 1) p[0] = 1.0;
+        if (!(p[0] > 0.0)) { set_err(ctx, "fd_set_kernel: Gaussian radius must be > 0"); return FD_E_INVALID; }
+    } else if (kind == FD_KERNEL_GAUSSIAN_QNN) {
+        if (nparams < 1) p[0] = 1.0;
+        if (nparams < 2) p[1] = 5.0;
+        if (!(p[0] > 0.0) || !(p[1] > 0.0)) { set_err(ctx, "fd_set_kernel: q and z must be > 0"); return FD_E_INVALID; }
+    }
+    ctx->kind = kind;
+    ctx->nparams = nparams;
+    memcpy(ctx->params, p, sizeof(p));
+    ctx->built = false;
+    ctx->build_pending = false;
+    return FD_OK;
+}
+
+int fd_set_term(fd_ctx *ctx, int term)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (term < FD_TERM_LINEAR || term > FD_TERM_ZERO) { set_err(ctx, "fd_set_term: bad term %d", term); return FD_E_INVALID; }
+    ctx->term = term;
+    ctx->built = false;
+    ctx->build_pending = false;
+    return FD_OK;
+}
+
+static double ctx_lambda(const fd_ctx *ctx)
+{
+    const int idx = ctx->kind == FD_KERNEL_GAUSSIAN ? 1 : (ctx->kind == FD_KERNEL_GAUSSIAN_QNN ? 2 : 0);
+    return ctx->nparams > idx ? ctx->params[idx] : 0.0;
+}
+
+static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
+{
+    b.M = ctx->M;
+    b.T = term_cols(ctx->term);
+    b.n = order_of(ctx);
+    b.npad = round_up(b.n, 32);
+    b.lda = b.npad;
+    b.ncols = b.npad + kRhsCols;
+    b.kind = ctx->kind;
+    b.term = ctx->term;
+    b.lambda = ctx_lambda(ctx);
+    b.gauss_R = ctx->kind == FD_KERNEL_GAUSSIAN ? ctx->params[0] : 1.0;
+    b.qnn_q = ctx->params[0];
+    b.qnn_z = ctx->params[1];
+    b.d_rest = ctx->d_rest; b.d_delta = ctx->d_delta;
+    b.d_centres = ctx->d_centres; b.d_radii = ctx->d_radii;
+    b.d_A = ctx->d_A; b.d_X = ctx->d_X;
+    b.d_ipiv = ctx->d_ipiv; b.d_moves = ctx->d_moves;
+    b.d_W = ctx->d_W;
+    b.d_rec32 = ctx->d_rec32; b.d_rec64 = ctx->d_rec64;
+    b.Mpad = round_up(ctx->M, kRecPad);
+    b.d_model = ctx->d_model;
+}
+
+int fd_build_async(fd_ctx *ctx)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (!ctx->points_set) { set_err(ctx, "fd_build: fd_set_points has not been called"); return FD_E_INVALID; }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const int npad = round_up(order_of(ctx), 32);
+    const bool grew = npad > ctx->cap_npad;
+    if ((rc = ensure_solver_capacity(ctx, npad))) return rc;
+    BuildBuffers b;
+    fill_build_buffers(ctx, b);
+    if (grew) {
+        // the 16 overrun columns past the RHS block must read as zero forever
+        const size_t cols = (size_t)ctx->cap_npad + kRhsCols + 16;
+        FD_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, sizeof(double) * (size_t)ctx->cap_npad * cols, ctx->stream));
+    } else {
+        FD_HIP(ctx, hipMemsetAsync(ctx->d_A + (size_t)b.lda * b.ncols, 0, sizeof(double) * (size_t)b.lda * 16,
+                                   ctx->stream));
+    }
+    FD_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    FD_HIP(ctx, launch_build(b, ctx->stream, ctx->ev_mid));
+    FD_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->build_pending = true;
+    ctx->built = false;
+    ctx->have_report = false;
+    return FD_OK;
+}
+
+int fd_build_result(fd_ctx *ctx, fd_report *report)
+{
+    if (!ctx) return FD_E_INVALID;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (ctx->build_pending) {
+        FD_HIP(ctx, hipMemcpyAsync(ctx->h_model, ctx->d_model, sizeof(DevModel), hipMemcpyDeviceToHost, ctx->stream));
+        FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        fd_report r{};
+        r.terminationtype = ctx->h_model->terminationtype;
+        r.iterationscount = ctx->h_model->iterations;
+        r.n = order_of(ctx);
+        double pmin, pmax;
+        memcpy(&pmin, &ctx->h_model->pivmin_bits, 8);
+        memcpy(&pmax, &ctx->h_model->pivmax_bits, 8);
+        r.pivot_ratio = (pmax > 0.0 && pmin <= pmax) ? pmin / pmax : 0.0;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_mid) == hipSuccess) r.t_assemble_ms = ms;
+        if (hipEventElapsedTime(&ms, ctx->ev_mid, ctx->ev1) == hipSuccess) r.t_solve_ms = ms;
+        ctx->report = r;
+        ctx->have_report = true;
+        ctx->build_pending = false;
+        ctx->built = r.terminationtype == 1;
+    }
+    if (!ctx->have_report) { set_err(ctx, "fd_build_result: no build has been enqueued"); return FD_E_NOT_BUILT; }
+    if (report) *report = ctx->report;
+    if (ctx->report.terminationtype == 1) return FD_OK;
+    if (ctx->report.terminationtype == -5) { set_err(ctx, "fd_build: coincident control points"); return FD_E_DUPLICATE; }
+    set_err(ctx, "fd_build: singular system (terminationtype %d)", ctx->report.terminationtype);
+    return FD_E_SINGULAR;
+}
+
+int fd_build(fd_ctx *ctx, fd_report *report)
+{
+    int rc = fd_build_async(ctx);
+    if (rc) {
+        if (report) { memset(report, 0, sizeof(*report)); report->terminationtype = -4; }
+        return rc;
+    }
+    return fd_build_result(ctx, report);
+}
+
+int fd_deform_dev(fd_ctx *ctx, int64_t N, const float *d_P_in, float *d_P_out, const float *d_dist2,
+                  float *d_falloff_out, const float *d_tu, const float *d_tv, const float *d_nrm,
+                  float radius2, float falloffrate)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (N < 0 || (N > 0 && (!d_P_in || !d_P_out))) { set_err(ctx, "fd_deform: bad N / P pointers"); return FD_E_INVALID; }
+    const int ntan = (d_tu != nullptr) + (d_tv != nullptr) + (d_nrm != nullptr);
+    if (ntan != 0 && ntan != 3) { set_err(ctx, "fd_deform: tu, tv, nrm must be all set or all NULL"); return FD_E_INVALID; }
+    if (!ctx->built && !ctx->build_pending) { set_err(ctx, "fd_deform: no successfully built model"); return FD_E_NOT_BUILT; }
+    if (N == 0) return FD_OK;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    DeformArgs a;
+    a.N = N;
+    a.P_in = d_P_in; a.P_out = d_P_out;
+    a.dist2 = d_dist2; a.falloff_out = d_falloff_out;
+    a.tu = d_tu; a.tv = d_tv; a.nrm = d_nrm;
+    a.radius2 = radius2; a.falloffrate = falloffrate;
+    a.M = ctx->M; a.Mpad = round_up(ctx->M, kRecPad); a.kind = ctx->kind;
+    a.rec32 = ctx->d_rec32; a.rec64 = ctx->d_rec64;
+    a.model = ctx->d_model;
+    a.precision = ctx->eval_precision;
+    a.variant = ctx->eval_variant;
+    FD_HIP(ctx, launch_deform(a, ctx->stream));
+    return FD_OK;
+}
+
+int fd_deform(fd_ctx *ctx, int64_t N, const float *P_in, float *P_out, const float *dist2,
+              float *falloff_out, const float *tu, const float *tv, const float *nrm, float radius2,
+              float falloffrate)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (N < 0 || (N > 0 && (!P_in || !P_out))) { set_err(ctx, "fd_deform: bad N / P pointers"); return FD_E_INVALID; }
+    const int ntan = (tu != nullptr) + (tv != nullptr) + (nrm != nullptr);
+    if (ntan != 0 && ntan != 3) { set_err(ctx, "fd_deform: tu, tv, nrm must be all set or all NULL"); return FD_E_INVALID; }
+    if (!ctx->built && !ctx->build_pending) { set_err(ctx, "fd_deform: no successfully built model"); return FD_E_NOT_BUILT; }
+    if (N == 0) return FD_OK;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (N > ctx->cap_N) {
+        if ((rc = dev_alloc(ctx, &ctx->d_P, (size_t)N * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_dist2, (size_t)N))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_fall, (size_t)N))) return rc;
+        // tangent frames are optional and 3x as large: allocate on first use
+        if (ctx->d_tu) { (void)hipFree(ctx->d_tu); ctx->d_tu = nullptr; }
+        if (ctx->d_tv) { (void)hipFree(ctx->d_tv); ctx->d_tv = nullptr; }
+        if (ctx->d_nrm) { (void)hipFree(ctx->d_nrm); ctx->d_nrm = nullptr; }
+        ctx->cap_N = N;
+    }
+    if (tu && !ctx->d_tu) {
+        if ((rc = dev_alloc(ctx, &ctx->d_tu, (size_t)ctx->cap_N * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_tv, (size_t)ctx->cap_N * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_nrm, (size_t)ctx->cap_N * 3))) return rc;
+    }
+    hipStream_t s = ctx->stream;
+    const size_t b3 = sizeof(float) * 3 * (size_t)N, b1 = sizeof(float) * (size_t)N;
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_P, P_in, b3, hipMemcpyHostToDevice, s));
+    if (dist2) FD_HIP(ctx, hipMemcpyAsync(ctx->d_dist2, dist2, b1, hipMemcpyHostToDevice, s));
+    if (falloff_out) FD_HIP(ctx, hipMemcpyAsync(ctx->d_fall, falloff_out, b1, hipMemcpyHostToDevice, s));
+    if (tu) {
+        FD_HIP(ctx, hipMemcpyAsync(ctx->d_tu, tu, b3, hipMemcpyHostToDevice, s));
+        FD_HIP(ctx, hipMemcpyAsync(ctx->d_tv, tv, b3, hipMemcpyHostToDevice, s));
+        FD_HIP(ctx, hipMemcpyAsync(ctx->d_nrm, nrm, b3, hipMemcpyHostToDevice, s));
+    }
+    rc = fd_deform_dev(ctx, N, ctx->d_P, ctx->d_P, dist2 ? ctx->d_dist2 : nullptr,
+                       falloff_out ? ctx->d_fall : nullptr, tu ? ctx->d_tu : nullptr,
+                       tu ? ctx->d_tv : nullptr, tu ? ctx->d_nrm : nullptr, radius2, falloffrate);
+    if (rc) return rc;
+    FD_HIP(ctx, hipMemcpyAsync(P_out, ctx->d_P, b3, hipMemcpyDeviceToHost, s));
+    if (falloff_out) FD_HIP(ctx, hipMemcpyAsync(falloff_out, ctx->d_fall, b1, hipMemcpyDeviceToHost, s));
+    FD_HIP(ctx, hipStreamSynchronize(s));
+    return FD_OK;
+}
+
+static int require_built(fd_ctx *ctx, const char *who)
+{
+    if (ctx->build_pending) {
+        int rc = fd_build_result(ctx, nullptr);
+        if (rc) return rc;
+    }
+    if (!ctx->built) { set_err(ctx, "%s: no successfully built model", who); return FD_E_NOT_BUILT; }
+    return FD_OK;
+}
+
+int fd_get_weights(fd_ctx *ctx, double *W, double *radii)
+{
+    if (!ctx || !W) return FD_E_INVALID;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if ((rc = require_built(ctx, "fd_get_weights"))) return rc;
+    FD_HIP(ctx, hipMemcpyAsync(W, ctx->d_W, sizeof(double) * 3 * (size_t)(ctx->M + 4), hipMemcpyDeviceToHost, ctx->stream));
+    if (radii) FD_HIP(ctx, hipMemcpyAsync(radii, ctx->d_radii, sizeof(double) * (size_t)ctx->M, hipMemcpyDeviceToHost, ctx->stream));
+    FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FD_OK;
+}
+
+static size_t model_bytes_for(int M)
+{
+    return sizeof(ModelHeader) + sizeof(double) * ((size_t)M * 3 + (size_t)M + (size_t)(M + 4) * 3);
+}
+
+size_t fd_model_bytes(const fd_ctx *ctx) { return ctx ? model_bytes_for(ctx->M) : 0; }
+
+int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device)
+{
+    if (!ctx || !buf) return FD_E_INVALID;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if ((rc = require_built(ctx, "fd_export_model"))) return rc;
+    const int M = ctx->M;
+    if (capacity < model_bytes_for(M)) { set_err(ctx, "fd_export_model: buffer too small"); return FD_E_INVALID; }
+    // the pinned header may still be the source of an earlier in-flight copy
+    FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ModelHeader *h = ctx->h_header;
+    memset(h, 0, sizeof(*h));
+    h->magic = kModelMagic;
+    h->M = M; h->kind = ctx->kind; h->term = ctx->term; h->nparams = ctx->nparams;
+    h->terminationtype = 1;
+    memcpy(h->params, ctx->params, sizeof(h->params));
+    char *p = (char *)buf;
+    const hipMemcpyKind kh = on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
+    const hipMemcpyKind kd = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    FD_HIP(ctx, hipMemcpyAsync(p, h, sizeof(*h), kh, ctx->stream));
+    p += sizeof(*h);
+    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_centres, sizeof(double) * 3 * (size_t)M, kd, ctx->stream));
+    p += sizeof(double) * 3 * (size_t)M;
+    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_radii, sizeof(double) * (size_t)M, kd, ctx->stream));
+    p += sizeof(double) * (size_t)M;
+    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_W, sizeof(double) * 3 * (size_t)(M + 4), kd, ctx->stream));
+    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FD_OK;
+}
+
+int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
+{
+    if (!ctx || !buf || bytes < sizeof(ModelHeader)) return FD_E_INVALID;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    ModelHeader h;
+    if (on_device) {
+        FD_HIP(ctx, hipMemcpyAsync(ctx->h_header, buf, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        h = *ctx->h_header;
+    } else {
+        memcpy(&h, buf, sizeof(h));
+    }
+    if (h.magic != kModelMagic || h.M <= 0 || h.M + 4 > kMaxOrder || h.kind < 0 || h.kind > FD_KERNEL_CUBIC ||
+        h.term < 0 || h.term > 2 || h.terminationtype != 1 || bytes < model_bytes_for(h.M)) {
+        set_err(ctx, "fd_import_model: not a valid model blob");
+        return FD_E_INVALID;
+    }
+    const int M = h.M;
+    if ((rc = ensure_model_capacity(ctx, M))) return rc;
+    ctx->M = M; ctx->kind = h.kind; ctx->term = h.term; ctx->nparams = h.nparams;
+    memcpy(ctx->params, h.params, sizeof(h.params));
+    const char *p = (const char *)buf + sizeof(ModelHeader);
+    const hipMemcpyKind kd = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_centres, p, sizeof(double) * 3 * (size_t)M, kd, ctx->stream));
+    p += sizeof(double) * 3 * (size_t)M;
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_radii, p, sizeof(double) * (size_t)M, kd, ctx->stream));
+    p += sizeof(double) * (size_t)M;
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_W, p, sizeof(double) * 3 * (size_t)(M + 4), kd, ctx->stream));
+    BuildBuffers b;
+    fill_build_buffers(ctx, b);
+    FD_HIP(ctx, launch_pack_from_weights(b, ctx->stream));
+    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->points_set = false;   // no rest/delta on this context: it can deform, not rebuild
+    ctx->build_pending = false;
+    ctx->built = true;
+    fd_report r{};
+    r.terminationtype = 1;
+    r.n = order_of(ctx);
+    ctx->report = r;
+    ctx->have_report = true;
+    return FD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// fd_eval.hip -- per-vertex RBF evaluation with the reference's fused epilogue.
+//
+// Replaces the loop body of SOP_FaceDeform::cookMySop,
+// reference src/SOP_FaceDeform.cpp:404-439 (gate, rbfcalc, project_to_tangents,
+// fall-off, write-back) with one gfx950 kernel.
+//
+// Mapping to the hardware
+//   * one lane owns V vertices (registers: position + 3 accumulators each); a
+//     256-thread workgroup covers 256*V consecutive vertices, so every global
+//     access of a wave is one contiguous 768 B (P) or 256 B (dist2/falloff) span;
+//   * the control data is wave-uniform.  Variant SCALAR streams the 32 B centre
+//     records through the scalar unit (s_load_dwordx8 -> SGPR operands: no VGPRs,
+//     no LDS bandwidth, no VALU cost); variant LDS stages a tile of records in
+//     LDS once per workgroup and broadcast-reads it (ds_read_b128, one address
+//     for all 64 lanes);
+//   * per (vertex, centre) pair: 3 sub, 3 fma (d2), one transcendental
+//     (v_log_f32 / v_exp_f32 / v_sqrt_f32), 1 mul, 3 fma.  The kernel constant
+//     (0.5*ln2 for thin-plate, ...) is folded into the weights by the pack kernel;
+//   * fp32 partial sums are folded into fp64 accumulators every 64 centres, which
+//     bounds the accumulation error independently of M.
+//   * FP64 variant: same structure, all arithmetic in fp64.
+#include "fd_internal.h"
+
+namespace fd {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kChunk = 64;  // centres per fp32 partial sum
+
+typedef const __attribute__((address_space(4))) Rec32 *ConstRec32;
+typedef const __attribute__((address_space(4))) Rec64 *ConstRec64;
+
+struct EvalParams {
+    int64_t N;
+    const float *P_in;
+    float *P_out;
+    const float *dist2;
+    float *falloff_out;
+    const float *tu, *tv, *nrm;
+    float radius2, falloffrate;
+    int Mpad;
+    const Rec32 *rec32;
+    const Rec64 *rec64;
+    const DevModel *model;
+};
+
+// ---- kernels phi'(d2) (constant factors live in the packed weights) ----------
+template <int KIND>
+__device__ __forceinline__ float phi32(float d2, float s)
+{
+    if constexpr (KIND == FD_KERNEL_THIN_PLATE) {
+        return d2 * __builtin_amdgcn_logf(d2);        // d2*log2(d2); d2 carries +1e-37
+    } else if constexpr (KIND == FD_KERNEL_GAUSSIAN || KIND == FD_KERNEL_GAUSSIAN_QNN) {
+        return __builtin_amdgcn_exp2f(d2 * s);        // s = -log2(e)/R_j^2
+    } else if constexpr (KIND == FD_KERNEL_BIHARMONIC) {
+        return __builtin_amdgcn_sqrtf(d2);
+    } else {
+        return d2 * __builtin_amdgcn_sqrtf(d2);
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ double phi64(double d2, double s)
+{
+    if constexpr (KIND == FD_KERNEL_THIN_PLATE) {
+        return d2 > 0.0 ? d2 * log(d2) : 0.0;         // weights carry the 0.5
+    } else if constexpr (KIND == FD_KERNEL_GAUSSIAN || KIND == FD_KERNEL_GAUSSIAN_QNN) {
+        return exp(d2 * s);                           // s = -1/R_j^2
+    } else if constexpr (KIND == FD_KERNEL_BIHARMONIC) {
+        return sqrt(d2);
+    } else {
+        return d2 * sqrt(d2);
+    }
+}
+
+// thin-plate only: keeps log2 finite at d2 == 0 (phi -> -1.2e-35, i.e. 0) at no cost,
+// because it rides in the first fma of the distance.
+template <int KIND>
+__device__ __forceinline__ constexpr float d2_bias()
+{
+    return KIND == FD_KERNEL_THIN_PLATE ? 1e-37f : 0.f;
+}
+
+// ---- fp32 epilogue, same operation order as the reference -------------------
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z)
+{
+    const float l2 = x * x + y * y + z * z;
+    if (l2 > 0.f) {
+        const float inv = 1.f / sqrtf(l2);
+        x *= inv; y *= inv; z *= inv;
+    }
+}
+
+// reference src/SOP_FaceDeform.hpp:28-41
+__device__ __forceinline__ void project_to_tangents(const float u[3], const float v[3],
+                                                    const float n[3], float d[3])
+{
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g[i][j] = u[i] * u[j] + v[i] * v[j] + n[i] * n[j];
+    float a1[3], a2[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        a1[j] = u[0] * g[0][j] + u[1] * g[1][j] + u[2] * g[2][j];
+        a2[j] = v[0] * g[0][j] + v[1] * g[1][j] + v[2] * g[2][j];
+    }
+    normalize3(a1[0], a1[1], a1[2]);
+    normalize3(a2[0], a2[1], a2[2]);
+    const float da1 = d[0] * a1[0] + d[1] * a1[1] + d[2] * a1[2];
+    const float da2 = d[0] * a2[0] + d[1] * a2[1] + d[2] * a2[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = a1[c] * da1 + a2[c] * da2;
+}
+
+// gate (:405-410) is decided by the caller; this is :415-438 for one vertex
+__device__ __forceinline__ void epilogue_store(const EvalParams &p, int64_t i, const float pos[3],
+                                               float disp[3], float dist2)
+{
+    if (p.tu) {
+        float u[3] = {p.tu[3 * i], p.tu[3 * i + 1], p.tu[3 * i + 2]};
+        float v[3] = {p.tv[3 * i], p.tv[3 * i + 1], p.tv[3 * i + 2]};
+        float n[3] = {p.nrm[3 * i], p.nrm[3 * i + 1], p.nrm[3 * i + 2]};
+        normalize3(u[0], u[1], u[2]);
+        normalize3(v[0], v[1], v[2]);
+        normalize3(n[0], n[1], n[2]);
+        project_to_tangents(u, v, n, disp);
+    }
+    float falloff = fminf(dist2 / p.radius2, 1.f);
+    falloff = powf(1.f - falloff, p.falloffrate);
+    if (p.falloff_out) p.falloff_out[i] = falloff;
+    p.P_out[3 * i] = pos[0] + disp[0] * falloff;
+    p.P_out[3 * i + 1] = pos[1] + disp[1] * falloff;
+    p.P_out[3 * i + 2] = pos[2] + disp[2] * falloff;
+}
+
+// ---- fp32 evaluation ----------------------------------------------------------
+template <int KIND, int V, bool USE_LDS>
+__global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * V);
+
+    float px[V], py[V], pz[V], d2v[V];
+    bool live[V];
+    bool any_live = false;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int64_t i = base + v * kBlock + tid;
+        const int64_t ic = i < p.N ? i : p.N - 1;
+        px[v] = p.P_in[3 * ic];
+        py[v] = p.P_in[3 * ic + 1];
+        pz[v] = p.P_in[3 * ic + 2];
+        d2v[v] = p.dist2 ? p.dist2[ic] : 0.f;
+        live[v] = (i < p.N) && !(d2v[v] > p.radius2);   // gate on squares, :402,:408
+        any_live |= live[v];
+    }
+    const bool built = p.model->terminationtype == 1;
+
+    double accx[V], accy[V], accz[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        // affine part V*[1;x] first (rows M..M+3 of the weights)
+        const float *a = p.model->affine32;
+        accx[v] = (double)(a[0] + a[1] * px[v] + a[2] * py[v] + a[3] * pz[v]);
+        accy[v] = (double)(a[4] + a[5] * px[v] + a[6] * py[v] + a[7] * pz[v]);
+        accz[v] = (double)(a[8] + a[9] * px[v] + a[10] * py[v] + a[11] * pz[v]);
+    }
+
+    // wave-uniform skip: every vertex of this wave is gated out or out of range
+    const bool wave_work = __any(any_live) && built;
+
+    if constexpr (USE_LDS) {
+        // stage all records once per workgroup (16 B per lane, coalesced)
+        const int n16 = p.Mpad * 2;
+        const float4 *src = reinterpret_cast<const float4 *>(p.rec32);
+        float4 *dst = reinterpret_cast<float4 *>(smem);
+        for (int q = tid; q < n16; q += kBlock) dst[q] = src[q];
+        __syncthreads();
+    }
+
+    if (wave_work) {
+        for (int j0 = 0; j0 < p.Mpad; j0 += kChunk) {
+            const int jend = (j0 + kChunk < p.Mpad) ? j0 + kChunk : p.Mpad;
+            float ax[V], ay[V], az[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) ax[v] = ay[v] = az[v] = 0.f;
+#pragma unroll 8
+            for (int j = j0; j < jend; ++j) {
+                float cx, cy, cz, s, wx, wy, wz;
+                if constexpr (USE_LDS) {
+                    const float4 *r = reinterpret_cast<const float4 *>(smem) + 2 * j;
+                    const float4 r0 = r[0], r1 = r[1];
+                    cx = r0.x; cy = r0.y; cz = r0.z; s = r0.w;
+                    wx = r1.x; wy = r1.y; wz = r1.z;
+                } else {
+                    ConstRec32 r = (ConstRec32)(uintptr_t)(p.rec32 + j);
+                    cx = r->cx; cy = r->cy; cz = r->cz; s = r->s;
+                    wx = r->wx; wy = r->wy; wz = r->wz;
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float dx = px[v] - cx;
+                    const float dy = py[v] - cy;
+                    const float dz = pz[v] - cz;
+                    float d2 = __builtin_fmaf(dx, dx, d2_bias<KIND>());
+                    d2 = __builtin_fmaf(dy, dy, d2);
+                    d2 = __builtin_fmaf(dz, dz, d2);
+                    const float t = phi32<KIND>(d2, s);
+                    ax[v] = __builtin_fmaf(t, wx, ax[v]);
+                    ay[v] = __builtin_fmaf(t, wy, ay[v]);
+                    az[v] = __builtin_fmaf(t, wz, az[v]);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                accx[v] += (double)ax[v];
+                accy[v] += (double)ay[v];
+                accz[v] += (double)az[v];
+            }
+        }
+    }
+
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int64_t i = base + v * kBlock + tid;
+        if (i >= p.N) continue;
+        const float pos[3] = {px[v], py[v], pz[v]};
+        if (!live[v] || !built) {
+            if (p.P_out != p.P_in) {
+                p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
+            }
+            continue;
+        }
+        float disp[3] = {(float)accx[v], (float)accy[v], (float)accz[v]};
+        epilogue_store(p, i, pos, disp, d2v[v]);
+    }
+}
+
+// ---- fp64 evaluation ----------------------------------------------------------
+template <int KIND, int V>
+__global__ __launch_bounds__(kBlock) void k_deform64(const EvalParams p)
+{
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * V);
+    float pxf[V], pyf[V], pzf[V], d2v[V];
+    bool live[V];
+    bool any_live = false;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int64_t i = base + v * kBlock + tid;
+        const int64_t ic = i < p.N ? i : p.N - 1;
+        pxf[v] = p.P_in[3 * ic];
+        pyf[v] = p.P_in[3 * ic + 1];
+        pzf[v] = p.P_in[3 * ic + 2];
+        d2v[v] = p.dist2 ? p.dist2[ic] : 0.f;
+        live[v] = (i < p.N) && !(d2v[v] > p.radius2);
+        any_live |= live[v];
+    }
+    const bool built = p.model->terminationtype == 1;
+    double accx[V], accy[V], accz[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const double *a = p.model->affine64;
+        const double x = pxf[v], y = pyf[v], z = pzf[v];
+        accx[v] = a[0] + a[1] * x + a[2] * y + a[3] * z;
+        accy[v] = a[4] + a[5] * x + a[6] * y + a[7] * z;
+        accz[v] = a[8] + a[9] * x + a[10] * y + a[11] * z;
+    }
+    if (__any(any_live) && built) {
+#pragma unroll 2
+        for (int j = 0; j < p.Mpad; ++j) {
+            ConstRec64 r = (ConstRec64)(uintptr_t)(p.rec64 + j);
+            const double cx = r->cx, cy = r->cy, cz = r->cz, s = r->s;
+            const double wx = r->wx, wy = r->wy, wz = r->wz;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double dx = (double)pxf[v] - cx;
+                const double dy = (double)pyf[v] - cy;
+                const double dz = (double)pzf[v] - cz;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                const double t = phi64<KIND>(d2, s);
+                accx[v] += t * wx;
+                accy[v] += t * wy;
+                accz[v] += t * wz;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int64_t i = base + v * kBlock + tid;
+        if (i >= p.N) continue;
+        const float pos[3] = {pxf[v], pyf[v], pzf[v]};
+        if (!live[v] || !built) {
+            if (p.P_out != p.P_in) {
+                p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
+            }
+            continue;
+        }
+        float disp[3] = {(float)accx[v], (float)accy[v], (float)accz[v]};
+        epilogue_store(p, i, pos, disp, d2v[v]);
+    }
+}
+
+template <int KIND>
+hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t stream)
+{
+    if (a.N <= 0) return hipSuccess;
+    if (a.precision == FD_EVAL_FP64) {
+        constexpr int V = 2;
+        const int64_t per = (int64_t)kBlock * V;
+        const unsigned grid = (unsigned)((a.N + per - 1) / per);
+        hipLaunchKernelGGL((k_deform64<KIND, V>), dim3(grid), dim3(kBlock), 0, stream, p);
+        return hipGetLastError();
+    }
+    constexpr int V = 4;
+    const int64_t per = (int64_t)kBlock * V;
+    const unsigned grid = (unsigned)((a.N + per - 1) / per);
+    const size_t lds_bytes = (size_t)a.Mpad * sizeof(Rec32);
+    // variant 2 = LDS-staged records (only while one tile holds them all)
+    if (a.variant == 2 && lds_bytes <= 64 * 1024) {
+        hipLaunchKernelGGL((k_deform32<KIND, V, true>), dim3(grid), dim3(kBlock), lds_bytes, stream, p);
+    } else {
+        hipLaunchKernelGGL((k_deform32<KIND, V, false>), dim3(grid), dim3(kBlock), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_deform(const DeformArgs &a, hipStream_t stream)
+{
+    EvalParams p;
+    p.N = a.N;
+    p.P_in = a.P_in; p.P_out = a.P_out;
+    p.dist2 = a.dist2; p.falloff_out = a.falloff_out;
+    p.tu = a.tu; p.tv = a.tv; p.nrm = a.nrm;
+    p.radius2 = a.radius2; p.falloffrate = a.falloffrate;
+    p.Mpad = a.Mpad;
+    p.rec32 = a.rec32; p.rec64 = a.rec64;
+    p.model = a.model;
+    switch (a.kind) {
+    case FD_KERNEL_GAUSSIAN:
+    case FD_KERNEL_GAUSSIAN_QNN: return launch_kind<FD_KERNEL_GAUSSIAN>(a, p, stream);
+    case FD_KERNEL_THIN_PLATE: return launch_kind<FD_KERNEL_THIN_PLATE>(a, p, stream);
+    case FD_KERNEL_BIHARMONIC: return launch_kind<FD_KERNEL_BIHARMONIC>(a, p, stream);
+    case FD_KERNEL_CUBIC: return launch_kind<FD_KERNEL_CUBIC>(a, p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+const char *deform_kernel_name(int kind, int precision, int variant)
+{
+    (void)kind;
+    if (precision == FD_EVAL_FP64) return "k_deform64";
+    return variant == 2 ? "k_deform32<LDS>" : "k_deform32<SCALAR>";
+}
+
+}  // namespace fd

@@ -1,0 +1,100 @@
+// fd_internal.h -- shared declarations of the gfx950 RBF deformation engine.
+// Not part of the ABI (that is include/facedeform_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/facedeform_hip.h"
+
+namespace fd {
+
+// ---- solved model as the evaluation kernels read it --------------------------
+// One record per centre, 32 B: the unit a scalar s_load_dwordx8 fetches.
+//   s  = per-centre kernel scale (Gaussian: -log2(e)/R_j^2, otherwise 0)
+//   w* = RBF weight pre-multiplied by the kernel's constant factor
+//        (thin-plate: 0.5*ln2, so phi' = d2*log2(d2); biharmonic: -1, phi' = sqrt(d2))
+struct Rec32 {
+    float cx, cy, cz, s;
+    float wx, wy, wz, pad;
+};
+struct Rec64 {
+    double cx, cy, cz, s;
+    double wx, wy, wz, pad;
+};
+
+// Centres are padded with zero-weight records to a multiple of this.
+constexpr int kRecPad = 8;
+
+// Device-resident build status + affine part; read by the deform kernel so that
+// an asynchronous build needs no host round trip before the deform launch.
+struct DevModel {
+    int terminationtype;   // 1 ok, -4, -5; 0 = not built
+    int dup_flag;          // set by the assembly kernel: coincident centres
+    int sing_flag;         // set by the panel kernel: pivot below threshold
+    int iterations;        // elimination steps done
+    unsigned long long amax_bits;  // max |A_ij| as raw double bits (atomicMax)
+    unsigned long long pivmin_bits;
+    unsigned long long pivmax_bits;
+    // affine[c*4 + 0] = constant of output c; affine[c*4 + 1..3] = x,y,z coefficients
+    float affine32[12];
+    double affine64[12];
+};
+
+// Blob header for fd_export_model / fd_import_model.
+struct ModelHeader {
+    uint32_t magic;        // 'FDM1'
+    int32_t M, kind, term, nparams;
+    int32_t terminationtype;
+    int32_t reserved[2];
+    double params[4];
+};
+constexpr uint32_t kModelMagic = 0x314D4446u;
+
+static inline int term_cols(int term) { return term == FD_TERM_LINEAR ? 4 : (term == FD_TERM_CONST ? 1 : 0); }
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- build pipeline (fd_build.hip) -------------------------------------------
+constexpr int kPanelThreads = 1024;   // one workgroup factors a panel
+constexpr int kMaxOrder = 8192;       // panel rows that fit one CU's registers at NB=4
+constexpr int kRhsCols = 16;          // 3 right-hand sides padded to one MFMA tile
+
+struct BuildBuffers {
+    int M, T, n, npad, lda, ncols;    // A is lda x ncols column-major; cols npad.. hold the RHS
+    int kind, term;
+    double lambda;
+    double gauss_R, qnn_q, qnn_z;
+    const float *d_rest, *d_delta;    // M x 3
+    double *d_centres;                // M x 3
+    double *d_radii;                  // M
+    double *d_A;                      // lda x (ncols + 16): 16 zero columns absorb block overrun
+    double *d_X;                      // 3 x npad solution, column per right-hand side
+    int *d_ipiv;                      // npad
+    int *d_moves;                     // [0] = count, then (dst, src) pairs, per panel
+    double *d_W;                      // (M+4) x 3
+    Rec32 *d_rec32;
+    Rec64 *d_rec64;
+    int Mpad;
+    DevModel *d_model;
+};
+
+hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
+hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream);
+hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream);
+
+// ---- evaluation (fd_eval.hip) --------------------------------------------------
+struct DeformArgs {
+    int64_t N;
+    const float *P_in; float *P_out;
+    const float *dist2; float *falloff_out;
+    const float *tu, *tv, *nrm;
+    float radius2, falloffrate;
+    int M, Mpad, kind;
+    const Rec32 *rec32; const Rec64 *rec64;
+    const DevModel *model;
+    int precision, variant;
+};
+hipError_t launch_deform(const DeformArgs &a, hipStream_t stream);
+const char *deform_kernel_name(int kind, int precision, int variant);
+
+}  // namespace fd

@@ -1,0 +1,314 @@
+// fd_sop_host.cpp -- HDK-free mirror of SOP_FaceDeform's cook over plain arrays.
+//
+// Same parm tokens, defaults and clamps as the reference's PRM_Template list
+// (reference src/SOP_FaceDeform.cpp:99-137), same cook order and the same
+// error / warning / message texts (:215-489), with the ALGLIB call sequence and
+// the evaluation loop replaced by the fd_* C ABI.  The HDK wrapper
+// (hdk/SOP_FaceDeformHip.cpp) gathers GU_Detail attributes into an fdsop_geo
+// and calls fdsop_cook; the tests drive the same entry points through ctypes.
+//
+// Out of scope here, as in SURVEY.md section 2: ProximityCapture (its product,
+// the per-vertex dist2 array, is an input) and the DirectBSEdit morph pass.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/facedeform_hip.h"
+
+namespace {
+
+enum ParmType { P_STRING, P_ORD, P_FLOAT, P_INT, P_TOGGLE, P_FLOAT2 };
+
+struct ParmDef {
+    const char *token;
+    ParmType type;
+    double def0, def1;
+    const char *label;
+};
+
+// reference src/SOP_FaceDeform.cpp:99-137; the last four are additions that the
+// survey allows (new parms, nothing renamed or removed).
+const ParmDef kParms[] = {
+    {"group", P_STRING, 0, 0, "Group"},
+    {"model", P_ORD, 0, 0, "Model"},                       // 0 QNN, 1 Multilayer   (:48-53)
+    {"term", P_ORD, 0, 0, "RBF Term"},                     // 0 Linear, 1 Constant, 2 Zero (:55-61)
+    {"qcoef", P_FLOAT, 1, 0, "Q (Smoothness)"},
+    {"zcoef", P_FLOAT, 5, 0, "Z (Deviation)"},
+    {"radius", P_FLOAT, 1, 0, "Radius"},
+    {"maxedges", P_INT, 4, 0, "Max edges"},
+    {"layers", P_INT, 4, 0, "Layers"},
+    {"lambda", P_FLOAT, 0.1, 0, "Lambda"},
+    {"tangent", P_TOGGLE, 0, 0, "Tangent space"},
+    {"morphspace", P_TOGGLE, 0, 0, "Blendshapes subspace"},
+    {"doclampweight", P_TOGGLE, 0, 0, "Clamp weights"},
+    {"weightrange", P_FLOAT2, 0, 1, "Range"},
+    {"dofalloff", P_TOGGLE, 0, 0, "Falloff"},
+    {"falloffradius", P_FLOAT, 1, 0, "Falloff radius"},
+    {"falloffrate", P_FLOAT, 1, 0, "Falloff rate (exponent)"},
+    // -- additions
+    {"kernel", P_ORD, 0, 0, "Kernel"},        // 0 = per `model` (Gaussian), 1 thin-plate, 2 biharmonic, 3 cubic
+    {"smoothing", P_FLOAT, 0, 0, "Smoothing"},  // diagonal lambda for kernel != 0 and for QNN
+    {"precision", P_ORD, 0, 0, "Evaluation precision"},  // 0 fp32, 1 fp64
+    {"device", P_INT, -1, 0, "GPU device"},
+};
+constexpr int kNumParms = (int)(sizeof(kParms) / sizeof(kParms[0]));
+
+int find_parm(const char *token)
+{
+    if (!token) return -1;
+    for (int i = 0; i < kNumParms; ++i)
+        if (strcmp(kParms[i].token, token) == 0) return i;
+    return -1;
+}
+
+template <typename T>
+T sys_max(T a, T b) { return a > b ? a : b; }
+
+}  // namespace
+
+struct fdsop_node {
+    fd_config cfg{};
+    fd_ctx *engine = nullptr;
+    double fval[kNumParms][2];
+    std::string sval[kNumParms];
+    std::string messages;
+    int severity = FDSOP_OK;
+    // clamped values of the last cook (A1)
+    float e_qcoef = 0, e_zcoef = 0, e_radius = 0, e_lambda = 0;
+    int e_layers = 0, e_maxedges = 0;
+    int engine_precision = -1, engine_device = -2;
+
+    void add(int sev, const char *text)
+    {
+        const char *name = sev == FDSOP_ERROR ? "error" : (sev == FDSOP_WARNING ? "warning" : "message");
+        messages += name;
+        messages += '\t';
+        messages += text;
+        messages += '\n';
+        if (sev > severity) severity = sev;
+    }
+    // ordinal parms are strings parsed with atoi, as reference :247-248
+    int ord(int idx) const { return atoi(sval[idx].c_str()); }
+};
+
+extern "C" {
+
+int fdsop_parm_count(void) { return kNumParms; }
+const char *fdsop_parm_token(int i) { return (i >= 0 && i < kNumParms) ? kParms[i].token : nullptr; }
+
+fdsop_node *fdsop_create(const fd_config *cfg)
+{
+    fdsop_node *n = new (std::nothrow) fdsop_node();
+    if (!n) return nullptr;
+    if (cfg) n->cfg = *cfg;
+    else { memset(&n->cfg, 0, sizeof(n->cfg)); n->cfg.device = -1; }
+    for (int i = 0; i < kNumParms; ++i) {
+        n->fval[i][0] = kParms[i].def0;
+        n->fval[i][1] = kParms[i].def1;
+        if (kParms[i].type == P_ORD) n->sval[i] = std::to_string((int)kParms[i].def0);
+    }
+    n->fval[find_parm("device")][0] = n->cfg.device;
+    n->sval[find_parm("precision")] = std::to_string(n->cfg.eval_precision == FD_EVAL_FP64 ? 1 : 0);
+    return n;
+}
+
+void fdsop_destroy(fdsop_node *node)
+{
+    if (!node) return;
+    if (node->engine) fd_destroy(node->engine);
+    delete node;
+}
+
+int fdsop_set_float(fdsop_node *node, const char *token, int index, double value)
+{
+    const int i = find_parm(token);
+    if (!node || i < 0 || index < 0 || index > 1) return FD_E_INVALID;
+    if (kParms[i].type == P_STRING) return FD_E_INVALID;
+    if (index == 1 && kParms[i].type != P_FLOAT2) return FD_E_INVALID;
+    node->fval[i][index] = value;
+    if (kParms[i].type == P_ORD) node->sval[i] = std::to_string((int)value);
+    return FD_OK;
+}
+
+int fdsop_set_int(fdsop_node *node, const char *token, int value)
+{
+    return fdsop_set_float(node, token, 0, (double)value);
+}
+
+int fdsop_set_string(fdsop_node *node, const char *token, const char *value)
+{
+    const int i = find_parm(token);
+    if (!node || i < 0 || !value) return FD_E_INVALID;
+    if (kParms[i].type != P_STRING && kParms[i].type != P_ORD) return FD_E_INVALID;
+    node->sval[i] = value;
+    if (kParms[i].type == P_ORD) node->fval[i][0] = atoi(value);
+    return FD_OK;
+}
+
+int fdsop_get_float(const fdsop_node *node, const char *token, int index, double *value)
+{
+    const int i = find_parm(token);
+    if (!node || i < 0 || !value || index < 0 || index > 1) return FD_E_INVALID;
+    *value = node->fval[i][index];
+    return FD_OK;
+}
+
+int fdsop_get_int(const fdsop_node *node, const char *token, int *value)
+{
+    const int i = find_parm(token);
+    if (!node || i < 0 || !value) return FD_E_INVALID;
+    *value = kParms[i].type == P_ORD ? node->ord(i) : (int)node->fval[i][0];
+    return FD_OK;
+}
+
+const char *fdsop_messages(const fdsop_node *node) { return node ? node->messages.c_str() : ""; }
+
+fd_ctx *fdsop_engine(fdsop_node *node) { return node ? node->engine : nullptr; }
+
+int fdsop_effective_float(const fdsop_node *node, const char *token, double *value)
+{
+    if (!node || !token || !value) return FD_E_INVALID;
+    if (!strcmp(token, "qcoef")) *value = node->e_qcoef;
+    else if (!strcmp(token, "zcoef")) *value = node->e_zcoef;
+    else if (!strcmp(token, "radius")) *value = node->e_radius;
+    else if (!strcmp(token, "lambda")) *value = node->e_lambda;
+    else if (!strcmp(token, "layers")) *value = node->e_layers;
+    else if (!strcmp(token, "maxedges")) *value = node->e_maxedges;
+    else return FD_E_INVALID;
+    return FD_OK;
+}
+
+// The cook: reference src/SOP_FaceDeform.cpp:215-489, step for step.
+int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
+{
+    if (!node || !geo) return FDSOP_ERROR;
+    node->messages.clear();
+    node->severity = FDSOP_OK;
+    if (geo->npoints < 0 || (geo->npoints > 0 && (!geo->P || !geo->P_out)) || !geo->rest_P || !geo->deform_P) {
+        node->add(FDSOP_ERROR, "Invalid geometry arrays.");
+        return node->severity;
+    }
+    // duplicatePointSource(0) (:226): the output starts as a copy of input 0
+    if (geo->P_out != geo->P && geo->npoints > 0)
+        memcpy(geo->P_out, geo->P, sizeof(float) * 3 * (size_t)geo->npoints);
+
+    // :228-234
+    if (geo->rest_npoints != geo->deform_npoints) {
+        node->add(FDSOP_ERROR, "Rest and deform geometry should match.");
+        return node->severity;
+    }
+
+    // :244-263 -- SYSmax(0.1, fpreal) is evaluated in double, then narrowed to float
+    const int model_index = node->ord(find_parm("model"));
+    const int term_index = node->ord(find_parm("term"));
+    const float qcoef = (float)sys_max(0.1, node->fval[find_parm("qcoef")][0]);
+    const float zcoef = (float)sys_max(0.1, node->fval[find_parm("zcoef")][0]);
+    const float radius = (float)sys_max(0.01, node->fval[find_parm("radius")][0]);
+    const int layers = sys_max(1, (int)node->fval[find_parm("layers")][0]);
+    const float lambda = (float)sys_max(0.01, node->fval[find_parm("lambda")][0]);
+    const int tangent_disp = (int)node->fval[find_parm("tangent")][0];
+    const int morph_space = (int)node->fval[find_parm("morphspace")][0];
+    const int max_edges = sys_max(1, (int)node->fval[find_parm("maxedges")][0]);
+    const float falloffrate = (float)node->fval[find_parm("falloffrate")][0];
+    node->e_qcoef = qcoef; node->e_zcoef = zcoef; node->e_radius = radius; node->e_lambda = lambda;
+    node->e_layers = layers; node->e_maxedges = max_edges;
+    const int kernel_ext = node->ord(find_parm("kernel"));
+    const double smoothing = node->fval[find_parm("smoothing")][0];
+    const int precision = node->ord(find_parm("precision")) == 1 ? FD_EVAL_FP64 : FD_EVAL_FP32;
+    const int device = (int)node->fval[find_parm("device")][0];
+
+    // :268-287 -- M x 6 table: rest position and fp32 delta
+    const int M = (int)geo->rest_npoints;
+    std::vector<float> delta((size_t)(M > 0 ? M : 0) * 3);
+    for (int i = 0; i < M; ++i)
+        for (int c = 0; c < 3; ++c) delta[3 * (size_t)i + c] = geo->deform_P[3 * (size_t)i + c] - geo->rest_P[3 * (size_t)i + c];
+
+    // :289-298
+    const bool do_tangent_disp = tangent_disp && geo->tangentu && geo->tangentv && geo->N;
+    if (tangent_disp && !do_tangent_disp)
+        node->add(FDSOP_WARNING, "Append PolyFrameSOP and enable tangent[u/v] and N attribute to allow tangent displacement.");
+
+    // :325-329 -- inputs 3.. (blendshapes) are not part of this boundary
+    if (morph_space) node->add(FDSOP_WARNING, "No blendshapes found. Ignoring morphspace deformation.");
+
+    // engine (re)creation when the device or the precision parm changed
+    if (!node->engine || node->engine_precision != precision || node->engine_device != device) {
+        if (node->engine) { fd_destroy(node->engine); node->engine = nullptr; }
+        fd_config cfg = node->cfg;
+        cfg.struct_size = (int)sizeof(fd_config);
+        cfg.device = device;
+        cfg.eval_precision = precision;
+        node->engine = fd_create(&cfg);
+        node->engine_precision = precision;
+        node->engine_device = device;
+        if (!node->engine) {
+            std::string t = std::string("Can't create the GPU deformation engine: ") + fd_last_error(nullptr);
+            node->add(FDSOP_ERROR, t.c_str());
+            return node->severity;
+        }
+    }
+    fd_ctx *ctx = node->engine;
+
+    // :331-340 -- rbfcreate + rbfsetpoints
+    if (M <= 0 || fd_set_points(ctx, geo->rest_P, delta.data(), M) != FD_OK) {
+        node->add(FDSOP_ERROR, "Can't build RBF model.");
+        return node->severity;
+    }
+    // :342-349 -- model select; `kernel` (addition) overrides the Gaussian family
+    int rc = FD_OK;
+    if (kernel_ext == 1 || kernel_ext == 2 || kernel_ext == 3) {
+        const int kind = kernel_ext == 1 ? FD_KERNEL_THIN_PLATE : (kernel_ext == 2 ? FD_KERNEL_BIHARMONIC : FD_KERNEL_CUBIC);
+        const double p[1] = {smoothing};
+        rc = fd_set_kernel(ctx, kind, p, 1);
+    } else if (model_index == 1) {   // ALGLIB_MODEL_ML: rbfsetalgomultilayer(model, radius, layers, lambda)
+        const double p[2] = {(double)radius, (double)lambda};
+        rc = fd_set_kernel(ctx, FD_KERNEL_GAUSSIAN, p, 2);
+    } else {                         // ALGLIB_MODEL_QNN: rbfsetalgoqnn(model, qcoef, zcoef)
+        const double p[3] = {(double)qcoef, (double)zcoef, smoothing};
+        rc = fd_set_kernel(ctx, FD_KERNEL_GAUSSIAN_QNN, p, 3);
+    }
+    // :351-361 -- any other ordinal leaves ALGLIB's default (linear) in place
+    const int term = (term_index == 1) ? FD_TERM_CONST : (term_index == 2 ? FD_TERM_ZERO : FD_TERM_LINEAR);
+    if (rc == FD_OK) rc = fd_set_term(ctx, term);
+    if (rc != FD_OK) {
+        node->add(FDSOP_ERROR, "Can't build RBF model.");
+        return node->severity;
+    }
+    // :363-368
+    fd_report report;
+    memset(&report, 0, sizeof(report));
+    rc = fd_build(ctx, &report);
+    if (report.terminationtype != 1 || rc != FD_OK) {
+        node->add(FDSOP_ERROR, "Can't solve the problem.");
+        return node->severity;
+    }
+    // :370-373
+    char info[200];
+    snprintf(info, sizeof(info), "Termination type: %d, Iterations: %d", report.terminationtype, report.iterationscount);
+    node->add(FDSOP_MESSAGE, info);
+
+    // :386-388 -- Cd is added white and never written again
+    if (geo->Cd)
+        for (int64_t i = 0; i < geo->npoints * 3; ++i) geo->Cd[i] = 1.f;
+    // :396-399
+    if (!geo->dist2)
+        node->add(FDSOP_WARNING, "Can't find distance capture attribute. Won't apply radius nor falloff.");
+    // :401 -- a fresh float attribute reads 0 until written
+    if (geo->fd_falloff && geo->npoints > 0) memset(geo->fd_falloff, 0, sizeof(float) * (size_t)geo->npoints);
+    const float radius_sqrt = radius * radius;   // :402 (a square, despite the name)
+
+    // :404-439
+    rc = fd_deform(ctx, geo->npoints, geo->P_out, geo->P_out, geo->dist2, geo->fd_falloff,
+                   do_tangent_disp ? geo->tangentu : nullptr, do_tangent_disp ? geo->tangentv : nullptr,
+                   do_tangent_disp ? geo->N : nullptr, radius_sqrt, falloffrate);
+    if (rc != FD_OK) {
+        std::string t = std::string("GPU deformation failed: ") + fd_last_error(ctx);
+        node->add(FDSOP_ERROR, t.c_str());
+    }
+    return node->severity;
+}
+
+}  // extern "C"

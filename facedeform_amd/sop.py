@@ -1,0 +1,132 @@
+"""Python handle on the C++ cook mirror (fdsop_* in include/facedeform_hip.h).
+
+Mirrors the node a Houdini user sees: parms by token (reference
+src/SOP_FaceDeform.cpp:99-137) and a cook over arrays standing in for the
+mesh / rest rig / deformed rig inputs (:215-489).  All logic lives in
+csrc/fd_sop_host.cpp; this file only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class CookResult:
+    severity: int
+    messages: list = field(default_factory=list)   # (severity_name, text)
+    P: np.ndarray | None = None
+    fd_falloff: np.ndarray | None = None
+    Cd: np.ndarray | None = None
+
+    @property
+    def errors(self):
+        return [t for s, t in self.messages if s == "error"]
+
+    @property
+    def warnings(self):
+        return [t for s, t in self.messages if s == "warning"]
+
+    @property
+    def infos(self):
+        return [t for s, t in self.messages if s == "message"]
+
+
+class FaceDeformSOP:
+    def __init__(self, device: int = -1, precision: int = capi.EVAL_FP32, variant: int = 0):
+        self.L = capi.load()
+        cfg = capi.FdConfig(C.sizeof(capi.FdConfig), device, precision, variant)
+        self.node = self.L.fdsop_create(C.byref(cfg))
+        if not self.node:
+            raise MemoryError("fdsop_create failed")
+
+    def close(self):
+        if getattr(self, "node", None):
+            self.L.fdsop_destroy(self.node)
+            self.node = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parm surface
+    @staticmethod
+    def parm_tokens():
+        L = capi.load()
+        return [L.fdsop_parm_token(i).decode() for i in range(L.fdsop_parm_count())]
+
+    def set(self, token: str, value, index: int = 0):
+        tok = token.encode()
+        if isinstance(value, str):
+            rc = self.L.fdsop_set_string(self.node, tok, value.encode())
+        elif isinstance(value, (tuple, list)):
+            rc = 0
+            for i, v in enumerate(value):
+                rc = rc or self.L.fdsop_set_float(self.node, tok, i, float(v))
+        else:
+            rc = self.L.fdsop_set_float(self.node, tok, index, float(value))
+        if rc != 0:
+            raise KeyError(f"bad parm {token!r} / value {value!r}")
+
+    def get(self, token: str, index: int = 0) -> float:
+        v = C.c_double()
+        if self.L.fdsop_get_float(self.node, token.encode(), index, C.byref(v)) != 0:
+            raise KeyError(token)
+        return v.value
+
+    def get_int(self, token: str) -> int:
+        v = C.c_int()
+        if self.L.fdsop_get_int(self.node, token.encode(), C.byref(v)) != 0:
+            raise KeyError(token)
+        return v.value
+
+    def effective(self, token: str) -> float:
+        """Clamped value used by the last cook (reference :249-257)."""
+        v = C.c_double()
+        if self.L.fdsop_effective_float(self.node, token.encode(), C.byref(v)) != 0:
+            raise KeyError(token)
+        return v.value
+
+    def engine(self) -> capi.Engine | None:
+        ctx = self.L.fdsop_engine(self.node)
+        if not ctx:
+            return None
+        e = capi.Engine(_borrowed=ctx)
+        return e
+
+    # -- cook
+    def cook(self, mesh_P, rest_P, deform_P, dist2=None, tangentu=None, tangentv=None, N=None) -> CookResult:
+        f32 = np.float32
+        P = np.ascontiguousarray(mesh_P, f32).reshape(-1, 3)
+        rest = np.ascontiguousarray(rest_P, f32).reshape(-1, 3)
+        deform = np.ascontiguousarray(deform_P, f32).reshape(-1, 3)
+        keep = [P, rest, deform]
+
+        def opt(a, cols):
+            if a is None:
+                return None
+            arr = np.ascontiguousarray(a, f32).reshape(-1, cols) if cols > 1 else np.ascontiguousarray(a, f32)
+            keep.append(arr)
+            return arr
+
+        d2, tu, tv, nn = opt(dist2, 1), opt(tangentu, 3), opt(tangentv, 3), opt(N, 3)
+        P_out = np.empty_like(P)
+        fall = np.empty(P.shape[0], f32)
+        Cd = np.empty_like(P)
+        fp = capi._f32p
+
+        def ptr(a):
+            return None if a is None else a.ctypes.data_as(fp)
+
+        geo = capi.FdsopGeo(P.shape[0], ptr(P), ptr(tu), ptr(tv), ptr(nn), ptr(d2), rest.shape[0],
+                            deform.shape[0], ptr(rest), ptr(deform), ptr(P_out), ptr(fall), ptr(Cd))
+        sev = self.L.fdsop_cook(self.node, C.byref(geo))
+        text = self.L.fdsop_messages(self.node).decode()
+        msgs = [tuple(line.split("\t", 1)) for line in text.splitlines() if "\t" in line]
+        return CookResult(sev, msgs, P_out, fall, Cd)

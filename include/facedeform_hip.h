@@ -1,0 +1,212 @@
+/*
+ * facedeform_hip.h -- C ABI of the MI355X (gfx950) RBF deformation engine.
+ *
+ * This is the drop-in boundary for the hot path of symek/facedeform's
+ * SOP_FaceDeform::cookMySop.  Each entry point names the reference interface
+ * it replaces (paths relative to the reference tree).  Plain C: no C++ types,
+ * no torch types, no exceptions cross it.  All functions return 0 (FD_OK) on
+ * success and a negative FD_E_* code on failure unless stated otherwise;
+ * fd_last_error() gives the text.
+ *
+ * Threading: an fd_ctx is not thread-safe; distinct contexts are independent
+ * and re-entrant (different SOP instances may cook concurrently).
+ *
+ * Memory: "host" entry points take caller-owned host pointers and copy.
+ * "_dev" entry points take device pointers valid on the context's device and
+ * enqueue on the context's stream without synchronising.
+ */
+#ifndef FACEDEFORM_HIP_H
+#define FACEDEFORM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_ABI_VERSION 1
+
+/* ---- error codes ---------------------------------------------------------- */
+enum {
+    FD_OK = 0,
+    FD_E_INVALID = -1,    /* bad argument / call order                           */
+    FD_E_NOMEM = -2,      /* host or device allocation failed                    */
+    FD_E_DEVICE = -3,     /* HIP runtime error (text in fd_last_error)           */
+    FD_E_SINGULAR = -4,   /* solver failure; report.terminationtype = -4         */
+    FD_E_DUPLICATE = -5,  /* coincident control points; terminationtype = -5     */
+    FD_E_NOT_BUILT = -6,  /* fd_deform before a successful fd_build              */
+    FD_E_NO_DEVICE = -7   /* no usable gfx950 device / kernels cannot load       */
+};
+
+/* ---- radial kernels (d2 = squared distance to centre j) --------------------
+ * The reference exposes ALGLIB's two Gaussian models through the `model` parm
+ * (src/SOP_FaceDeform.cpp:48-53,342-349).  The engine solves the dense system
+ * north_star describes; kinds 0/1 are the reference's family, 2..4 BASELINE's.
+ *   FD_KERNEL_GAUSSIAN      exp(-d2/R^2)            params {R [, lambda]}
+ *       (model=1 "Multilayer" collapsed to one layer: R = radius, lambda = lambda)
+ *   FD_KERNEL_GAUSSIAN_QNN  exp(-d2/R_j^2), R_j = min(q*nn_j, z*median_k(q*nn_k))
+ *       (model=0 "QNN": q = qcoef, z = zcoef)      params {q, z [, lambda]}
+ *   FD_KERNEL_THIN_PLATE    r^2 ln r                params {[lambda]}
+ *   FD_KERNEL_BIHARMONIC    -r                      params {[lambda]}
+ *   FD_KERNEL_CUBIC         r^3                     params {[lambda]}
+ * lambda is added to the diagonal of the kernel block (smoothing); default 0. */
+enum {
+    FD_KERNEL_GAUSSIAN = 0,
+    FD_KERNEL_GAUSSIAN_QNN = 1,
+    FD_KERNEL_THIN_PLATE = 2,
+    FD_KERNEL_BIHARMONIC = 3,
+    FD_KERNEL_CUBIC = 4
+};
+
+/* Same integers as ALGLIB_TERM_LINEAR/CONST/ZERO, src/SOP_FaceDeform.hpp:16-18. */
+enum { FD_TERM_LINEAR = 0, FD_TERM_CONST = 1, FD_TERM_ZERO = 2 };
+
+/* Evaluation arithmetic.  FP32: fp32 distances and kernel, partial sums folded
+ * into fp64 every 64 centres.  FP64: everything in fp64 (ill-conditioned
+ * weights).  The solve is always fp64. */
+enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
+
+typedef struct fd_ctx fd_ctx;
+
+typedef struct fd_config {
+    int struct_size;     /* = sizeof(fd_config); 0 is accepted as "version 1"   */
+    int device;          /* HIP device ordinal; -1 = the calling thread's current */
+    int eval_precision;  /* FD_EVAL_*                                            */
+    int eval_variant;    /* 0 = auto; otherwise a kernel variant id (tuning/tests) */
+    int reserved[4];
+} fd_config;
+
+/* Replaces alglib::rbfreport as read at src/SOP_FaceDeform.cpp:365-373. */
+typedef struct fd_report {
+    int terminationtype; /* 1 ok; -5 coincident centres; -4 solver failure       */
+    int iterationscount; /* elimination steps taken by the direct solver         */
+    int n;               /* order of the solved system (M + term columns)        */
+    int reserved;
+    double pivot_ratio;  /* min|pivot| / max|pivot| of the LU (cheap rcond proxy) */
+    float t_assemble_ms; /* device time: prepare + kernel-matrix assembly        */
+    float t_solve_ms;    /* device time: factorisation + substitution + pack     */
+} fd_report;
+
+/* ---- lifetime ---------------------------------------------------------------
+ * fd_create replaces `alglib::rbfmodel model; alglib::rbfcreate(3, 3, model)`
+ * (src/SOP_FaceDeform.cpp:332,335).  NULL on failure (no device, out of
+ * memory); fd_last_error(NULL) then holds the reason. */
+fd_ctx *fd_create(const fd_config *cfg);
+void fd_destroy(fd_ctx *ctx);
+const char *fd_last_error(const fd_ctx *ctx);
+int fd_abi_version(void);
+
+/* Launch everything on `hip_stream` (a hipStream_t) instead of the context's
+ * own stream.  NULL restores the context's stream. */
+int fd_set_stream(fd_ctx *ctx, void *hip_stream);
+
+/* ---- model set-up -----------------------------------------------------------
+ * fd_set_points replaces alglib::rbfsetpoints(model, xy) with the M x 6 table
+ * split into its two halves (src/SOP_FaceDeform.cpp:268-287,336): rest_xyz and
+ * delta_xyz are AoS M x 3 fp32; delta = float(deformP - restP) computed by the
+ * caller in fp32 as the reference does (:278). */
+int fd_set_points(fd_ctx *ctx, const float *rest_xyz, const float *delta_xyz, int M);
+int fd_set_points_dev(fd_ctx *ctx, const float *d_rest_xyz, const float *d_delta_xyz, int M);
+
+/* Replaces rbfsetalgoqnn / rbfsetalgomultilayer (src/SOP_FaceDeform.cpp:342-349). */
+int fd_set_kernel(fd_ctx *ctx, int kind, const double *params, int nparams);
+
+/* Replaces rbfsetlinterm / rbfsetconstterm / rbfsetzeroterm (:351-361). */
+int fd_set_term(fd_ctx *ctx, int term);
+
+/* fd_build replaces alglib::rbfbuildmodel(model, report) (:363-368): kernel
+ * matrix assembly + dense solve on the device; synchronises; fills *report.
+ * Returns FD_OK iff report->terminationtype == 1.
+ * fd_build_async enqueues the same work and returns; fd_build_result waits and
+ * reports.  A deform enqueued after a failed build passes P through unchanged. */
+int fd_build(fd_ctx *ctx, fd_report *report);
+int fd_build_async(fd_ctx *ctx);
+int fd_build_result(fd_ctx *ctx, fd_report *report);
+
+/* ---- evaluation -------------------------------------------------------------
+ * fd_deform replaces the whole loop body src/SOP_FaceDeform.cpp:404-439
+ * (gate :405-410, rbfcalc :411-415, project_to_tangents :416-422 with
+ * src/SOP_FaceDeform.hpp:28-41, fall-off :423-425, write-back :437-438).
+ *   P_in / P_out   N x 3 AoS fp32; P_out may alias P_in
+ *   dist2          N fp32 squared capture distance, or NULL (= 0 everywhere)
+ *   falloff_out    N fp32 (the fd_falloff attribute), or NULL; vertices skipped
+ *                  by the gate are not written (the attribute keeps its default)
+ *   tu, tv, nrm    N x 3 fp32 tangentu / tangentv / N, all three or all NULL
+ *   radius2        radius*radius (:402);  falloffrate  the exponent (:424)
+ * Synchronises before returning. */
+int fd_deform(fd_ctx *ctx, int64_t N, const float *P_in, float *P_out, const float *dist2,
+              float *falloff_out, const float *tu, const float *tv, const float *nrm,
+              float radius2, float falloffrate);
+
+/* Same, device pointers, asynchronous on the context's stream. */
+int fd_deform_dev(fd_ctx *ctx, int64_t N, const float *d_P_in, float *d_P_out,
+                  const float *d_dist2, float *d_falloff_out, const float *d_tu,
+                  const float *d_tv, const float *d_nrm, float radius2, float falloffrate);
+
+/* ---- model access -----------------------------------------------------------
+ * W is (M+4) x 3 fp64 row-major: M RBF weights, the constant row, the x,y,z
+ * linear rows (zero when the term lacks them).  radii (may be NULL) gets M
+ * Gaussian radii.  For tests and for RCCL-free replication. */
+int fd_get_weights(fd_ctx *ctx, double *W, double *radii);
+
+/* Solved model as one relocatable blob (header + centres + radii + weights):
+ * what a vertex-range split broadcasts from the solving GPU (RCCL over xGMI,
+ * or any other transport).  on_device != 0: buf is a device pointer and the
+ * copy is enqueued on the context's stream. */
+size_t fd_model_bytes(const fd_ctx *ctx);
+int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device);
+int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device);
+
+/* Block until everything enqueued on the context's stream has finished. */
+int fd_synchronize(fd_ctx *ctx);
+
+/* ---- host-side cook: the HDK-free mirror of cookMySop ----------------------
+ * fdsop_* mirrors the SOP's parm surface (src/SOP_FaceDeform.cpp:99-137) and
+ * the cook sequence (:215-489) over plain arrays standing in for GU_Detail:
+ * same parm tokens, defaults and clamps, same error / warning texts.  The HDK
+ * wrapper (hdk/SOP_FaceDeformHip.cpp) and the tests drive this. */
+typedef struct fdsop_node fdsop_node;
+
+/* Severity of the worst message of the last cook, as OP_ERROR orders them. */
+enum { FDSOP_OK = 0, FDSOP_MESSAGE = 1, FDSOP_WARNING = 2, FDSOP_ERROR = 3 };
+
+typedef struct fdsop_geo {
+    /* input 0: the mesh (cooked in place into the output, duplicatePointSource :226) */
+    int64_t npoints;
+    const float *P;        /* npoints x 3 */
+    const float *tangentu; /* npoints x 3 or NULL */
+    const float *tangentv;
+    const float *N;
+    const float *dist2;    /* ProximityCapture's detached attribute (capture.cpp:31) or NULL */
+    /* inputs 1 and 2: rest and deformed rig */
+    int64_t rest_npoints, deform_npoints;
+    const float *rest_P;
+    const float *deform_P;
+    /* outputs */
+    float *P_out;          /* npoints x 3 */
+    float *fd_falloff;     /* npoints, or NULL */
+    float *Cd;             /* npoints x 3, or NULL (always white, :386-388) */
+} fdsop_geo;
+
+fdsop_node *fdsop_create(const fd_config *cfg);
+void fdsop_destroy(fdsop_node *node);
+/* Parm access by token ("radius", "model", ...).  Unknown token: FD_E_INVALID. */
+int fdsop_set_float(fdsop_node *node, const char *token, int index, double value);
+int fdsop_set_int(fdsop_node *node, const char *token, int value);
+int fdsop_set_string(fdsop_node *node, const char *token, const char *value);
+int fdsop_get_float(const fdsop_node *node, const char *token, int index, double *value);
+int fdsop_get_int(const fdsop_node *node, const char *token, int *value);
+int fdsop_parm_count(void);
+const char *fdsop_parm_token(int i);
+/* Cook.  Returns the FDSOP_* severity.  Messages: "severity\ttext\n" lines. */
+int fdsop_cook(fdsop_node *node, const fdsop_geo *geo);
+const char *fdsop_messages(const fdsop_node *node);
+/* The clamped values the last cook actually used (A1), and the engine underneath. */
+int fdsop_effective_float(const fdsop_node *node, const char *token, double *value);
+fd_ctx *fdsop_engine(fdsop_node *node);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACEDEFORM_HIP_H */

@@ -1,0 +1,295 @@
+"""GPU: parity of the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.
+
+Tolerances (north_star: "within 1e-5 relative per-vertex displacement"):
+  * solved weights (fp64 LU on both sides, same pivoting rule): 1e-8 relative to max|W|
+  * deformation, fp32 evaluation: per-vertex metric of SURVEY.md 8d <= 1e-5
+  * deformation, fp64 evaluation: <= 2e-7 (one fp32 rounding of the displacement)
+"""
+import numpy as np
+import pytest
+
+from conftest import case_kind_term, parity_ratio
+from facedeform_amd import capi, synth
+from facedeform_amd.sop import FaceDeformSOP
+from oracle import fd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+TOL_W = 1e-8
+TOL_FP32 = 1e-5
+TOL_FP64 = 2e-7
+
+
+def _engine(kind, params, term, rest, deform, precision=capi.EVAL_FP32, variant=0):
+    e = capi.Engine(precision=precision, variant=variant)
+    delta = (np.asarray(deform, np.float32) - np.asarray(rest, np.float32)).astype(np.float32)
+    e.set_points(rest, delta)
+    e.set_kernel(kind, params)
+    e.set_term(term)
+    return e
+
+
+def _oracle_model(oracle, kind, params, term, rest, deform):
+    table = oracle.control_table(rest, deform)
+    rc, tt, W, radii = oracle.build(table, kind, params, term)
+    assert rc == 0 and tt == 1
+    return table, W, radii
+
+
+def test_weights_match_oracle_and_golden(hip_lib, oracle, golden):
+    for name in [str(n) for n in golden["names"]]:
+        kind, term = case_kind_term(name)
+        rest, deform, params = golden[name + "/rest"], golden[name + "/deform"], golden[name + "/params"]
+        e = _engine(kind, params, term, rest, deform)
+        rep = e.build()
+        assert rep.terminationtype == 1 and rep.n == rest.shape[0] + (4, 1, 0)[term], name
+        assert rep.iterationscount == rep.n
+        W, radii = e.get_weights()
+        table, W_ref, radii_ref = _oracle_model(oracle, kind, params, term, rest, deform)
+        scale = np.abs(W_ref).max()
+        assert np.abs(W - W_ref).max() <= TOL_W * scale, name
+        assert np.abs(W[: rest.shape[0]] - golden[name + "/w"]).max() <= TOL_W * scale, name
+        assert np.allclose(radii, radii_ref, rtol=1e-13), name
+        e.close()
+
+
+@pytest.mark.parametrize("precision,tol", [(capi.EVAL_FP32, TOL_FP32), (capi.EVAL_FP64, TOL_FP64)])
+def test_golden_points_deform_all_kernels(hip_lib, oracle, golden, precision, tol):
+    for name in [str(n) for n in golden["names"]]:
+        kind, term = case_kind_term(name)
+        rest, deform, params = golden[name + "/rest"], golden[name + "/deform"], golden[name + "/params"]
+        P = golden[name + "/x"].astype(np.float32)
+        e = _engine(kind, params, term, rest, deform, precision)
+        e.build()
+        out, fall = e.deform(P)
+        # golden displacement (SciPy), narrowed and added in fp32 as the reference does (:415,:438)
+        ref = P + golden[name + "/delta"].astype(np.float32)
+        assert parity_ratio(out, ref, P, tol) <= 1.0, (name, parity_ratio(out, ref, P, tol))
+        assert np.array_equal(fall, np.ones(P.shape[0], np.float32))
+        e.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_c1_sphere_matches_oracle(hip_lib, oracle, variant):
+    """BASELINE config 1: 10k-vertex sphere, 32 control points, thin-plate, linear term."""
+    P = synth.sphere_mesh(10_000)
+    rest = synth.control_points(32, "sphere")
+    deform = synth.deformed_rig(rest)
+    e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, deform, variant=variant)
+    e.build()
+    out, fall = e.deform(P)
+    table, W, radii = _oracle_model(oracle, fo.KERNEL_THIN_PLATE, [], 0, rest, deform)
+    ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    assert parity_ratio(out, ref, P, TOL_FP32) <= 1.0
+    assert np.array_equal(fall, ref_fall)
+    e.close()
+
+
+def test_epilogue_gate_falloff_and_tangents(hip_lib, oracle):
+    rng = np.random.default_rng(5)
+    P = synth.head_mesh(5000)
+    rest = synth.control_points(48, "head")
+    deform = synth.deformed_rig(rest)
+    tu, tv, nn = synth.tangent_frames(P)
+    # dist2: zeros, exactly r2, above r2 (gated), negative (B4)
+    r2 = np.float32(0.3 * 0.3)
+    dist2 = (rng.random(5000) * 0.15).astype(np.float32)
+    dist2[::7] = 0.0
+    dist2[1::11] = r2
+    dist2[2::13] = -1.0
+    table, W, radii = _oracle_model(oracle, fo.KERNEL_GAUSSIAN_QNN, [1.0, 5.0], 1, rest, deform)
+    for rate in (0.0, 0.5, 1.0, 2.0):
+        e = _engine(capi.KERNEL_GAUSSIAN_QNN, [1.0, 5.0], capi.TERM_CONST, rest, deform)
+        e.build()
+        out, fall = e.deform(P, dist2=dist2, tangents=(tu, tv, nn), radius2=r2, falloffrate=rate)
+        ref, ref_fall = oracle.deform(table, fo.KERNEL_GAUSSIAN_QNN, radii, W, P, dist2=dist2,
+                                      tangents=(tu, tv, nn), radius2=r2, falloffrate=rate)
+        gated = dist2 > r2
+        assert gated.any() and (~gated).any()
+        assert np.array_equal(out[gated], P[gated])                 # B2: untouched
+        assert np.array_equal(fall[gated], np.zeros(gated.sum(), np.float32))
+        assert np.allclose(fall, ref_fall, rtol=2e-6, atol=1e-7), rate   # powf: device vs libm
+        assert parity_ratio(out, ref, P, 3e-5) <= 1.0, rate         # fp32 tangent algebra on both sides
+        e.close()
+
+
+def test_duplicate_and_degenerate_rigs(hip_lib):
+    rest = synth.control_points(16, "sphere")
+    rest[9] = rest[2]
+    e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, rest + np.float32(0.01))
+    rep = e.build(check=False)
+    assert rep.rc == capi.FD_E_DUPLICATE and rep.terminationtype == -5
+    with pytest.raises(capi.FdError) as ei:
+        e.deform(synth.sphere_mesh(10))
+    assert ei.value.code == capi.FD_E_NOT_BUILT
+    e.close()
+    rest = synth.control_points(3, "sphere")
+    e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, rest + np.float32(0.01))
+    rep = e.build(check=False)
+    assert rep.rc == capi.FD_E_SINGULAR and rep.terminationtype == -4
+    e.close()
+
+
+def test_call_order_and_argument_errors(hip_lib):
+    e = capi.Engine()
+    with pytest.raises(capi.FdError) as ei:
+        e.build()
+    assert ei.value.code == capi.FD_E_INVALID
+    with pytest.raises(capi.FdError):
+        e.set_kernel(99)
+    with pytest.raises(capi.FdError):
+        e.set_term(3)
+    with pytest.raises(capi.FdError):
+        e.set_kernel(capi.KERNEL_GAUSSIAN, [-1.0])
+    e.close()
+
+
+def test_failed_async_build_passes_points_through(hip_lib):
+    torch = pytest.importorskip("torch")
+    rest = synth.control_points(8, "sphere")
+    rest[5] = rest[1]
+    e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, rest + np.float32(0.01))
+    P = torch.from_numpy(synth.sphere_mesh(1000)).cuda()
+    out = torch.empty_like(P)
+    e.build_async()
+    e.deform_dev(1000, P.data_ptr(), out.data_ptr())
+    rep = e.build_result(check=False)
+    assert rep.terminationtype == -5
+    e.synchronize()
+    assert torch.equal(out, P)
+    e.close()
+
+
+def test_device_pointer_path_on_torch_stream(hip_lib, oracle):
+    torch = pytest.importorskip("torch")
+    P = synth.head_mesh(20_000)
+    rest = synth.control_points(64, "head")
+    deform = synth.deformed_rig(rest)
+    e = capi.Engine()
+    stream = torch.cuda.Stream()
+    e.set_stream(stream.cuda_stream)
+    d_rest = torch.from_numpy(rest).cuda()
+    d_delta = torch.from_numpy((deform - rest).astype(np.float32)).cuda()
+    d_P = torch.from_numpy(P).cuda()
+    d_out = torch.zeros_like(d_P)
+    d_fall = torch.zeros(P.shape[0], device="cuda")
+    torch.cuda.synchronize()
+    e.set_kernel(capi.KERNEL_THIN_PLATE)
+    e.set_term(capi.TERM_LINEAR)
+    e.set_points_dev(d_rest.data_ptr(), d_delta.data_ptr(), 64)
+    e.build_async()                      # no host sync between build and deform
+    e.deform_dev(P.shape[0], d_P.data_ptr(), d_out.data_ptr(), d_falloff=d_fall.data_ptr())
+    rep = e.build_result()
+    assert rep.terminationtype == 1
+    stream.synchronize()
+    table, W, radii = _oracle_model(oracle, fo.KERNEL_THIN_PLATE, [], 0, rest, deform)
+    ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    assert parity_ratio(d_out.cpu().numpy(), ref, P, TOL_FP32) <= 1.0
+    assert torch.equal(d_fall.cpu(), torch.ones(P.shape[0]))
+    assert torch.equal(d_P.cpu(), torch.from_numpy(P))          # input untouched when not aliased
+    e.set_stream(None)
+    e.close()
+
+
+def test_vertex_range_split_is_bit_identical(hip_lib):
+    """a split mesh evaluated range by range equals the whole-mesh result."""
+    P = synth.head_mesh(50_000)
+    rest = synth.control_points(128, "head")
+    e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, synth.deformed_rig(rest))
+    e.build()
+    whole, _ = e.deform(P)
+    cuts = [0, 1024, 13_312, 13_313, 40_000, 50_000]    # aligned and ragged range starts
+    parts = [e.deform(P[a:b])[0] for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts), whole)
+    e.close()
+
+
+def test_model_export_import_replicates_bitwise(hip_lib):
+    P = synth.head_mesh(30_000)
+    rest = synth.control_points(96, "head")
+    for kind, params in ((capi.KERNEL_THIN_PLATE, []), (capi.KERNEL_GAUSSIAN_QNN, [1.0, 5.0])):
+        a = _engine(kind, params, capi.TERM_LINEAR, rest, synth.deformed_rig(rest))
+        a.build()
+        blob = a.export_model()
+        assert blob.size == a.model_bytes()
+        b = capi.Engine()
+        b.import_model(blob)
+        out_a, _ = a.deform(P)
+        out_b, _ = b.deform(P)
+        assert np.array_equal(out_a, out_b)
+        Wa, _ = a.get_weights()
+        Wb, _ = b.get_weights()
+        assert np.array_equal(Wa, Wb)
+        with pytest.raises(capi.FdError):
+            b.import_model(blob[:100])
+        a.close(); b.close()
+
+
+def test_rebuild_with_new_deltas_and_bigger_rig(hip_lib, oracle):
+    """One context reused across cooks, as a SOP instance does (rebuilt every cook, B12)."""
+    P = synth.head_mesh(4000)
+    e = capi.Engine()
+    e.set_kernel(capi.KERNEL_THIN_PLATE)
+    e.set_term(capi.TERM_LINEAR)
+    for M, frame in ((40, 0), (200, 1), (24, 2), (200, 3)):
+        rest = synth.control_points(M, "head")
+        deform = synth.deformed_rig(rest, frame)
+        e.set_points(rest, (deform - rest).astype(np.float32))
+        e.build()
+        out, _ = e.deform(P)
+        table, W, radii = _oracle_model(oracle, fo.KERNEL_THIN_PLATE, [], 0, rest, deform)
+        ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+        assert parity_ratio(out, ref, P, TOL_FP32) <= 1.0, (M, frame)
+    e.close()
+
+
+def test_noise_deltas_need_and_pass_fp64(hip_lib, oracle):
+    """white-noise deltas make the weights cancel massively."""
+    P = synth.head_mesh(3000)
+    rest = synth.control_points(256, "head")
+    deform = (rest + synth.noise_deltas(256)).astype(np.float32)
+    table, W, radii = _oracle_model(oracle, fo.KERNEL_THIN_PLATE, [], 0, rest, deform)
+    ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, deform, capi.EVAL_FP64)
+    e.build()
+    out, _ = e.deform(P)
+    assert parity_ratio(out, ref, P, TOL_FP32) <= 1.0
+    e.close()
+
+
+def test_sop_cook_matches_oracle_and_reports_like_reference(hip_lib, oracle):
+    P = synth.sphere_mesh(10_000)
+    rest = synth.control_points(32, "sphere")
+    deform = synth.deformed_rig(rest)
+    node = FaceDeformSOP()
+    node.set("kernel", 1)            # thin-plate (BASELINE config 1)
+    node.set("radius", 0.7)
+    node.set("falloffrate", 1.5)
+    dist2 = (0.6 * np.abs(P[:, 0])).astype(np.float32)
+    res = node.cook(P, rest, deform, dist2=dist2)
+    assert res.severity == capi.FDSOP_MESSAGE, res.messages
+    assert res.infos == ["Termination type: 1, Iterations: 36"]       # reference :371
+    table, W, radii = _oracle_model(oracle, fo.KERNEL_THIN_PLATE, [0.0], 0, rest, deform)
+    r2 = np.float32(0.7) * np.float32(0.7)
+    ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=dist2, radius2=r2,
+                                  falloffrate=1.5)
+    assert parity_ratio(res.P, ref, P, 2e-5) <= 1.0
+    assert np.allclose(res.fd_falloff, ref_fall, rtol=2e-6, atol=1e-7)
+    assert np.array_equal(res.Cd, np.ones_like(P))                     # :386-388
+    # defaults: QNN Gaussian, linear term; no dist attribute -> warning text of :398
+    node2 = FaceDeformSOP()
+    res2 = node2.cook(P, rest, deform)
+    assert res2.warnings == ["Can't find distance capture attribute. Won't apply radius nor falloff."]
+    t2, W2, r2_ = _oracle_model(oracle, fo.KERNEL_GAUSSIAN_QNN, [1.0, 5.0, 0.0], 0, rest, deform)
+    ref2, _ = oracle.deform(t2, fo.KERNEL_GAUSSIAN_QNN, r2_, W2, P)
+    assert parity_ratio(res2.P, ref2, P, TOL_FP32) <= 1.0
+    # tangent toggle without frames -> the reference's warning, and no projection
+    node2.set("tangent", 1)
+    res3 = node2.cook(P, rest, deform)
+    assert any(w.startswith("Append PolyFrameSOP") for w in res3.warnings)
+    assert np.array_equal(res3.P, res2.P)
+    # duplicate rig points -> "Can't solve the problem."
+    bad = rest.copy(); bad[4] = bad[0]
+    res4 = node2.cook(P, bad, deform)
+    assert res4.errors == ["Can't solve the problem."] and np.array_equal(res4.P, P)

@@ -1,0 +1,232 @@
+// ubench_valu.hip -- instruction issue rates on gfx950 that decide the shape of the
+// evaluation kernel: fp32 fma vs packed fma vs transcendentals vs MFMA, alone and mixed.
+// Build:  hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o tools/ubench_valu
+// Output: one line per (kernel, waves/SIMD): wave-instructions per ns chip-wide and the
+//         implied cycles per wave-instruction per SIMD at the measured clock.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ITERS = 2048;
+
+#define REP8(x) x x x x x x x x
+
+// each kernel: 8 independent accumulators, body = 32 instructions per iteration (or as noted)
+__global__ void k_fma(float *out, float a, float b)
+{
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+}
+
+__global__ void k_fma_sgpr(float *out, float a, float b)
+{
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("v_fmac_f32 %0, %8, %1\n v_fmac_f32 %1, %8, %2\n v_fmac_f32 %2, %8, %3\n v_fmac_f32 %3, %8, %4\n"
+                         "v_fmac_f32 %4, %8, %5\n v_fmac_f32 %5, %8, %6\n v_fmac_f32 %6, %8, %7\n v_fmac_f32 %7, %8, %0\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "s"(a), "s"(b));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+}
+
+__global__ void k_pk_fma(float *out, float a, float b)
+{
+    f32x2 r0 = {(float)threadIdx.x, 1.f}, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f, r4 = r0 + 4.f, r5 = r0 + 5.f, r6 = r0 + 6.f, r7 = r0 + 7.f;
+    f32x2 va = {a, a}, vb = {b, b};
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                         "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(va), "v"(vb));
+    }
+    f32x2 s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+}
+
+#define TRANS_KERNEL(NAME, OP)                                                                        \
+    __global__ void NAME(float *out, float a, float b)                                                \
+    {                                                                                                 \
+        float r0 = threadIdx.x + 1.5f, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+        for (int i = 0; i < ITERS; ++i) {                                                             \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u)                                             \
+                asm volatile(OP " %0, %0\n " OP " %1, %1\n " OP " %2, %2\n " OP " %3, %3\n"           \
+                             OP " %4, %4\n " OP " %5, %5\n " OP " %6, %6\n " OP " %7, %7\n"           \
+                             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)); \
+        }                                                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + a + b;   \
+    }
+TRANS_KERNEL(k_log, "v_log_f32")
+TRANS_KERNEL(k_exp, "v_exp_f32")
+TRANS_KERNEL(k_sqrt, "v_sqrt_f32")
+
+// the evaluation loop's mix per pair: 10 full-rate VALU + 1 transcendental (x8 pairs = 88 instr)
+__global__ void k_mix10_1(float *out, float a, float b)
+{
+    float r0 = threadIdx.x + 1.5f, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float t0 = 1, t1 = 2, t2 = 3, t3 = 4, t4 = 5, t5 = 6, t6 = 7, t7 = 8;
+    for (int i = 0; i < ITERS; ++i) {
+#define PAIR(R, T)                                                                                   \
+        asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n" \
+                     "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_log_f32 %1, %0\n"        \
+                     "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n" \
+                     "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n"                           \
+                     : "+v"(R), "+v"(T) : "v"(a), "v"(b));
+        PAIR(r0, t0) PAIR(r1, t1) PAIR(r2, t2) PAIR(r3, t3) PAIR(r4, t4) PAIR(r5, t5) PAIR(r6, t6) PAIR(r7, t7)
+#undef PAIR
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + t0 + t1 + t2 + t3 + t4 + t5 + t6 + t7;
+}
+
+// same arithmetic packed two pairs at a time: 5 pk + 2 trans + ... = per 2 pairs: 10 pk-VALU + 2 trans
+__global__ void k_mixpk(float *out, float a, float b)
+{
+    f32x2 r0 = {(float)threadIdx.x + 1.5f, 2.5f}, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f;
+    f32x2 t0 = {1, 2}, t1 = {2, 3}, t2 = {3, 4}, t3 = {4, 5};
+    float l0 = 1.5f, l1 = 2.5f, l2 = 3.5f, l3 = 4.5f, m0 = 1.25f, m1 = 2.25f, m2 = 3.25f, m3 = 4.25f;
+    f32x2 va = {a, a}, vb = {b, b};
+    for (int i = 0; i < ITERS; ++i) {
+#define PAIR2(R, T, LA, LB)                                                                                  \
+        asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %0, %0, %4, %5\n" \
+                     "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %0, %0, %4, %5\n"                    \
+                     "v_log_f32 %2, %2\n v_log_f32 %3, %3\n"                                         \
+                     "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %0, %1, %4, %5\n v_pk_fma_f32 %0, %0, %4, %5\n" \
+                     "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %0, %0, %4, %5\n"                    \
+                     : "+v"(R), "+v"(T), "+v"(LA), "+v"(LB) : "v"(va), "v"(vb));
+        PAIR2(r0, t0, l0, m0) PAIR2(r1, t1, l1, m1) PAIR2(r2, t2, l2, m2) PAIR2(r3, t3, l3, m3)
+#undef PAIR2
+    }
+    f32x2 s = r0 + r1 + r2 + r3 + t0 + t1 + t2 + t3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y + l0 + l1 + l2 + l3 + m0 + m1 + m2 + m3;
+}
+
+// 7 VALU + 1 trans + one 4x4x1 MFMA doing the 3-wide accumulate
+__global__ void k_mix_mfma(float *out, float a, float b)
+{
+    float r0 = threadIdx.x + 1.5f, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3;
+    float t0 = 1, t1 = 2, t2 = 3, t3 = 4;
+    f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < ITERS; ++i) {
+#define PAIRM(R, T, C)                                                                               \
+        asm volatile("v_fma_f32 %0, %0, %3, %4\n v_fma_f32 %0, %0, %3, %4\n v_fma_f32 %0, %0, %3, %4\n" \
+                     "v_fma_f32 %0, %0, %3, %4\n v_fma_f32 %0, %0, %3, %4\n v_fma_f32 %0, %0, %3, %4\n" \
+                     "v_log_f32 %1, %0\n v_fma_f32 %0, %1, %3, %4\n s_nop 1\n"                        \
+                     "v_mfma_f32_4x4x1_16b_f32 %2, %3, %0, %2\n"                                      \
+                     : "+v"(R), "+v"(T), "+v"(C) : "v"(a), "v"(b));
+        PAIRM(r0, t0, c0) PAIRM(r1, t1, c1) PAIRM(r2, t2, c2) PAIRM(r3, t3, c3)
+        PAIRM(r0, t0, c0) PAIRM(r1, t1, c1) PAIRM(r2, t2, c2) PAIRM(r3, t3, c3)
+#undef PAIRM
+    }
+    f32x4 s = c0 + c1 + c2 + c3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3] + r0 + r1 + r2 + r3 + t0 + t1 + t2 + t3;
+}
+
+__global__ void k_mfma4(float *out, float a, float b)
+{
+    f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %8, %9, %0\n v_mfma_f32_4x4x1_16b_f32 %1, %8, %9, %1\n"
+                         "v_mfma_f32_4x4x1_16b_f32 %2, %8, %9, %2\n v_mfma_f32_4x4x1_16b_f32 %3, %8, %9, %3\n"
+                         "v_mfma_f32_4x4x1_16b_f32 %4, %8, %9, %4\n v_mfma_f32_4x4x1_16b_f32 %5, %8, %9, %5\n"
+                         "v_mfma_f32_4x4x1_16b_f32 %6, %8, %9, %6\n v_mfma_f32_4x4x1_16b_f32 %7, %8, %9, %7\n"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));
+    }
+    f32x4 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void k_fma64(float *out, float a, float b)
+{
+    double r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    double da = a, db = b;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                         "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(da), "v"(db));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7);
+}
+
+__global__ void k_mfma64(float *out, float a, float b)
+{
+    f64x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    double da = a, db = b;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %4, %5, %0\n v_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n"
+                         "v_mfma_f64_16x16x4_f64 %2, %4, %5, %2\n v_mfma_f64_16x16x4_f64 %3, %4, %5, %3\n"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(da), "v"(db));
+    }
+    f64x4 s = c0 + c1 + c2 + c3;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(s[0] + s[1] + s[2] + s[3]);
+}
+
+struct Bench { const char *name; void (*fn)(float *, float, float); int instr_per_iter; const char *note; };
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    printf("device %s, %d CUs, clockRate %d kHz\n", prop.gcnArchName, ncu, prop.clockRate);
+    float *out;
+    CHECK(hipMalloc(&out, sizeof(float) * 256 * ncu * 8));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const Bench benches[] = {
+        {"v_fma_f32", k_fma, 32, "full-rate VALU"},
+        {"v_fmac_f32 sgpr-src", k_fma_sgpr, 32, "SGPR operand, 1-deep dependency ring"},
+        {"v_pk_fma_f32", k_pk_fma, 32, "2 fma per lane per instr"},
+        {"v_log_f32", k_log, 32, "transcendental"},
+        {"v_exp_f32", k_exp, 32, "transcendental"},
+        {"v_sqrt_f32", k_sqrt, 32, "transcendental"},
+        {"mix 10 fma + 1 log", k_mix10_1, 88, "the evaluation loop's mix, 8 pairs"},
+        {"mix 10 pk_fma + 2 log", k_mixpk, 48, "same, packed: 8 pairs = 4 x (10 pk + 2 log)"},
+        {"mix 7 fma + log + mfma4x4x1", k_mix_mfma, 72, "8 pairs, accumulate on the matrix pipe (9 issue slots/pair)"},
+        {"v_mfma_f32_4x4x1", k_mfma4, 32, "512 flop per instr"},
+        {"v_fma_f64", k_fma64, 32, ""},
+        {"v_mfma_f64_16x16x4", k_mfma64, 32, "2048 flop per instr"},
+    };
+    for (const Bench &b : benches) {
+        for (int wps = 1; wps <= 8; wps *= 2) {
+            const int blocks = ncu * wps;   // 256 threads = 4 waves = 1 wave per SIMD per block
+            hipLaunchKernelGGL(b.fn, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+            CHECK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(b.fn, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                best = ms < best ? ms : best;
+            }
+            const double winstr = (double)blocks * 4 * ITERS * b.instr_per_iter;   // wave-instructions
+            const double per_simd_per_ns = winstr / (best * 1e6) / (ncu * 4);
+            printf("%-30s waves/SIMD %d  %8.3f ms  %7.3f winstr/ns/SIMD  -> %6.2f cycles/winstr/SIMD @2.4GHz  (%s)\n",
+                   b.name, wps, best, per_simd_per_ns, 2.4 / per_simd_per_ns, b.note);
+        }
+    }
+    return 0;
+}
