@@ -129,7 +129,10 @@ def main():
 
     precision = capi.EVAL_FP64 if args.precision == "fp64" else capi.EVAL_FP32
     eng = capi.Engine(device=local_rank, precision=precision, variant=args.variant)
-    stream = torch.cuda.current_stream()
+    # a stream of our own: torch's default stream has handle 0, which fd_set_stream reads as
+    # "use the context's stream", and HIP events only time the stream they are recorded on
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
     eng.set_kernel(capi.KERNEL_THIN_PLATE)
     eng.set_term(capi.TERM_LINEAR)

@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     obj_dir = os.path.join(_PKG, "build")
     os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc_path()
-    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(_ROOT, "include")]
+    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(_ROOT, "include")]
     objs = []
     procs = []
     for src in SOURCES:

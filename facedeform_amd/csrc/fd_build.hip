@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_lu_panel(double *A, int lda, 
                 const double l = a[t][j] * inv;
                 a[t][j] = l;
 #pragma clang loop unroll(full)
-                for (int c = j + 1; c < NB; ++c) a[t][c] -= l * s_row[buf][gw][c];
+                for (int c = j + 1; c < NB; ++c) a[t][c] = fma(-l, s_row[buf][gw][c], a[t][c]);
             }
         }
     }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_lu_trail(double *A, int lda, int npad, 
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int i = g + 4 * s;
-            if (i > j) u[s] -= sL[i][j] * uj;
+            if (i > j) u[s] = fma(-sL[i][j], uj, u[s]);
         }
     }
     if (wave == 0) {
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_backsub(double *A, int lda, int npad, i
         __syncthreads();
         if (tid < 96) {
             const int i = tid & 31, rc = tid >> 5;
-            if (i < k) sx[i][rc] -= sU[i][k] * sx[k][rc];
+            if (i < k) sx[i][rc] = fma(-sU[i][k], sx[k][rc], sx[i][rc]);
         }
         __syncthreads();
     }
@@ -426,9 +426,9 @@ __global__ __launch_bounds__(256) void k_backsub(double *A, int lda, int npad, i
         double y0 = 0.0, y1 = 0.0, y2 = 0.0;
         for (int k = 0; k < 32; ++k) {
             const double uik = A[(size_t)(b0 + k) * lda + i];
-            y0 += uik * sx[k][0];
-            y1 += uik * sx[k][1];
-            y2 += uik * sx[k][2];
+            y0 = fma(uik, sx[k][0], y0);
+            y1 = fma(uik, sx[k][1], y1);
+            y2 = fma(uik, sx[k][2], y2);
         }
         A[(size_t)(npad + 0) * lda + i] -= y0;
         A[(size_t)(npad + 1) * lda + i] -= y1;

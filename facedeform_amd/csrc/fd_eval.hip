@@ -19,6 +19,9 @@
 //   * fp32 partial sums are folded into fp64 accumulators every 64 centres, which
 //     bounds the accumulation error independently of M.
 //   * FP64 variant: same structure, all arithmetic in fp64.
+// Built with -ffp-contract=off: every fused multiply-add is written out, so a vertex
+// gets the same bits whichever lane / register slot it lands in (range splits are
+// bit-identical) and the fp32 epilogue rounds like the reference's unfused CPU code.
 #include "fd_internal.h"
 
 namespace fd {
@@ -27,6 +30,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 64;  // centres per fp32 partial sum
+constexpr int kDefaultVariant = 102;  // packed lanes, scalar-loaded records, V = 4
 
 typedef const __attribute__((address_space(4))) Rec32 *ConstRec32;
 typedef const __attribute__((address_space(4))) Rec64 *ConstRec64;
@@ -137,23 +141,69 @@ __device__ __forceinline__ void epilogue_store(const EvalParams &p, int64_t i, c
 }
 
 // ---- fp32 evaluation ----------------------------------------------------------
-template <int KIND, int V, bool USE_LDS>
+// LaneT = float: one vertex per register; LaneT = f32x2: two vertices per register
+// pair, arithmetic on v_pk_{add,mul,fma}_f32 (measured 1.29x the issue rate of the
+// scalar mix on gfx950, tools/ubench_valu.hip).  Wave-uniform operands are splat by
+// the instruction's op_sel bits, so they cost no extra registers or moves.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Lanes;
+template <> struct Lanes<float> {
+    static constexpr int W = 1;
+    static __device__ __forceinline__ float splat(float x) { return x; }
+    static __device__ __forceinline__ float get(float v, int) { return v; }
+    static __device__ __forceinline__ void set(float &v, int, float x) { v = x; }
+};
+template <> struct Lanes<f32x2> {
+    static constexpr int W = 2;
+    static __device__ __forceinline__ f32x2 splat(float x) { return (f32x2){x, x}; }
+    static __device__ __forceinline__ float get(f32x2 v, int k) { return k ? v.y : v.x; }
+    static __device__ __forceinline__ void set(f32x2 &v, int k, float x) { if (k) v.y = x; else v.x = x; }
+};
+
+__device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f32x2 vfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int KIND>
+__device__ __forceinline__ f32x2 phi32(f32x2 d2, float s)
+{
+    if constexpr (KIND == FD_KERNEL_THIN_PLATE) {
+        const f32x2 l = {__builtin_amdgcn_logf(d2.x), __builtin_amdgcn_logf(d2.y)};
+        return d2 * l;
+    } else if constexpr (KIND == FD_KERNEL_GAUSSIAN || KIND == FD_KERNEL_GAUSSIAN_QNN) {
+        const f32x2 e = d2 * s;
+        return (f32x2){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    } else if constexpr (KIND == FD_KERNEL_BIHARMONIC) {
+        return (f32x2){__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+    } else {
+        const f32x2 r = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+        return d2 * r;
+    }
+}
+
+// V vertices per lane in Q = V / W registers; vertex v sits in register v / W, component v % W
+template <int KIND, int V, bool USE_LDS, typename LaneT>
 __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
 {
+    using L = Lanes<LaneT>;
+    constexpr int W = L::W;
+    constexpr int Q = V / W;
+    static_assert(V % W == 0, "V must be a multiple of the lane width");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * (kBlock * V);
 
-    float px[V], py[V], pz[V], d2v[V];
+    LaneT px[Q], py[Q], pz[Q];
+    float d2v[V];
     bool live[V];
     bool any_live = false;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const int64_t i = base + v * kBlock + tid;
         const int64_t ic = i < p.N ? i : p.N - 1;
-        px[v] = p.P_in[3 * ic];
-        py[v] = p.P_in[3 * ic + 1];
-        pz[v] = p.P_in[3 * ic + 2];
+        L::set(px[v / W], v % W, p.P_in[3 * ic]);
+        L::set(py[v / W], v % W, p.P_in[3 * ic + 1]);
+        L::set(pz[v / W], v % W, p.P_in[3 * ic + 2]);
         d2v[v] = p.dist2 ? p.dist2[ic] : 0.f;
         live[v] = (i < p.N) && !(d2v[v] > p.radius2);   // gate on squares, :402,:408
         any_live |= live[v];
@@ -165,9 +215,10 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
     for (int v = 0; v < V; ++v) {
         // affine part V*[1;x] first (rows M..M+3 of the weights)
         const float *a = p.model->affine32;
-        accx[v] = (double)(a[0] + a[1] * px[v] + a[2] * py[v] + a[3] * pz[v]);
-        accy[v] = (double)(a[4] + a[5] * px[v] + a[6] * py[v] + a[7] * pz[v]);
-        accz[v] = (double)(a[8] + a[9] * px[v] + a[10] * py[v] + a[11] * pz[v]);
+        const float x = L::get(px[v / W], v % W), y = L::get(py[v / W], v % W), z = L::get(pz[v / W], v % W);
+        accx[v] = (double)__builtin_fmaf(a[3], z, __builtin_fmaf(a[2], y, __builtin_fmaf(a[1], x, a[0])));
+        accy[v] = (double)__builtin_fmaf(a[7], z, __builtin_fmaf(a[6], y, __builtin_fmaf(a[5], x, a[4])));
+        accz[v] = (double)__builtin_fmaf(a[11], z, __builtin_fmaf(a[10], y, __builtin_fmaf(a[9], x, a[8])));
     }
 
     // wave-uniform skip: every vertex of this wave is gated out or out of range
@@ -183,12 +234,13 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
     }
 
     if (wave_work) {
+        const LaneT bias = L::splat(d2_bias<KIND>());
         for (int j0 = 0; j0 < p.Mpad; j0 += kChunk) {
             const int jend = (j0 + kChunk < p.Mpad) ? j0 + kChunk : p.Mpad;
-            float ax[V], ay[V], az[V];
+            LaneT ax[Q], ay[Q], az[Q];
 #pragma unroll
-            for (int v = 0; v < V; ++v) ax[v] = ay[v] = az[v] = 0.f;
-#pragma unroll 8
+            for (int q = 0; q < Q; ++q) ax[q] = ay[q] = az[q] = L::splat(0.f);
+#pragma unroll 4
             for (int j = j0; j < jend; ++j) {
                 float cx, cy, cz, s, wx, wy, wz;
                 if constexpr (USE_LDS) {
@@ -201,25 +253,35 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
                     cx = r->cx; cy = r->cy; cz = r->cz; s = r->s;
                     wx = r->wx; wy = r->wy; wz = r->wz;
                 }
+                // stage by stage across the Q register slots: Q independent dependency
+                // chains interleave, so no stage waits on (or pads for) its predecessor
+                LaneT dx[Q], dy[Q], dz[Q], d2[Q], t[Q];
 #pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const float dx = px[v] - cx;
-                    const float dy = py[v] - cy;
-                    const float dz = pz[v] - cz;
-                    float d2 = __builtin_fmaf(dx, dx, d2_bias<KIND>());
-                    d2 = __builtin_fmaf(dy, dy, d2);
-                    d2 = __builtin_fmaf(dz, dz, d2);
-                    const float t = phi32<KIND>(d2, s);
-                    ax[v] = __builtin_fmaf(t, wx, ax[v]);
-                    ay[v] = __builtin_fmaf(t, wy, ay[v]);
-                    az[v] = __builtin_fmaf(t, wz, az[v]);
-                }
+                for (int q = 0; q < Q; ++q) dx[q] = px[q] - cx;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) dy[q] = py[q] - cy;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) dz[q] = pz[q] - cz;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) d2[q] = vfma(dx[q], dx[q], bias);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) d2[q] = vfma(dy[q], dy[q], d2[q]);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) d2[q] = vfma(dz[q], dz[q], d2[q]);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) t[q] = phi32<KIND>(d2[q], s);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) ax[q] = vfma(t[q], L::splat(wx), ax[q]);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) ay[q] = vfma(t[q], L::splat(wy), ay[q]);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) az[q] = vfma(t[q], L::splat(wz), az[q]);
             }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                accx[v] += (double)ax[v];
-                accy[v] += (double)ay[v];
-                accz[v] += (double)az[v];
+                accx[v] += (double)L::get(ax[v / W], v % W);
+                accy[v] += (double)L::get(ay[v / W], v % W);
+                accz[v] += (double)L::get(az[v / W], v % W);
             }
         }
     }
@@ -228,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
     for (int v = 0; v < V; ++v) {
         const int64_t i = base + v * kBlock + tid;
         if (i >= p.N) continue;
-        const float pos[3] = {px[v], py[v], pz[v]};
+        const float pos[3] = {L::get(px[v / W], v % W), L::get(py[v / W], v % W), L::get(pz[v / W], v % W)};
         if (!live[v] || !built) {
             if (p.P_out != p.P_in) {
                 p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
@@ -266,9 +328,9 @@ __global__ __launch_bounds__(kBlock) void k_deform64(const EvalParams p)
     for (int v = 0; v < V; ++v) {
         const double *a = p.model->affine64;
         const double x = pxf[v], y = pyf[v], z = pzf[v];
-        accx[v] = a[0] + a[1] * x + a[2] * y + a[3] * z;
-        accy[v] = a[4] + a[5] * x + a[6] * y + a[7] * z;
-        accz[v] = a[8] + a[9] * x + a[10] * y + a[11] * z;
+        accx[v] = fma(a[3], z, fma(a[2], y, fma(a[1], x, a[0])));
+        accy[v] = fma(a[7], z, fma(a[6], y, fma(a[5], x, a[4])));
+        accz[v] = fma(a[11], z, fma(a[10], y, fma(a[9], x, a[8])));
     }
     if (__any(any_live) && built) {
 #pragma unroll 2
@@ -281,11 +343,11 @@ __global__ __launch_bounds__(kBlock) void k_deform64(const EvalParams p)
                 const double dx = (double)pxf[v] - cx;
                 const double dy = (double)pyf[v] - cy;
                 const double dz = (double)pzf[v] - cz;
-                const double d2 = dx * dx + dy * dy + dz * dz;
+                const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
                 const double t = phi64<KIND>(d2, s);
-                accx[v] += t * wx;
-                accy[v] += t * wy;
-                accz[v] += t * wz;
+                accx[v] = fma(t, wx, accx[v]);
+                accy[v] = fma(t, wy, accy[v]);
+                accz[v] = fma(t, wz, accz[v]);
             }
         }
     }
@@ -316,17 +378,35 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
         hipLaunchKernelGGL((k_deform64<KIND, V>), dim3(grid), dim3(kBlock), 0, stream, p);
         return hipGetLastError();
     }
-    constexpr int V = 4;
-    const int64_t per = (int64_t)kBlock * V;
-    const unsigned grid = (unsigned)((a.N + per - 1) / per);
+    // variant = lanes * 100 + source * 10 + log2(V):  lanes 0 scalar / 1 packed,
+    // source 0 scalar-loaded records / 1 LDS-staged records.  0 = the default below.
+    int variant = a.variant > 0 ? a.variant : kDefaultVariant;
     const size_t lds_bytes = (size_t)a.Mpad * sizeof(Rec32);
-    // variant 2 = LDS-staged records (only while one tile holds them all)
-    if (a.variant == 2 && lds_bytes <= 64 * 1024) {
-        hipLaunchKernelGGL((k_deform32<KIND, V, true>), dim3(grid), dim3(kBlock), lds_bytes, stream, p);
-    } else {
-        hipLaunchKernelGGL((k_deform32<KIND, V, false>), dim3(grid), dim3(kBlock), 0, stream, p);
+    if ((variant / 10) % 10 == 1 && lds_bytes > 64 * 1024) variant -= 10;   // one LDS tile must hold them all
+#define FD_LAUNCH(VV, LDS, LT)                                                                      \
+    do {                                                                                             \
+        const int64_t per = (int64_t)kBlock * (VV);                                                  \
+        const unsigned grid = (unsigned)((a.N + per - 1) / per);                                     \
+        hipLaunchKernelGGL((k_deform32<KIND, VV, LDS, LT>), dim3(grid), dim3(kBlock),                \
+                           (LDS) ? lds_bytes : 0, stream, p);                                        \
+        return hipGetLastError();                                                                    \
+    } while (0)
+    switch (variant) {
+    case 1: FD_LAUNCH(2, false, float);
+    case 2: FD_LAUNCH(4, false, float);
+    case 3: FD_LAUNCH(8, false, float);
+    case 11: FD_LAUNCH(2, true, float);
+    case 12: FD_LAUNCH(4, true, float);
+    case 13: FD_LAUNCH(8, true, float);
+    case 101: FD_LAUNCH(2, false, f32x2);
+    case 102: FD_LAUNCH(4, false, f32x2);
+    case 103: FD_LAUNCH(8, false, f32x2);
+    case 111: FD_LAUNCH(2, true, f32x2);
+    case 112: FD_LAUNCH(4, true, f32x2);
+    case 113: FD_LAUNCH(8, true, f32x2);
+    default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+#undef FD_LAUNCH
 }
 
 }  // namespace
@@ -356,7 +436,8 @@ const char *deform_kernel_name(int kind, int precision, int variant)
 {
     (void)kind;
     if (precision == FD_EVAL_FP64) return "k_deform64";
-    return variant == 2 ? "k_deform32<LDS>" : "k_deform32<SCALAR>";
+    (void)variant;
+    return "k_deform32";
 }
 
 }  // namespace fd

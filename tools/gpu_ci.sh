@@ -22,6 +22,8 @@ for step in "$@"; do
         ubench) run ubench ./tools/ubench_valu ;;
         bench) run bench python bench.py --steps 100 --warmup 10 ;;
         bench_nocpu) run bench_nocpu python bench.py --steps 100 --warmup 10 --no-cpu-baseline ;;
+        prof) mkdir -p gpurun_out/prof; (cd /tmp && export TMPDIR=/tmp && run_prof() { :; }); 
+              run prof rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline ;;
         *) echo "unknown step $step" ;;
     esac
 done

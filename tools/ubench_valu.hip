@@ -182,6 +182,86 @@ __global__ void k_mfma64(float *out, float a, float b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(s[0] + s[1] + s[2] + s[3]);
 }
 
+// ---- SGPR-vs-VGPR uniform operands -------------------------------------------------
+__global__ void k_fma_s0(float *out, float a, float b)   // v_fma_f32 v, s, v, v : independent accumulators
+{
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float vb = b;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("v_fma_f32 %0, %8, %0, %9\n v_fma_f32 %1, %8, %1, %9\n v_fma_f32 %2, %8, %2, %9\n v_fma_f32 %3, %8, %3, %9\n"
+                         "v_fma_f32 %4, %8, %4, %9\n v_fma_f32 %5, %8, %5, %9\n v_fma_f32 %6, %8, %6, %9\n v_fma_f32 %7, %8, %7, %9\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "s"(a), "v"(vb));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+}
+
+__global__ void k_pk_fma_s(float *out, float a, float b)   // v_pk_fma_f32 v, v, s[pair] op_sel_hi, v
+{
+    f32x2 r0 = {(float)threadIdx.x, 1.f}, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f, r4 = r0 + 4.f, r5 = r0 + 5.f, r6 = r0 + 6.f, r7 = r0 + 7.f;
+    f32x2 sa = {a, b};
+    f32x2 vb = {b, b};
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %1, %8, %9 op_sel_hi:[1,0,1]\n"
+                         "v_pk_fma_f32 %2, %2, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %3, %8, %9 op_sel_hi:[1,0,1]\n"
+                         "v_pk_fma_f32 %4, %4, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %5, %5, %8, %9 op_sel_hi:[1,0,1]\n"
+                         "v_pk_fma_f32 %6, %6, %8, %9 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %7, %7, %8, %9 op_sel_hi:[1,0,1]\n"
+                         : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "s"(sa), "v"(vb));
+    }
+    f32x2 s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+}
+
+// the evaluation kernel's exact per-centre sequence for two packed register slots (24 VALU),
+// uniform operands in SGPRs (as the SCALAR variant issues them) ...
+#define EVAL_SEQ(C01, C23, W01, W23, BIAS)                                                                   \
+    asm volatile(                                                                                            \
+        "v_pk_add_f32 %6, %0, " C01 " op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
+        "v_pk_add_f32 %7, %3, " C01 " op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"                           \
+        "v_pk_add_f32 %8, %1, " C01 " op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"                              \
+        "v_pk_add_f32 %9, %4, " C01 " op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"                              \
+        "v_pk_fma_f32 %6, %6, %6, " BIAS " op_sel_hi:[1,1,0]\n"                                              \
+        "v_pk_fma_f32 %7, %7, %7, " BIAS " op_sel_hi:[1,1,0]\n"                                              \
+        "v_pk_add_f32 %10, %2, " C23 " op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"                          \
+        "v_pk_add_f32 %11, %5, " C23 " op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"                          \
+        "v_pk_fma_f32 %6, %8, %8, %6\n v_pk_fma_f32 %7, %9, %9, %7\n"                                        \
+        "v_pk_fma_f32 %6, %10, %10, %6\n v_pk_fma_f32 %7, %11, %11, %7\n"                                    \
+        "v_log_f32 %12, %13\n v_log_f32 %13, %12\n v_log_f32 %14, %15\n v_log_f32 %15, %14\n"                \
+        "v_pk_mul_f32 %8, %6, %8\n v_pk_mul_f32 %9, %7, %9\n"                                                \
+        "v_pk_fma_f32 %16, %8, " W01 ", %16 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %17, %9, " W01 ", %17 op_sel_hi:[1,0,1]\n" \
+        "v_pk_fma_f32 %18, %8, " W01 ", %18 op_sel:[0,1,0]\n v_pk_fma_f32 %19, %9, " W01 ", %19 op_sel:[0,1,0]\n"       \
+        "v_pk_fma_f32 %20, %8, " W23 ", %20 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %21, %9, " W23 ", %21 op_sel_hi:[1,0,1]\n" \
+        : "+v"(px0), "+v"(py0), "+v"(pz0), "+v"(px1), "+v"(py1), "+v"(pz1), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), \
+          "+v"(t4), "+v"(t5), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) \
+        : "s"(c01), "s"(c23), "s"(w01), "s"(w23), "s"(bias), "v"(vc01), "v"(vc23), "v"(vw01), "v"(vw23), "v"(vbias))
+
+#define EVAL_DECL                                                                                            \
+    f32x2 px0 = {(float)threadIdx.x, 1.f}, py0 = px0 + 1.f, pz0 = px0 + 2.f, px1 = px0 + 3.f, py1 = px0 + 4.f, pz1 = px0 + 5.f; \
+    f32x2 t0 = px0, t1 = px0, t2 = px0, t3 = px0, t4 = px0, t5 = px0;                                        \
+    float l0 = 1.5f, l1 = 2.5f, l2 = 3.5f, l3 = 4.5f;                                                        \
+    f32x2 a0 = {0, 0}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0;                                          \
+    f32x2 c01 = {a, b}, c23 = {b, a}, w01 = {a, a}, w23 = {b, b}, bias = {1e-37f, 1e-37f};                   \
+    f32x2 vc01 = c01, vc23 = c23, vw01 = w01, vw23 = w23, vbias = bias;
+
+__global__ void k_evalseq_sgpr(float *out, float a, float b)
+{
+    EVAL_DECL
+    for (int i = 0; i < ITERS; ++i) { EVAL_SEQ("%22", "%23", "%24", "%25", "%26"); EVAL_SEQ("%22", "%23", "%24", "%25", "%26"); }
+    f32x2 s = a0 + a1 + a2 + a3 + a4 + a5 + t0 + t1;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y + l0 + l1 + l2 + l3;
+}
+// ... and the same sequence with the uniform operands in VGPR pairs
+__global__ void k_evalseq_vgpr(float *out, float a, float b)
+{
+    EVAL_DECL
+    for (int i = 0; i < ITERS; ++i) { EVAL_SEQ("%27", "%28", "%29", "%30", "%31"); EVAL_SEQ("%27", "%28", "%29", "%30", "%31"); }
+    f32x2 s = a0 + a1 + a2 + a3 + a4 + a5 + t0 + t1;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y + l0 + l1 + l2 + l3;
+}
+
 struct Bench { const char *name; void (*fn)(float *, float, float); int instr_per_iter; const char *note; };
 
 int main()
@@ -197,6 +277,10 @@ int main()
     const Bench benches[] = {
         {"v_fma_f32", k_fma, 32, "full-rate VALU"},
         {"v_fmac_f32 sgpr-src", k_fma_sgpr, 32, "SGPR operand, 1-deep dependency ring"},
+        {"v_fma_f32 v,s,v,v", k_fma_s0, 32, "SGPR src0, independent accumulators"},
+        {"v_pk_fma_f32 sgpr op_sel", k_pk_fma_s, 32, "SGPR pair broadcast by op_sel_hi"},
+        {"eval sequence, SGPR uniforms", k_evalseq_sgpr, 48, "24 VALU per centre for 2 packed slots, x2"},
+        {"eval sequence, VGPR uniforms", k_evalseq_vgpr, 48, "same, uniforms in VGPR pairs"},
         {"v_pk_fma_f32", k_pk_fma, 32, "2 fma per lane per instr"},
         {"v_log_f32", k_log, 32, "transcendental"},
         {"v_exp_f32", k_exp, 32, "transcendental"},
