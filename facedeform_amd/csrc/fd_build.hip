@@ -22,7 +22,7 @@
 //               interchanges (as a gather/scatter of the <= 2*NB moved rows),
 //               the NB x 16 triangular solve in registers in MFMA B-fragment
 //               layout, then C -= L21 * U12 with v_mfma_f64_16x16x4_f64.
-// Back substitution: one launch per 32-row block, bottom up.
+// Back substitution: one workgroup, bottom up over 32-row blocks.
 #include "fd_internal.h"
 
 namespace fd {
@@ -158,136 +158,208 @@ __global__ __launch_bounds__(256) void k_assemble(const double *centres, const d
 }
 
 // ---- LU panel -------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(kPanelThreads) void k_lu_panel(double *A, int lda, int npad, int n_real,
-                                                            int k0, int *ipiv, int *moves,
-                                                            DevModel *model)
+// wave-wide maximum of a 32-bit key without touching LDS: rotate-reduce inside each
+// 16-lane row on the DPP network, then combine the four rows through SGPRs
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#define FD_DPP_MAX(CTRL)                                                                         \
+    {                                                                                            \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); \
+        v = o > v ? o : v;                                                                       \
+    }
+    FD_DPP_MAX(0x121)   // row_ror:1
+    FD_DPP_MAX(0x122)   // row_ror:2
+    FD_DPP_MAX(0x124)   // row_ror:4
+    FD_DPP_MAX(0x128)   // row_ror:8
+#undef FD_DPP_MAX
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+    const unsigned r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32);
+    const unsigned r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+    return m01 > m23 ? m01 : m23;
+}
+
+// 1/x to within an ulp or two: hardware estimate + two Newton steps (the IEEE divide
+// sequence is ~3x longer and sits on the per-column critical path of the panel)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Diagnostic build only (tools/panel_bench.hip defines FD_PANEL_STAMPS): shader-clock shares of
+// the phases of one column step, summed over the panel by thread 0.  Never in the product.
+#ifdef FD_PANEL_B64
+#define FD_WRITE_FENCE asm volatile("" ::: "memory");
+#else
+#define FD_WRITE_FENCE
+#endif
+#ifdef FD_PANEL_STAMPS
+__device__ unsigned long long g_panel_stamps[16];
+#define FD_STAMP_DECL unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define FD_STAMP(K) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[K] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#define FD_STAMP_FLUSH if (threadIdx.x == 0) { for (int q_ = 0; q_ < 10; ++q_) g_panel_stamps[q_] = st_acc[q_]; }
+#else
+#define FD_STAMP_DECL
+#define FD_STAMP(K)
+#define FD_STAMP_FLUSH
+#endif
+
+// Pivot rule: the row with the largest |a| as seen through an fp32 key (so rows whose
+// magnitudes agree to 2^-24 tie), ties to the smaller row index across waves and to the
+// lower lane inside a wave.  Any such pivot is as good as the exact maximum for partial
+// pivoting; the choice is deterministic.
+//
+// The column loop is fully unrolled so that every register index is static and each step
+// touches only the live columns j..NB-1 (a rolled loop with a rotating register row was
+// measured slower: it has to mask and move all NB columns every step).
+template <int NB, int TMAX>
+__global__ __launch_bounds__(TMAX) void k_lu_panel(double *A, int lda, int npad, int n_real,
+                                                   int k0, int *ipiv, int *moves, DevModel *model)
 {
     constexpr int R = 32 / NB;          // rows per lane: R * NB = 32 doubles in registers
-    constexpr int kDiag = 16;           // LDS slot of the current diagonal row
-    __shared__ double s_row[2][17][NB];
-    __shared__ int s_orig[2][17];
-    __shared__ double s_val[2][16];
-    __shared__ int s_idx[2][16];
+    // live part of the pivot row of the current column, one slot per wave's candidate
+    __shared__ __attribute__((aligned(16))) double s_row[2][16][NB];
+    __shared__ unsigned long long s_key[3];
     __shared__ int s_count;
+    (void)ipiv;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nthreads = blockDim.x;
-    const int nwaves = nthreads >> 6;
     const int nrem = npad - k0;
 
+    // Rows never travel between threads.  pos[t] is the row's current LOGICAL position in the
+    // panel: an interchange swaps two integers, and the write-back scatters each row to
+    // k0 + pos[t].  (Moving 32-double rows through LDS costs 450-850 cycles per row: one
+    // active lane per 16-byte ds_write; measured in tools/lds_write_bench.hip.)
     double a[R][NB];
-    int orig[R];
+    int pos[R];
 #pragma clang loop unroll(full)
     for (int t = 0; t < R; ++t) {
         const int slot = tid + t * nthreads;
-        orig[t] = k0 + slot;
+        pos[t] = slot;
 #pragma clang loop unroll(full)
         for (int c = 0; c < NB; ++c)
             a[t][c] = slot < nrem ? A[(size_t)(k0 + c) * lda + k0 + slot] : 0.0;
     }
-    if (tid == 0) s_count = 0;
+    if (tid == 0) { s_count = 0; s_key[0] = 0ull; s_key[1] = 0ull; s_key[2] = 0ull; }
+    __syncthreads();
 
     const double amax = __longlong_as_double((long long)model->amax_bits);
     const double tiny = (double)n_real * kEps * amax;
     double pmin = INFINITY, pmax = 0.0;
     bool singular = false;
+    FD_STAMP_DECL
 
 #pragma clang loop unroll(full)
     for (int j = 0; j < NB; ++j) {
         const int buf = j & 1;
         // candidate among my rows at or below the diagonal
         double best = -1.0;
-        int bslot = 0x7fffffff;
+        int bpos = 0x7fffffff;
+        int bt = 0;
 #pragma clang loop unroll(full)
         for (int t = 0; t < R; ++t) {
-            const int slot = tid + t * nthreads;
-            if (slot >= j && slot < nrem) {
+            if (pos[t] >= j && tid + t * nthreads < nrem) {
                 const double v = fabs(a[t][j]);
-                if (v > best || (v == best && slot < bslot)) { best = v; bslot = slot; }
+                if (v > best) { best = v; bpos = pos[t]; bt = t; }
             }
         }
-        // wave argmax: larger |a| wins, ties go to the smaller row (first maximum)
+        // fp32 key, +1 so that a real candidate of magnitude 0 still beats "no candidate"
+        const bool has = best >= 0.0;
+        const unsigned key = has ? __float_as_uint((float)best) + 1u : 0u;
+        FD_STAMP(0)
+        const unsigned wmax = wave_max_u32(key);
+        const unsigned long long cand = __ballot(has && key == wmax);
+        FD_STAMP(1)
+        if (cand != 0ull) {
+            const int src = __ffsll((unsigned long long)cand) - 1;
+            const int wpos = __builtin_amdgcn_readlane(bpos, src);
+            if (lane == src) {
 #pragma clang loop unroll(full)
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(best, off);
-            const int os = __shfl_xor(bslot, off);
-            if (ov > best || (ov == best && os < bslot)) { best = ov; bslot = os; }
-        }
+                for (int t = 0; t < R; ++t) {
+                    if (t == bt) {
 #pragma clang loop unroll(full)
-        for (int t = 0; t < R; ++t) {
-            const int slot = tid + t * nthreads;
-            if (slot == bslot && best >= 0.0) {
-#pragma clang loop unroll(full)
-                for (int c = 0; c < NB; ++c) s_row[buf][wave][c] = a[t][c];
-                s_orig[buf][wave] = orig[t];
-            }
-            if (slot == j) {
-#pragma clang loop unroll(full)
-                for (int c = 0; c < NB; ++c) s_row[buf][kDiag][c] = a[t][c];
-                s_orig[buf][kDiag] = orig[t];
-            }
-        }
-        if (lane == 0) { s_val[buf][wave] = best; s_idx[buf][wave] = bslot; }
-        __syncthreads();
-
-        double gbest = -1.0;
-        int gslot = 0x7fffffff, gw = 0;
-        for (int w = 0; w < nwaves; ++w) {
-            const double v = s_val[buf][w];
-            const int s = s_idx[buf][w];
-            if (v > gbest || (v == gbest && s < gslot)) { gbest = v; gslot = s; gw = w; }
-        }
-        // interchange rows j and gslot (contents travel, slots stay)
-        if (gslot != j) {
-#pragma clang loop unroll(full)
-            for (int t = 0; t < R; ++t) {
-                const int slot = tid + t * nthreads;
-                if (slot == j) {
-#pragma clang loop unroll(full)
-                    for (int c = 0; c < NB; ++c) a[t][c] = s_row[buf][gw][c];
-                    orig[t] = s_orig[buf][gw];
-                } else if (slot == gslot) {
-#pragma clang loop unroll(full)
-                    for (int c = 0; c < NB; ++c) a[t][c] = s_row[buf][kDiag][c];
-                    orig[t] = s_orig[buf][kDiag];
+                        for (int c = j & ~1; c < NB; ++c) s_row[buf][wave][c] = a[t][c];
+                    }
                 }
             }
+            // low word: the smaller logical row wins a key tie; the owning wave rides along
+            if (lane == 0)
+                atomicMax(&s_key[j % 3], ((unsigned long long)wmax << 32) |
+                                             (unsigned)(((0xffff - wpos) << 8) | wave));
         }
-        const double piv = s_row[buf][gw][j];
+        // the next cell was last read two columns ago, i.e. before a barrier everyone has passed
+        if (tid == 0) s_key[(j + 1) % 3] = 0ull;
+        FD_STAMP(2)
+        __syncthreads();
+        FD_STAMP(3)
+
+        const unsigned glow = (unsigned)(s_key[j % 3] & 0xffffffffull);
+        const int gpos = 0xffff - (int)(glow >> 8);
+        const int gw = (int)(glow & 0xffu);
+        // the interchange: the pivot row takes logical position j, the row that was there takes gpos
+#pragma clang loop unroll(full)
+        for (int t = 0; t < R; ++t) {
+            const int p = pos[t];
+            pos[t] = p == gpos ? j : (p == j ? gpos : p);
+        }
+        FD_STAMP(4)
+        // the live part of the pivot row into registers in one burst of LDS reads -- read one
+        // element at a time next to its fma, hipcc waits for every read separately
+        double prow[NB];
+#pragma clang loop unroll(full)
+        for (int c = j & ~1; c < NB; ++c) prow[c] = s_row[buf][gw][c];
+        asm volatile("" ::: "memory");
+        const double piv = prow[j];
+        const double gbest = fabs(piv);
         const bool ok = gbest > tiny;   // false for NaN as well
         if (k0 + j < n_real) {
             if (!ok) singular = true;
             pmin = gbest < pmin ? gbest : pmin;
             pmax = gbest > pmax ? gbest : pmax;
         }
-        if (tid == 0) ipiv[k0 + j] = k0 + gslot;
-        const double inv = ok ? 1.0 / piv : 0.0;
+        const double inv = ok ? fast_rcp(piv) : 0.0;
+        FD_STAMP(5)
 #pragma clang loop unroll(full)
         for (int t = 0; t < R; ++t) {
-            const int slot = tid + t * nthreads;
-            if (slot > j && slot < nrem) {
+            if (pos[t] > j && tid + t * nthreads < nrem) {
                 const double l = a[t][j] * inv;
                 a[t][j] = l;
 #pragma clang loop unroll(full)
-                for (int c = j + 1; c < NB; ++c) a[t][c] = fma(-l, s_row[buf][gw][c], a[t][c]);
+                for (int c = j + 1; c < NB; ++c) a[t][c] = fma(-l, prow[c], a[t][c]);
             }
         }
+        FD_STAMP(6)
+        FD_STAMP(7)
     }
+    FD_STAMP(8)
 
-    // write the factored panel back, and the list of rows that moved
+    // write the factored panel back, every row at its logical position, and list the rows
+    // that moved for the trailing update
 #pragma clang loop unroll(full)
     for (int t = 0; t < R; ++t) {
         const int slot = tid + t * nthreads;
         if (slot < nrem) {
 #pragma clang loop unroll(full)
-            for (int c = 0; c < NB; ++c) A[(size_t)(k0 + c) * lda + k0 + slot] = a[t][c];
-            if (orig[t] != k0 + slot) {
+            for (int c = 0; c < NB; ++c) A[(size_t)(k0 + c) * lda + k0 + pos[t]] = a[t][c];
+            if (pos[t] != slot) {
                 const int q = atomicAdd(&s_count, 1);
-                moves[1 + 2 * q] = k0 + slot;   // destination row
-                moves[2 + 2 * q] = orig[t];     // row (as of panel start) whose content lands there
+                moves[1 + 2 * q] = k0 + pos[t];   // destination row
+                moves[2 + 2 * q] = k0 + slot;     // row (as of panel start) whose content lands there
             }
         }
     }
@@ -302,6 +374,8 @@ __global__ __launch_bounds__(kPanelThreads) void k_lu_panel(double *A, int lda, 
             atomicMax(&model->pivmax_bits, (unsigned long long)__double_as_longlong(pmax));
         }
     }
+    FD_STAMP(9)
+    FD_STAMP_FLUSH
 }
 
 // ---- LU trailing update ---------------------------------------------------------
@@ -319,27 +393,25 @@ __global__ __launch_bounds__(256) void k_lu_trail(double *A, int lda, int npad, 
     const int c = lane & 15;            // column inside the block
     const int g = lane >> 4;            // row group (MFMA k index)
 
-    // 1. row interchanges of this panel, restricted to my 16 columns:
-    //    read every moved row first, then write (the two sets overlap)
-    const int nmov = moves[0];
-    double tmp[8];
+    // 1. row interchanges of this panel, restricted to my 16 columns: the move list comes
+    //    in with one coalesced load; every moved row is read before any is written
+    //    (sources and destinations overlap)
+    __shared__ int s_moves[2 * 2 * NB + 1];
+    if (tid < 2 * 2 * NB + 1) s_moves[tid] = moves[tid];
+    __syncthreads();
+    const int nmov = s_moves[0];
+    double tmp[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
         const int e = tid + q * 256;
         tmp[q] = 0.0;
-        if (e < nmov * kColBlock) {
-            const int m = e >> 4;
-            tmp[q] = A[(size_t)(c0 + (e & 15)) * lda + moves[2 + 2 * m]];
-        }
+        if (e < nmov * kColBlock) tmp[q] = A[(size_t)(c0 + (e & 15)) * lda + s_moves[2 + 2 * (e >> 4)]];
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
         const int e = tid + q * 256;
-        if (e < nmov * kColBlock) {
-            const int m = e >> 4;
-            A[(size_t)(c0 + (e & 15)) * lda + moves[1 + 2 * m]] = tmp[q];
-        }
+        if (e < nmov * kColBlock) A[(size_t)(c0 + (e & 15)) * lda + s_moves[1 + 2 * (e >> 4)]] = tmp[q];
     }
     for (int e = tid; e < NB * NB; e += 256) {
         const int r = e % NB, cc = e / NB;
@@ -374,66 +446,137 @@ __global__ __launch_bounds__(256) void k_lu_trail(double *A, int lda, int npad, 
     const int rfirst = k0 + NB;
     const int rbase = rfirst & ~15;
     const int ntiles = (npad - rbase) / 16;
-    for (int tile = wave; tile < ntiles; tile += 4) {
+    // two tiles per iteration: all loads of both tiles are issued before the first MFMA
+    for (int tile = wave; tile < ntiles; tile += 8) {
         const int r0 = rbase + tile * 16;
-        double *cptr = A + (size_t)(c0 + c) * lda + r0 + g;
-        double4_t acc;
-        acc[0] = cptr[0]; acc[1] = cptr[4]; acc[2] = cptr[8]; acc[3] = cptr[12];
-        const double *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
-        const bool arow_ok = r0 + c >= rfirst;
-        double av[S];
+        const bool two = tile + 4 < ntiles;
+        const int r1 = two ? r0 + 64 : r0;
+        double *cptr0 = A + (size_t)(c0 + c) * lda + r0 + g;
+        double *cptr1 = A + (size_t)(c0 + c) * lda + r1 + g;
+        const double *aptr0 = A + (size_t)(k0 + g) * lda + r0 + c;
+        const double *aptr1 = A + (size_t)(k0 + g) * lda + r1 + c;
+        double4_t acc0, acc1;
+        acc0[0] = cptr0[0]; acc0[1] = cptr0[4]; acc0[2] = cptr0[8]; acc0[3] = cptr0[12];
+        acc1[0] = cptr1[0]; acc1[1] = cptr1[4]; acc1[2] = cptr1[8]; acc1[3] = cptr1[12];
+        const bool ok0 = r0 + c >= rfirst, ok1 = r1 + c >= rfirst;
+        double av0[S], av1[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const double v = aptr[(size_t)(4 * s) * lda];
-            av[s] = arow_ok ? v : 0.0;
+            const double v0 = aptr0[(size_t)(4 * s) * lda];
+            const double v1 = aptr1[(size_t)(4 * s) * lda];
+            av0[s] = ok0 ? v0 : 0.0;
+            av1[s] = ok1 ? v1 : 0.0;
         }
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], u[s], acc, 0, 0, 0);
+        for (int s = 0; s < S; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[s], u[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[s], u[s], acc1, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (r0 + g + 4 * r >= rfirst) cptr[4 * r] = acc[r];
+            if (r0 + g + 4 * r >= rfirst) cptr0[4 * r] = acc0[r];
+        if (two) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r1 + g + 4 * r >= rfirst) cptr1[4 * r] = acc1[r];
+        }
     }
 }
 
-// ---- back substitution, one 32-row block per launch ------------------------------
-// Solves U * X = Y bottom-up.  Y lives in columns npad.. of A; X goes to its own
-// buffer so that workgroups re-solving the diagonal block never race with a writer.
-__global__ __launch_bounds__(256) void k_backsub(double *A, int lda, int npad, int b0, double *X)
+// ---- back substitution, one workgroup, bottom-up over 32-row blocks ----------------
+// Solves U * X = Y (Y = columns npad.. of A after forward elimination).  Y lives in LDS
+// for the whole kernel; the diagonal block of the NEXT step is fetched while the current
+// one is solved; every thread issues the loads of its U row segment before wave 0 starts
+// the 32 x 32 triangle (rows in registers, x_k travels by v_readlane: no LDS round trip,
+// no barrier inside), so global latency hides behind the solve.
+template <int T>
+__global__ __launch_bounds__(T) void k_backsub_all(const double *A, int lda, int npad, double *X)
 {
-    __shared__ double sU[32][33];
-    __shared__ double sx[32][3];
+    extern __shared__ __attribute__((aligned(16))) double s_y[];   // [3][npad]
+    __shared__ double s_u[2][32][33];
+    __shared__ double s_x[32][3];
+    constexpr int E = 1024 / T;          // diagonal-block elements per thread
     const int tid = threadIdx.x;
-    for (int e = tid; e < 32 * 32; e += 256) {
-        const int r = e & 31, cc = e >> 5;
-        sU[r][cc] = A[(size_t)(b0 + cc) * lda + b0 + r];
+    const int lane = tid & 63;
+
+    for (int e = tid; e < 3 * npad; e += T) s_y[e] = A[(size_t)(npad + e / npad) * lda + e % npad];
+    double dnext[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+        const int e = tid + q * T;
+        dnext[q] = A[(size_t)(npad - 32 + (e >> 5)) * lda + npad - 32 + (e & 31)];
     }
-    if (tid < 96) sx[tid & 31][tid >> 5] = A[(size_t)(npad + (tid >> 5)) * lda + b0 + (tid & 31)];
+    int buf = 0;
+    for (int b0 = npad - 32; b0 >= 0; b0 -= 32, buf ^= 1) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const int e = tid + q * T;
+            s_u[buf][e & 31][e >> 5] = dnext[q];
+        }
+        if (b0 >= 32) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const int e = tid + q * T;
+                dnext[q] = A[(size_t)(b0 - 32 + (e >> 5)) * lda + b0 - 32 + (e & 31)];
+            }
+        }
+        // my first row's segment of U for the update below (does not depend on x); only the
+        // small-system variant has the registers to hold it across the solve
+        constexpr bool kPrefetch = T <= 256;
+        const int i0 = tid;
+        double uik[32];
+        if (kPrefetch && i0 < b0) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) uik[k] = A[(size_t)(b0 + k) * lda + i0];
+        }
+        __syncthreads();                 // diagonal block and the Y rows of this block are in LDS
+
+        if (tid < 64) {
+            const int i = lane & 31;
+            double ub[32];
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) ub[cc] = s_u[buf][i][cc];
+            double y0 = s_y[b0 + i], y1 = s_y[npad + b0 + i], y2 = s_y[2 * npad + b0 + i];
+            const double dinv = 1.0 / s_u[buf][i][i];
+#pragma unroll
+            for (int k = 31; k >= 0; --k) {
+                const double inv = readlane_f64(dinv, k);
+                const double x0 = readlane_f64(y0, k) * inv;
+                const double x1 = readlane_f64(y1, k) * inv;
+                const double x2 = readlane_f64(y2, k) * inv;
+                if (i < k) {
+                    y0 = fma(-ub[k], x0, y0);
+                    y1 = fma(-ub[k], x1, y1);
+                    y2 = fma(-ub[k], x2, y2);
+                } else if (i == k) {
+                    y0 = x0; y1 = x1; y2 = x2;
+                }
+            }
+            if (lane < 32) {
+                s_x[i][0] = y0; s_x[i][1] = y1; s_x[i][2] = y2;
+                s_y[b0 + i] = y0; s_y[npad + b0 + i] = y1; s_y[2 * npad + b0 + i] = y2;
+            }
+        }
+        __syncthreads();
+        for (int i = i0; i < b0; i += T) {
+            if (!kPrefetch || i != i0) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) uik[k] = A[(size_t)(b0 + k) * lda + i];
+            }
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                a0 = fma(uik[k], s_x[k][0], a0);
+                a1 = fma(uik[k], s_x[k][1], a1);
+                a2 = fma(uik[k], s_x[k][2], a2);
+            }
+            s_y[i] -= a0; s_y[npad + i] -= a1; s_y[2 * npad + i] -= a2;
+        }
+        // no barrier here: the next iteration's barrier orders these writes before its solve,
+        // and s_x / s_u[buf] are not rewritten before that barrier either (s_u alternates)
+    }
     __syncthreads();
-    for (int k = 31; k >= 0; --k) {
-        if (tid < 3) sx[k][tid] = sx[k][tid] / sU[k][k];
-        __syncthreads();
-        if (tid < 96) {
-            const int i = tid & 31, rc = tid >> 5;
-            if (i < k) sx[i][rc] = fma(-sU[i][k], sx[k][rc], sx[i][rc]);
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0 && tid < 96) X[(size_t)(tid >> 5) * npad + b0 + (tid & 31)] = sx[tid & 31][tid >> 5];
-    // rows above the block: y_i -= U[i, b0:b0+32] * x_b
-    const int i = blockIdx.x * 256 + tid;
-    if (i < b0) {
-        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-        for (int k = 0; k < 32; ++k) {
-            const double uik = A[(size_t)(b0 + k) * lda + i];
-            y0 = fma(uik, sx[k][0], y0);
-            y1 = fma(uik, sx[k][1], y1);
-            y2 = fma(uik, sx[k][2], y2);
-        }
-        A[(size_t)(npad + 0) * lda + i] -= y0;
-        A[(size_t)(npad + 1) * lda + i] -= y1;
-        A[(size_t)(npad + 2) * lda + i] -= y2;
-    }
+    for (int e = tid; e < 3 * npad; e += T) X[e] = s_y[e];
 }
 
 // ---- pack: solution -> weights, evaluation records, status -----------------------
@@ -507,8 +650,12 @@ void lu_step(const BuildBuffers &b, int k0, hipStream_t stream)
     const int nrem = b.npad - k0;
     int threads = round_up((nrem + R - 1) / R, 64);
     if (threads < 64) threads = 64;
-    hipLaunchKernelGGL((k_lu_panel<NB>), dim3(1), dim3(threads), 0, stream, b.d_A, b.lda, b.npad,
-                       b.n, k0, b.d_ipiv, b.d_moves, b.d_model);
+    if (threads <= 512)
+        hipLaunchKernelGGL((k_lu_panel<NB, 512>), dim3(1), dim3(threads), 0, stream, b.d_A, b.lda, b.npad,
+                           b.n, k0, b.d_ipiv, b.d_moves, b.d_model);
+    else
+        hipLaunchKernelGGL((k_lu_panel<NB, 1024>), dim3(1), dim3(threads), 0, stream, b.d_A, b.lda, b.npad,
+                           b.n, k0, b.d_ipiv, b.d_moves, b.d_model);
     // the last block may run into the 16 zero columns allocated past ncols
     const int ncb = (b.ncols - (k0 + NB) + kColBlock - 1) / kColBlock;
     if (ncb > 0)
@@ -550,9 +697,22 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
         else { lu_step<4>(b, k0, stream); k0 += 4; }
     }
     double *X = b.d_X;
-    for (int b0 = b.npad - 32; b0 >= 0; b0 -= 32) {
-        const int blocks = b0 > 0 ? (b0 + 255) / 256 : 1;
-        hipLaunchKernelGGL(k_backsub, dim3(blocks), dim3(256), 0, stream, b.d_A, b.lda, b.npad, b0, X);
+    {
+        // Y (3 x npad fp64) stays in LDS: 3 * 8192 * 8 B = 192 KiB would not fit, but the panel
+        // kernel already limits the order to kMaxOrder and 3 * npad * 8 <= 160 KiB - 18 KiB
+        // holds up to npad = 5900; larger systems are rejected in fd_set_points
+        const size_t ybytes = sizeof(double) * 3 * (size_t)b.npad;
+        if (b.npad <= 512)
+            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1), dim3(256), ybytes, stream, b.d_A, b.lda, b.npad, X);
+        else {
+            static bool attr_set = false;   // > 64 KiB of dynamic LDS has to be requested once
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backsub_all<1024>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((k_backsub_all<1024>), dim3(1), dim3(1024), ybytes, stream, b.d_A, b.lda, b.npad, X);
+        }
     }
     hipError_t e = launch_pack(b, stream);
     if (e != hipSuccess) return e;

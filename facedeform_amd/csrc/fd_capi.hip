@@ -45,6 +45,16 @@ struct fd_ctx {
     float *d_tu = nullptr, *d_tv = nullptr, *d_nrm = nullptr;
 
     hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
+
+    // The build is ~25 dependent launches whose arguments depend only on the configuration
+    // and on buffer addresses: captured once into a hipGraph, replayed on every later build.
+    hipGraphExec_t build_exec = nullptr;
+    bool use_graph = true;
+    struct GraphKey {
+        int M, kind, term, nparams;
+        double params[4];
+        const void *A, *rest, *rec32;
+    } graph_key{};
     char err[512] = {0};
 };
 
@@ -178,6 +188,7 @@ fd_ctx *fd_create(const fd_config *cfg)
         return nullptr;
     }
     ctx->stream = ctx->own_stream;
+    ctx->use_graph = getenv("FD_NO_GRAPH") == nullptr;
     return ctx;
 }
 
@@ -192,6 +203,7 @@ void fd_destroy(fd_ctx *ctx)
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (ctx->h_model) (void)hipHostFree(ctx->h_model);
     if (ctx->h_header) (void)hipHostFree(ctx->h_header);
+    if (ctx->build_exec) (void)hipGraphExecDestroy(ctx->build_exec);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -328,12 +340,42 @@ int fd_build_async(fd_ctx *ctx)
         // the 16 overrun columns past the RHS block must read as zero forever
         const size_t cols = (size_t)ctx->cap_npad + kRhsCols + 16;
         FD_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, sizeof(double) * (size_t)ctx->cap_npad * cols, ctx->stream));
-    } else {
-        FD_HIP(ctx, hipMemsetAsync(ctx->d_A + (size_t)b.lda * b.ncols, 0, sizeof(double) * (size_t)b.lda * 16,
-                                   ctx->stream));
+    }
+    double *pad_cols = ctx->d_A + (size_t)b.lda * b.ncols;
+    const size_t pad_bytes = sizeof(double) * (size_t)b.lda * 16;
+
+    fd_ctx::GraphKey key{};
+    key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term; key.nparams = ctx->nparams;
+    memcpy(key.params, ctx->params, sizeof(key.params));
+    key.A = ctx->d_A; key.rest = ctx->d_rest; key.rec32 = ctx->d_rec32;
+    if (ctx->use_graph && (!ctx->build_exec || memcmp(&key, &ctx->graph_key, sizeof(key)) != 0)) {
+        if (ctx->build_exec) { (void)hipGraphExecDestroy(ctx->build_exec); ctx->build_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            hipError_t e1 = hipMemsetAsync(pad_cols, 0, pad_bytes, ctx->stream);
+            hipError_t e2 = launch_build(b, ctx->stream, nullptr);
+            e = hipStreamEndCapture(ctx->stream, &graph);
+            if (e == hipSuccess && (e1 != hipSuccess || e2 != hipSuccess)) e = e1 != hipSuccess ? e1 : e2;
+        }
+        if (e == hipSuccess && graph) e = hipGraphInstantiate(&ctx->build_exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->build_exec = nullptr;
+            ctx->use_graph = false;      // this runtime cannot capture the sequence: launch directly
+        } else {
+            ctx->graph_key = key;
+        }
     }
     FD_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    FD_HIP(ctx, launch_build(b, ctx->stream, ctx->ev_mid));
+    if (ctx->use_graph && ctx->build_exec) {
+        FD_HIP(ctx, hipEventRecord(ctx->ev_mid, ctx->stream));   // phases are not split inside a graph
+        FD_HIP(ctx, hipGraphLaunch(ctx->build_exec, ctx->stream));
+    } else {
+        FD_HIP(ctx, hipMemsetAsync(pad_cols, 0, pad_bytes, ctx->stream));
+        FD_HIP(ctx, launch_build(b, ctx->stream, ctx->ev_mid));
+    }
     FD_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->build_pending = true;
     ctx->built = false;

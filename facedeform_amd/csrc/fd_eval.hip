@@ -22,6 +22,8 @@
 // Built with -ffp-contract=off: every fused multiply-add is written out, so a vertex
 // gets the same bits whichever lane / register slot it lands in (range splits are
 // bit-identical) and the fp32 epilogue rounds like the reference's unfused CPU code.
+#include <cstdlib>
+
 #include "fd_internal.h"
 
 namespace fd {
@@ -30,6 +32,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 64;  // centres per fp32 partial sum
+constexpr unsigned kNumCU = 256;      // MI355X
 constexpr int kDefaultVariant = 102;  // packed lanes, scalar-loaded records, V = 4
 
 typedef const __attribute__((address_space(4))) Rec32 *ConstRec32;
@@ -383,12 +386,18 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
     int variant = a.variant > 0 ? a.variant : kDefaultVariant;
     const size_t lds_bytes = (size_t)a.Mpad * sizeof(Rec32);
     if ((variant / 10) % 10 == 1 && lds_bytes > 64 * 1024) variant -= 10;   // one LDS tile must hold them all
+    // Even placement: with every workgroup resident at once the dispatcher may stack 5 on one
+    // CU and 3 on another, and the kernel then lasts as long as the fullest CU.  Reserving
+    // 160 KiB / ceil(grid / 256) of LDS per workgroup caps every CU at the even share.
+    const bool balance = getenv("FD_NO_BALANCE") == nullptr;
 #define FD_LAUNCH(VV, LDS, LT)                                                                      \
     do {                                                                                             \
         const int64_t per = (int64_t)kBlock * (VV);                                                  \
         const unsigned grid = (unsigned)((a.N + per - 1) / per);                                     \
-        hipLaunchKernelGGL((k_deform32<KIND, VV, LDS, LT>), dim3(grid), dim3(kBlock),                \
-                           (LDS) ? lds_bytes : 0, stream, p);                                        \
+        size_t dyn = (LDS) ? lds_bytes : 0;                                                          \
+        const unsigned share = (grid + kNumCU - 1) / kNumCU;                                         \
+        if (!(LDS) && balance && share >= 3 && share <= 8) dyn = ((160u * 1024u) / share) & ~1023u;  \
+        hipLaunchKernelGGL((k_deform32<KIND, VV, LDS, LT>), dim3(grid), dim3(kBlock), dyn, stream, p); \
         return hipGetLastError();                                                                    \
     } while (0)
     switch (variant) {

@@ -56,7 +56,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ---- build pipeline (fd_build.hip) -------------------------------------------
 constexpr int kPanelThreads = 1024;   // one workgroup factors a panel
-constexpr int kMaxOrder = 8192;       // panel rows that fit one CU's registers at NB=4
+constexpr int kMaxOrder = 5632;       // back-substitution keeps Y (3 x order fp64) in LDS
 constexpr int kRhsCols = 16;          // 3 right-hand sides padded to one MFMA tile
 
 struct BuildBuffers {

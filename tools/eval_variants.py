@@ -7,7 +7,7 @@ from facedeform_amd import capi, synth
 from oracle import fd_oracle as fo
 
 def main():
-    cfgs = [("c2", 1_000_000, 256), ("c3", 1_000_000, 2048), ("c1big", 1_000_000, 32), ("c2pad", 1024 * 1024, 256)]
+    cfgs = [("c2", 1_000_000, 256), ("c3", 1_000_000, 2048), ("c1big", 1_000_000, 32), ("c2pad", 1024 * 1024, 256), ("c2x16", 16_000_000, 256)]
     if len(sys.argv) > 2:
         cfgs = [c for c in cfgs if c[0] in sys.argv[2].split(",")]
     variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,3,11,12,13,101,102,103,111,112,113".split(","))]

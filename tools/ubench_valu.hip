@@ -262,6 +262,39 @@ __global__ void k_evalseq_vgpr(float *out, float a, float b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y + l0 + l1 + l2 + l3;
 }
 
+// ---- does a 16x16x4 f32 MFMA run in the shadow of VALU work? ---------------------------
+// per iteration: NM MFMAs (each produces 4 d2 per lane) + for each: 4 v_log + 2 v_pk_mul + 6 v_pk_fma
+template <bool WITH_MFMA, bool WITH_VALU>
+__global__ void k_mfma16_mix(float *out, float a, float b)
+{
+    f32x4 c0 = {1, 2, 3, 4}, d0 = c0, d1 = c0;
+    f32x2 acc0 = {0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0, acc4 = acc0, acc5 = acc0;
+    f32x2 w0 = {a, b}, w1 = {b, a}, w2 = {a, a}, w3 = {b, b}, w4 = {a, 1}, w5 = {b, 1};
+    float va = a + threadIdx.x, vb = b;
+    for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (WITH_MFMA) {
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, %4\n" : "=v"(d0) : "0"(d0), "v"(va), "v"(vb), "v"(c0));
+            }
+            if (WITH_VALU) {
+                // VALU work on the OTHER buffer (software-pipelined: independent of the MFMA just issued)
+                asm volatile("v_log_f32 %0, %0\n v_log_f32 %1, %1\n v_log_f32 %2, %2\n v_log_f32 %3, %3\n"
+                             : "+v"(d1[0]), "+v"(d1[1]), "+v"(d1[2]), "+v"(d1[3]));
+                f32x2 t01 = {d1[0], d1[1]}, t23 = {d1[2], d1[3]};
+                asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1\n"
+                             "v_pk_fma_f32 %2, %0, %8, %2\n v_pk_fma_f32 %3, %0, %9, %3\n v_pk_fma_f32 %4, %0, %10, %4\n"
+                             "v_pk_fma_f32 %5, %1, %11, %5\n v_pk_fma_f32 %6, %1, %12, %6\n v_pk_fma_f32 %7, %1, %13, %7\n"
+                             : "+v"(t01), "+v"(t23), "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4), "+v"(acc5)
+                             : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5));
+            }
+            f32x4 tmp = d0; d0 = d1; d1 = tmp;
+        }
+    }
+    f32x2 s = acc0 + acc1 + acc2 + acc3 + acc4 + acc5;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y + d0[0] + d1[1];
+}
+
 struct Bench { const char *name; void (*fn)(float *, float, float); int instr_per_iter; const char *note; };
 
 int main()
@@ -289,6 +322,9 @@ int main()
         {"mix 10 pk_fma + 2 log", k_mixpk, 48, "same, packed: 8 pairs = 4 x (10 pk + 2 log)"},
         {"mix 7 fma + log + mfma4x4x1", k_mix_mfma, 72, "8 pairs, accumulate on the matrix pipe (9 issue slots/pair)"},
         {"v_mfma_f32_4x4x1", k_mfma4, 32, "512 flop per instr"},
+        {"mfma16x16x4f32 alone", k_mfma16_mix<true, false>, 2, "2 MFMA per iteration"},
+        {"valu tile work alone", k_mfma16_mix<false, true>, 24, "2 x (4 log + 2 pk_mul + 6 pk_fma)"},
+        {"mfma16x16x4f32 + valu tile", k_mfma16_mix<true, true>, 26, "2 x (1 MFMA + 12 VALU): overlap?"},
         {"v_fma_f64", k_fma64, 32, ""},
         {"v_mfma_f64_16x16x4", k_mfma64, 32, "2048 flop per instr"},
     };
