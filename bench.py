@@ -24,6 +24,10 @@ import time
 
 import numpy as np
 
+# Independent frames run on separate HIP streams; the runtime maps streams onto this many
+# hardware queues (default 4, which lets only ~2 streams overlap).  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -238,24 +238,47 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
 
     if (wave_work) {
         const LaneT bias = L::splat(d2_bias<KIND>());
-        for (int j0 = 0; j0 < p.Mpad; j0 += kChunk) {
-            const int jend = (j0 + kChunk < p.Mpad) ? j0 + kChunk : p.Mpad;
-            LaneT ax[Q], ay[Q], az[Q];
+        LaneT ax[Q], ay[Q], az[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) ax[q] = ay[q] = az[q] = L::splat(0.f);
+
+        struct Ctr { float cx, cy, cz, s, wx, wy, wz; };
+        auto fetch = [&](int j) -> Ctr {
+            Ctr c;
+            if constexpr (USE_LDS) {
+                const float4 *r = reinterpret_cast<const float4 *>(smem) + 2 * j;
+                const float4 r0 = r[0], r1 = r[1];
+                c.cx = r0.x; c.cy = r0.y; c.cz = r0.z; c.s = r0.w;
+                c.wx = r1.x; c.wy = r1.y; c.wz = r1.z;
+            } else {
+                ConstRec32 r = (ConstRec32)(uintptr_t)(p.rec32 + j);
+                c.cx = r->cx; c.cy = r->cy; c.cz = r->cz; c.s = r->s;
+                c.wx = r->wx; c.wy = r->wy; c.wz = r->wz;
+            }
+            return c;
+        };
+        // Software pipeline with two register sets: while group A is consumed the records of
+        // group B are already requested, and vice versa, so a wave never sits on s_waitcnt
+        // with an empty pipe (the waves of a small launch run in lockstep and would all
+        // stall together).  Mpad is a multiple of 2 * kGroup.
+        constexpr int kGroup = 2;            // 2 sets x 2 records x 7 SGPRs; 4 spills scalars
+        static_assert(kRecPad % (2 * kGroup) == 0, "record padding must cover two groups");
+        // fold the fp32 partial sums into fp64 (every kChunk centres and at the end)
+        auto flush = [&]() {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                accx[v] += (double)L::get(ax[v / W], v % W);
+                accy[v] += (double)L::get(ay[v / W], v % W);
+                accz[v] += (double)L::get(az[v / W], v % W);
+            }
 #pragma unroll
             for (int q = 0; q < Q; ++q) ax[q] = ay[q] = az[q] = L::splat(0.f);
-#pragma unroll 4
-            for (int j = j0; j < jend; ++j) {
-                float cx, cy, cz, s, wx, wy, wz;
-                if constexpr (USE_LDS) {
-                    const float4 *r = reinterpret_cast<const float4 *>(smem) + 2 * j;
-                    const float4 r0 = r[0], r1 = r[1];
-                    cx = r0.x; cy = r0.y; cz = r0.z; s = r0.w;
-                    wx = r1.x; wy = r1.y; wz = r1.z;
-                } else {
-                    ConstRec32 r = (ConstRec32)(uintptr_t)(p.rec32 + j);
-                    cx = r->cx; cy = r->cy; cz = r->cz; s = r->s;
-                    wx = r->wx; wy = r->wy; wz = r->wz;
-                }
+        };
+        // (records travel by value: an array passed by reference becomes an LDS-backed alloca)
+        auto consume1 = [&](const Ctr g) {
+            {
+                const float cx = g.cx, cy = g.cy, cz = g.cz, s = g.s;
+                const float wx = g.wx, wy = g.wy, wz = g.wz;
                 // stage by stage across the Q register slots: Q independent dependency
                 // chains interleave, so no stage waits on (or pads for) its predecessor
                 LaneT dx[Q], dy[Q], dz[Q], d2[Q], t[Q];
@@ -280,13 +303,31 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
 #pragma unroll
                 for (int q = 0; q < Q; ++q) az[q] = vfma(t[q], L::splat(wz), az[q]);
             }
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                accx[v] += (double)L::get(ax[v / W], v % W);
-                accy[v] += (double)L::get(ay[v / W], v % W);
-                accz[v] += (double)L::get(az[v / W], v % W);
-            }
+        };
+        static_assert(kGroup == 2 && kRecPad == 8, "four stages of two records per iteration");
+        // Four stages per iteration; each requests the next pair of records before it consumes
+        // the current pair.  Scalar loads return out of order, so every wait on them is
+        // lgkmcnt(0): the wait for the pair about to be consumed comes BEFORE the next request,
+        // never after.  The loads stay compiler-visible on purpose: hand-issued (inline asm)
+        // s_loads whose results cross the loop back-edge get copied / their registers reused
+        // before the data lands (seen in the ISA: an in-flight destination reused as an address
+        // -> memory fault).  hipcc sinks only the loop-carried request to the latch, so three
+        // of the four stages overlap their fetch with arithmetic.
+#define FD_STAGE(N0, N1, JJ, C0, C1)                                          \
+        if constexpr (!USE_LDS) __builtin_amdgcn_s_waitcnt(0xc07f);           \
+        N0 = fetch(JJ); N1 = fetch((JJ) + 1);                                 \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        consume1(C0); consume1(C1);
+        Ctr a0 = fetch(0), a1 = fetch(1), b0, b1, c0, c1, d0, d1;
+        for (int j = 0; j < p.Mpad; j += 8) {
+            FD_STAGE(b0, b1, j + 2, a0, a1)
+            FD_STAGE(c0, c1, j + 4, b0, b1)
+            FD_STAGE(d0, d1, j + 6, c0, c1)
+            const int jn = (j + 8 < p.Mpad) ? j + 8 : j;   // the last pass re-reads its own records
+            FD_STAGE(a0, a1, jn, d0, d1)
+            if (((j + 8) & (kChunk - 1)) == 0 || j + 8 >= p.Mpad) flush();
         }
+#undef FD_STAGE
     }
 
 #pragma unroll
