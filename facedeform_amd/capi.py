@@ -47,7 +47,7 @@ class FdsopGeo(C.Structure):
 EXPORTS = [
     "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_points",
     "fd_set_points_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
-    "fd_build_result", "fd_deform", "fd_deform_dev", "fd_get_weights", "fd_model_bytes",
+    "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
     "fdsop_get_float", "fdsop_get_int", "fdsop_parm_count", "fdsop_parm_token", "fdsop_cook",
@@ -89,6 +89,8 @@ def load() -> C.CDLL:
     L.fd_deform.restype = i32
     L.fd_deform_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float]
     L.fd_deform_dev.restype = i32
+    L.fd_deform_dev_stream.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float]
+    L.fd_deform_dev_stream.restype = i32
     L.fd_get_weights.argtypes = [vp, _f64p, _f64p]; L.fd_get_weights.restype = i32
     L.fd_model_bytes.argtypes = [vp]; L.fd_model_bytes.restype = sz
     L.fd_export_model.argtypes = [vp, vp, sz, i32]; L.fd_export_model.restype = i32
@@ -217,6 +219,15 @@ class Engine:
         self._check(self.L.fd_deform_dev(self.ctx, N, vp(d_P_in), vp(d_P_out), vp(d_dist2 or None),
                                          vp(d_falloff or None), vp(d_tu or None), vp(d_tv or None),
                                          vp(d_nrm or None), float(radius2), float(falloffrate)))
+
+    def deform_dev_stream(self, stream_ptr: int, N: int, d_P_in: int, d_P_out: int, d_dist2: int = 0,
+                          d_falloff: int = 0, d_tu: int = 0, d_tv: int = 0, d_nrm: int = 0, radius2=1.0,
+                          falloffrate=1.0):
+        vp = C.c_void_p
+        self._check(self.L.fd_deform_dev_stream(self.ctx, vp(stream_ptr), N, vp(d_P_in), vp(d_P_out),
+                                                vp(d_dist2 or None), vp(d_falloff or None), vp(d_tu or None),
+                                                vp(d_tv or None), vp(d_nrm or None), float(radius2),
+                                                float(falloffrate)))
 
     def get_weights(self):
         W = np.zeros((self.M + 4, 3), np.float64)

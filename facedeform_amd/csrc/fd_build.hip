@@ -235,6 +235,9 @@ __global__ __launch_bounds__(TMAX) void k_lu_panel(double *A, int lda, int npad,
     __shared__ int s_count;
     (void)ipiv;
 
+    // latency chain on one CU: when it shares SIMDs with another stream's evaluation waves,
+    // let it issue first
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(256) void k_lu_trail(double *A, int lda, int npad, 
 {
     constexpr int S = NB / 4;           // k-steps of the f64 16x16x4 MFMA
     __shared__ double sL[NB][NB + 1];   // L11 (unit lower), +1 pad: column reads conflict-free
+    __builtin_amdgcn_s_setprio(3);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -496,6 +500,7 @@ __global__ __launch_bounds__(T) void k_backsub_all(const double *A, int lda, int
     __shared__ double s_u[2][32][33];
     __shared__ double s_x[32][3];
     constexpr int E = 1024 / T;          // diagonal-block elements per thread
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 

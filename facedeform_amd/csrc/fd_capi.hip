@@ -430,6 +430,16 @@ int fd_deform_dev(fd_ctx *ctx, int64_t N, const float *d_P_in, float *d_P_out, c
                   float radius2, float falloffrate)
 {
     if (!ctx) return FD_E_INVALID;
+    return fd_deform_dev_stream(ctx, ctx->stream, N, d_P_in, d_P_out, d_dist2, d_falloff_out, d_tu, d_tv,
+                                d_nrm, radius2, falloffrate);
+}
+
+int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *d_P_in, float *d_P_out,
+                         const float *d_dist2, float *d_falloff_out, const float *d_tu,
+                         const float *d_tv, const float *d_nrm, float radius2, float falloffrate)
+{
+    if (!ctx) return FD_E_INVALID;
+    hipStream_t launch_stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     if (N < 0 || (N > 0 && (!d_P_in || !d_P_out))) { set_err(ctx, "fd_deform: bad N / P pointers"); return FD_E_INVALID; }
     const int ntan = (d_tu != nullptr) + (d_tv != nullptr) + (d_nrm != nullptr);
     if (ntan != 0 && ntan != 3) { set_err(ctx, "fd_deform: tu, tv, nrm must be all set or all NULL"); return FD_E_INVALID; }
@@ -448,7 +458,7 @@ int fd_deform_dev(fd_ctx *ctx, int64_t N, const float *d_P_in, float *d_P_out, c
     a.model = ctx->d_model;
     a.precision = ctx->eval_precision;
     a.variant = ctx->eval_variant;
-    FD_HIP(ctx, launch_deform(a, ctx->stream));
+    FD_HIP(ctx, launch_deform(a, launch_stream));
     return FD_OK;
 }
 

@@ -144,6 +144,15 @@ int fd_deform_dev(fd_ctx *ctx, int64_t N, const float *d_P_in, float *d_P_out,
                   const float *d_dist2, float *d_falloff_out, const float *d_tu,
                   const float *d_tv, const float *d_nrm, float radius2, float falloffrate);
 
+/* Same again, but launched on `hip_stream` (a hipStream_t) instead of the context's stream, so
+ * that one stream can evaluate frame after frame while other streams build the next models.
+ * Ordering is the caller's: make `hip_stream` wait for this context's build (an event recorded
+ * on the context's stream after fd_build_async), and make the next fd_set_points / fd_build on
+ * this context wait for the evaluation, which reads the model. */
+int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *d_P_in, float *d_P_out,
+                         const float *d_dist2, float *d_falloff_out, const float *d_tu,
+                         const float *d_tv, const float *d_nrm, float radius2, float falloffrate);
+
 /* ---- model access -----------------------------------------------------------
  * W is (M+4) x 3 fp64 row-major: M RBF weights, the constant row, the x,y,z
  * linear rows (zero when the term lacks them).  radii (may be NULL) gets M
