@@ -1,0 +1,229 @@
+// SOP_FaceDeformHip.cpp -- Houdini-side wrapper: the `facedeform` SOP with its RBF hot path
+// running in libfacedeform_hip.so (MI355X) instead of ALGLIB.
+//
+// NOT compiled by this repository's build: it needs the Houdini HDK ($HT), which is not
+// available in the build container.  It is the reference-side binding INTEGRATION.md refers
+// to.  It keeps the outer plugin contract of the reference (operator name/label/inputs:
+// reference src/SOP_FaceDeform.cpp:35-46; parm tokens and defaults: :99-137) and hands the cook
+// to fdsop_cook(), the HDK-free mirror of cookMySop in facedeform_amd/csrc/fd_sop_host.cpp.
+//
+// What stays on the host, as in the reference: input locking, duplicatePointSource, data-ID
+// bumping, and ProximityCapture (reference src/capture.cpp), whose product -- the per-point
+// squared distance -- is handed over as the `dist2` array.  Morph space (DirectBSEdit) is not
+// part of the boundary yet.
+#include <UT/UT_DSOVersion.h>
+
+#include <GA/GA_Handle.h>
+#include <GA/GA_PageHandle.h>
+#include <GA/GA_SplittableRange.h>
+#include <GU/GU_Detail.h>
+#include <OP/OP_AutoLockInputs.h>
+#include <OP/OP_Operator.h>
+#include <OP/OP_OperatorTable.h>
+#include <PRM/PRM_Include.h>
+#include <SOP/SOP_Node.h>
+
+#include <string>
+#include <vector>
+
+#include "facedeform_hip.h"
+
+namespace fdhip {
+
+// ---- parm surface: driven by the engine's own table so the two cannot drift -------------
+// (token, label, kind) -- kinds: s string, o ordinal, f float, l log-float, i int, t toggle, 2 float2
+struct ParmRow { const char *token, *label; char kind; float def0, def1; };
+static const ParmRow kRows[] = {
+    {"model", "Model", 'o', 0, 0},          {"term", "RBF Term", 'o', 0, 0},
+    {"qcoef", "Q (Smoothness)", 'f', 1, 0}, {"zcoef", "Z (Deviation)", 'f', 5, 0},
+    {"radius", "Radius", 'l', 1, 0},        {"maxedges", "Max edges", 'i', 4, 0},
+    {"layers", "Layers", 'i', 4, 0},        {"lambda", "Lambda", 'f', 0.1f, 0},
+    {"tangent", "Tangent space", 't', 0, 0}, {"morphspace", "Blendshapes subspace", 't', 0, 0},
+    {"doclampweight", "Clamp weights", 't', 0, 0}, {"weightrange", "Range", '2', 0, 1},
+    {"dofalloff", "Falloff", 't', 0, 0},    {"falloffradius", "Falloff radius", 'l', 1, 0},
+    {"falloffrate", "Falloff rate (exponent)", 'f', 1, 0},
+    // additions (SURVEY.md 8b allows new parms; nothing above is renamed or removed)
+    {"kernel", "Kernel", 'o', 0, 0},        {"smoothing", "Smoothing", 'f', 0, 0},
+    {"precision", "Evaluation precision", 'o', 0, 0}, {"device", "GPU device", 'i', -1, 0},
+};
+static constexpr int kNumRows = sizeof(kRows) / sizeof(kRows[0]);
+
+static PRM_Name sModel[] = {PRM_Name("0", "QNN"), PRM_Name("1", "Multilayer"), PRM_Name(0)};
+static PRM_Name sTerm[] = {PRM_Name("0", "Linear"), PRM_Name("1", "Constant"), PRM_Name("2", "Zero"), PRM_Name(0)};
+static PRM_Name sKernel[] = {PRM_Name("0", "Gaussian (per Model)"), PRM_Name("1", "Thin plate"),
+                             PRM_Name("2", "Biharmonic"), PRM_Name("3", "Cubic"), PRM_Name(0)};
+static PRM_Name sPrecision[] = {PRM_Name("0", "fp32"), PRM_Name("1", "fp64"), PRM_Name(0)};
+static PRM_ChoiceList sModelMenu(PRM_CHOICELIST_SINGLE, sModel), sTermMenu(PRM_CHOICELIST_SINGLE, sTerm),
+    sKernelMenu(PRM_CHOICELIST_SINGLE, sKernel), sPrecisionMenu(PRM_CHOICELIST_SINGLE, sPrecision);
+static PRM_Range sRadiusRange(PRM_RANGE_RESTRICTED, 0.0, PRM_RANGE_UI, 10.0);
+static PRM_Range sFalloffRange(PRM_RANGE_RESTRICTED, 0.0, PRM_RANGE_UI, 2.0);
+
+static std::vector<PRM_Name> sNames;
+static std::vector<PRM_Default> sDefaults;
+static std::vector<PRM_Template> sTemplates;
+
+static PRM_Template *buildTemplates()
+{
+    if (!sTemplates.empty()) return sTemplates.data();
+    sNames.reserve(kNumRows);
+    sDefaults.reserve(2 * kNumRows);
+    sTemplates.emplace_back(PRM_STRING, 1, &PRMgroupName, nullptr, &SOP_Node::pointGroupMenu, nullptr, nullptr,
+                            SOP_Node::getGroupSelectButton(GA_GROUP_POINT));
+    for (const ParmRow &r : kRows) {
+        sNames.emplace_back(r.token, r.label);
+        sDefaults.emplace_back(r.def0);
+        PRM_Default *def = &sDefaults.back();
+        if (r.kind == '2') sDefaults.emplace_back(r.def1);
+        PRM_Name *name = &sNames.back();
+        const std::string tok(r.token);
+        switch (r.kind) {
+        case 'o': {
+            PRM_ChoiceList *menu = tok == "model" ? &sModelMenu : tok == "term" ? &sTermMenu
+                                   : tok == "kernel" ? &sKernelMenu : &sPrecisionMenu;
+            sTemplates.emplace_back(PRM_ORD, 1, name, def, menu);
+            break;
+        }
+        case 'f': sTemplates.emplace_back(PRM_FLT_J, 1, name, def, nullptr, tok == "falloffrate" ? &sFalloffRange : nullptr); break;
+        case 'l': sTemplates.emplace_back(PRM_FLT_LOG, 1, name, def, nullptr, &sRadiusRange); break;
+        case 'i': sTemplates.emplace_back(PRM_INT_J, 1, name, def); break;
+        case 't': sTemplates.emplace_back(PRM_TOGGLE, 1, name, def); break;
+        case '2': sTemplates.emplace_back(PRM_FLT_J, 2, name, def); break;
+        }
+    }
+    sTemplates.emplace_back();
+    return sTemplates.data();
+}
+
+// ---- page-wise gather / scatter between GA attributes and flat arrays --------------------
+// (the access pattern the reference's dead threaded evaluator sketches,
+//  src/SOP_FaceDeform.hpp:116-188: GA pages are contiguous runs of 1024 elements)
+static void gatherV3(const GU_Detail *gdp, const GA_Attribute *attr, std::vector<float> &out)
+{
+    out.resize(3 * (size_t)gdp->getNumPoints());
+    GA_ROPageHandleV3 h(attr);
+    GA_Offset start, end;
+    for (GA_Iterator it(gdp->getPointRange()); it.blockAdvance(start, end);) {
+        h.setPage(start);
+        for (GA_Offset o = start; o < end; ++o) {
+            const UT_Vector3 v = h.get(o);
+            const size_t i = 3 * (size_t)gdp->pointIndex(o);
+            out[i] = v.x(); out[i + 1] = v.y(); out[i + 2] = v.z();
+        }
+    }
+}
+
+static void scatterV3(GU_Detail *gdp, GA_Attribute *attr, const std::vector<float> &in)
+{
+    GA_RWPageHandleV3 h(attr);
+    GA_Offset start, end;
+    for (GA_Iterator it(gdp->getPointRange()); it.blockAdvance(start, end);) {
+        h.setPage(start);
+        for (GA_Offset o = start; o < end; ++o) {
+            const size_t i = 3 * (size_t)gdp->pointIndex(o);
+            h.set(o, UT_Vector3(in[i], in[i + 1], in[i + 2]));
+        }
+    }
+}
+
+class SOP_FaceDeformHip : public SOP_Node
+{
+public:
+    static OP_Node *create(OP_Network *net, const char *name, OP_Operator *op) { return new SOP_FaceDeformHip(net, name, op); }
+
+    SOP_FaceDeformHip(OP_Network *net, const char *name, OP_Operator *op) : SOP_Node(net, name, op)
+    {
+        mySopFlags.setManagesDataIDs(true);     // as the reference: it bumps P's data ID itself
+        myNode = fdsop_create(nullptr);
+    }
+    ~SOP_FaceDeformHip() override { fdsop_destroy(myNode); }
+
+protected:
+    OP_ERROR cookMySop(OP_Context &context) override
+    {
+        OP_AutoLockInputs inputs(this);
+        if (inputs.lock(context) >= UT_ERROR_ABORT) return error();
+        const fpreal t = context.getTime();
+        duplicatePointSource(0, context);
+        const GU_Detail *rest = inputGeo(1);
+        const GU_Detail *deform = inputGeo(2);
+        if (!myNode) { addError(SOP_MESSAGE, "GPU deformation engine unavailable."); return error(); }
+
+        // forward every parm by token
+        for (const ParmRow &r : kRows) {
+            if (r.kind == 'o') { UT_String s; evalString(s, r.token, 0, t); fdsop_set_string(myNode, r.token, s.buffer()); }
+            else if (r.kind == 'i' || r.kind == 't') fdsop_set_int(myNode, r.token, (int)evalInt(r.token, 0, t));
+            else { fdsop_set_float(myNode, r.token, 0, evalFloat(r.token, 0, t)); if (r.kind == '2') fdsop_set_float(myNode, r.token, 1, evalFloat(r.token, 1, t)); }
+        }
+
+        std::vector<float> P, restP, deformP, tu, tv, nn, dist2, Pout, falloff, Cd;
+        gatherV3(gdp, gdp->getP(), P);
+        gatherV3(rest, rest->getP(), restP);
+        gatherV3(deform, deform->getP(), deformP);
+        const GA_Attribute *aU = gdp->findFloatTuple(GA_ATTRIB_POINT, "tangentu", 3);
+        const GA_Attribute *aV = gdp->findFloatTuple(GA_ATTRIB_POINT, "tangentv", 3);
+        const GA_Attribute *aN = gdp->findFloatTuple(GA_ATTRIB_POINT, "N", 3);
+        if (aU && aV && aN) { gatherV3(gdp, aU, tu); gatherV3(gdp, aV, tv); gatherV3(gdp, aN, nn); }
+        // dist2: the detached attribute ProximityCapture maintains (reference src/capture.cpp:31);
+        // the capture itself stays host code and is not reproduced here.
+        if (const GA_Attribute *aD = captureDistanceAttribute()) {
+            dist2.resize((size_t)gdp->getNumPoints());
+            GA_ROHandleF h(aD);
+            GA_Offset o;
+            GA_FOR_ALL_PTOFF(gdp, o) dist2[(size_t)gdp->pointIndex(o)] = h.get(o);
+        }
+        const size_t n = (size_t)gdp->getNumPoints();
+        Pout.resize(3 * n); falloff.resize(n); Cd.resize(3 * n);
+
+        fdsop_geo geo{};
+        geo.npoints = (int64_t)n;
+        geo.P = P.data();
+        geo.tangentu = tu.empty() ? nullptr : tu.data();
+        geo.tangentv = tv.empty() ? nullptr : tv.data();
+        geo.N = nn.empty() ? nullptr : nn.data();
+        geo.dist2 = dist2.empty() ? nullptr : dist2.data();
+        geo.rest_npoints = rest->getNumPoints();
+        geo.deform_npoints = deform->getNumPoints();
+        geo.rest_P = restP.data();
+        geo.deform_P = deformP.data();
+        geo.P_out = Pout.data();
+        geo.fd_falloff = falloff.data();
+        geo.Cd = Cd.data();
+        fdsop_cook(myNode, &geo);
+
+        // replay the engine's messages through the node's own channels
+        std::string msgs(fdsop_messages(myNode));
+        for (size_t p = 0; p < msgs.size();) {
+            const size_t e = msgs.find('\n', p), tab = msgs.find('\t', p);
+            const std::string sev = msgs.substr(p, tab - p), text = msgs.substr(tab + 1, e - tab - 1);
+            if (sev == "error") addError(sev == "error" && text == "Rest and deform geometry should match." ? SOP_ERR_MISMATCH_POINT : SOP_ERR_NO_DEFORM_EFFECT, text.c_str());
+            else if (sev == "warning") addWarning(SOP_MESSAGE, text.c_str());
+            else addMessage(SOP_MESSAGE, text.c_str());
+            p = e + 1;
+        }
+        if (error() >= UT_ERROR_ABORT) return error();
+
+        scatterV3(gdp, gdp->getP(), Pout);
+        GA_RWHandleF hf(gdp->addFloatTuple(GA_ATTRIB_POINT, "fd_falloff", 1));
+        GA_RWHandleV3 hc(gdp->addFloatTuple(GA_ATTRIB_POINT, "Cd", 3, GA_Defaults(GA_STORE_REAL32, 3, 1.f, 1.f, 1.f)));
+        GA_Offset o;
+        GA_FOR_ALL_PTOFF(gdp, o) hf.set(o, falloff[(size_t)gdp->pointIndex(o)]);
+        (void)hc;
+        gdp->getP()->bumpDataId();
+        return error();
+    }
+
+private:
+    // Hook for the host-side ProximityCapture of the reference; returns nullptr when the
+    // capture has not run (the cook then warns exactly as the reference does, :398).
+    const GA_Attribute *captureDistanceAttribute() const { return nullptr; }
+
+    fdsop_node *myNode = nullptr;
+};
+
+}  // namespace fdhip
+
+void newSopOperator(OP_OperatorTable *table)
+{
+    table->addOperator(new OP_Operator("facedeform", "Face Deform", fdhip::SOP_FaceDeformHip::create,
+                                       fdhip::buildTemplates(), 3, 1000, nullptr));
+}

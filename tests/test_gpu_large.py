@@ -1,0 +1,144 @@
+"""GPU: BASELINE.json's full sizes.  The oracle is too slow to run over 1M x 256 pairs in a
+test, so full-size runs are checked through (a) the oracle on a vertex sample, (b) properties
+that do not depend on size: interpolation at the control points, zero deltas leave P
+bit-identical, range splits are bit-identical, an exported model replicates bitwise."""
+import numpy as np
+import pytest
+
+from conftest import parity_ratio
+from facedeform_amd import capi, dist as fdist, synth
+from oracle import fd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+TOL_FP32 = 1e-5
+
+
+def _build(M, mesh="head", frame=0, kind=capi.KERNEL_THIN_PLATE, params=(), precision=capi.EVAL_FP32):
+    rest = synth.control_points(M, mesh)
+    deform = synth.deformed_rig(rest, frame)
+    e = capi.Engine(precision=precision)
+    e.set_points(rest, (deform - rest).astype(np.float32))
+    e.set_kernel(kind, params)
+    e.set_term(capi.TERM_LINEAR)
+    rep = e.build()
+    return e, rest, deform, rep
+
+
+def _oracle(oracle, rest, deform, kind=fo.KERNEL_THIN_PLATE, params=()):
+    table = oracle.control_table(rest, deform)
+    rc, tt, W, radii = oracle.build(table, kind, params, fo.TERM_LINEAR)
+    assert tt == 1
+    return table, W, radii
+
+
+def test_c2_one_million_vertices_256_centres(hip_lib, oracle):
+    """BASELINE config 2."""
+    P = synth.head_mesh(1_000_000)
+    e, rest, deform, rep = _build(256)
+    assert rep.terminationtype == 1 and rep.n == 260
+    out, fall = e.deform(P)
+    table, W, radii = _oracle(oracle, rest, deform)
+    Wg, _ = e.get_weights()
+    assert np.abs(Wg - W).max() <= 1e-8 * np.abs(W).max()
+    idx = np.unique(np.concatenate([np.arange(0, 1_000_000, 397), [0, 1, 255, 256, 1023, 1024, 999_999]]))
+    ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P[idx])
+    assert parity_ratio(out[idx], ref, P[idx], TOL_FP32) <= 1.0
+    assert np.array_equal(fall, np.ones(1_000_000, np.float32))
+    # vertex ranges as 8 GPUs would take them (config 5 layout) reproduce the whole run bit for bit
+    for r in (0, 3, 7):
+        lo, hi = fdist.vertex_range(1_000_000, r, 8)
+        part, _ = e.deform(P[lo:hi])
+        assert np.array_equal(part, out[lo:hi])
+    e.close()
+
+
+def test_interpolation_property_at_full_rig_sizes(hip_lib):
+    """Evaluating at the control points returns their deltas (lambda = 0): no oracle needed,
+    so it also covers orders the CPU LU would take minutes for.  M = 1100 / 2100 / 4200 walk
+    the NB = 16 / 8 / 4 panel widths of the blocked LU."""
+    for M in (256, 1100, 2100, 4200):
+        e, rest, deform, rep = _build(M, precision=capi.EVAL_FP64)
+        assert rep.terminationtype == 1 and rep.n == M + 4, M
+        assert rep.iterationscount == M + 4
+        out, _ = e.deform(rest)
+        delta = (deform - rest).astype(np.float32)
+        got = out.astype(np.float64) - rest
+        scale = np.linalg.norm(delta, axis=1).max()
+        # one fp32 rounding of P + d on top of the solve's backward error
+        assert np.abs(got - delta).max() <= 2e-5 * scale + 2 * np.spacing(np.float32(1.0)), M
+        e.close()
+
+
+def test_c3_2048_centres_weights_and_sample(hip_lib, oracle):
+    """BASELINE config 3 (solve-bound): fp64 LU of order 2052 against the CPU LU."""
+    e, rest, deform, rep = _build(2048)
+    assert rep.terminationtype == 1 and rep.n == 2052
+    table, W, radii = _oracle(oracle, rest, deform)
+    Wg, _ = e.get_weights()
+    assert np.abs(Wg - W).max() <= 1e-7 * np.abs(W).max()      # cond ~ 1e6: 1e-16 * cond and headroom
+    P = synth.head_mesh(1_000_000)[::500]
+    out, _ = e.deform(P)
+    ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    assert parity_ratio(out, ref, P, TOL_FP32) <= 1.0
+    e.close()
+
+
+def test_zero_deltas_leave_points_bit_identical(hip_lib):
+    P = synth.head_mesh(200_000)
+    rest = synth.control_points(256, "head")
+    for kind, params in ((capi.KERNEL_THIN_PLATE, ()), (capi.KERNEL_GAUSSIAN_QNN, (1.0, 5.0))):
+        e = capi.Engine()
+        e.set_points(rest, np.zeros_like(rest))
+        e.set_kernel(kind, params)
+        e.set_term(capi.TERM_LINEAR)
+        e.build()
+        out, _ = e.deform(P)
+        assert np.array_equal(out, P)
+        e.close()
+
+
+def test_linearity_in_the_deltas(hip_lib):
+    """The weights are linear in the right-hand side: W(a*d1 + d2) = a*W(d1) + W(d2)."""
+    rest = synth.control_points(256, "head")
+    d1 = synth.smooth_deltas(rest, 0).astype(np.float64)
+    d2 = synth.smooth_deltas(rest, 5).astype(np.float64)
+    Ws = []
+    for d in (d1, d2, (0.5 * d1 + d2)):
+        e = capi.Engine()
+        e.set_points(rest, d.astype(np.float32))
+        e.set_kernel(capi.KERNEL_THIN_PLATE)
+        e.set_term(capi.TERM_LINEAR)
+        e.build()
+        Ws.append(e.get_weights()[0])
+        e.close()
+    # the fp32 rounding of the inputs is the only non-linearity
+    assert np.abs(0.5 * Ws[0] + Ws[1] - Ws[2]).max() <= 1e-5 * np.abs(Ws[2]).max()
+
+
+def test_split_mesh_with_device_side_model_broadcast(hip_lib):
+    """Config 5 on one GPU: the solving context exports its model into device memory, a second
+    context (standing in for another rank after the RCCL broadcast) imports it from there and
+    evaluates its vertex range; the union equals the single-context result bit for bit."""
+    torch = pytest.importorskip("torch")
+    N, M = 300_000, 512
+    P = synth.head_mesh(N)
+    a, rest, deform, rep = _build(M)
+    whole, _ = a.deform(P)
+    nbytes = a.model_bytes()
+    blob = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    a.export_model_dev(blob.data_ptr(), nbytes)
+    a.synchronize()
+    received = blob.clone()                      # what dist.broadcast would deliver on a peer
+    b = capi.Engine()
+    b.import_model_dev(received.data_ptr(), nbytes, M)
+    b.synchronize()
+    d_P = torch.from_numpy(P).cuda()
+    d_out = torch.zeros_like(d_P)
+    torch.cuda.synchronize()
+    for r in range(4):
+        lo, hi = fdist.vertex_range(N, r, 4)
+        eng = a if r == 0 else b
+        eng.deform_dev(hi - lo, d_P.data_ptr() + 12 * lo, d_out.data_ptr() + 12 * lo)
+    a.synchronize(); b.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), whole)
+    a.close(); b.close()
