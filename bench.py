@@ -116,11 +116,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the engine has no CPU path)")
+    # FD_BENCH_REHEARSE=1: several ranks share GPU 0 and talk over gloo -- only for rehearsing the
+    # multi-rank launch on a one-GPU box (RCCL refuses two ranks on one device)
+    rehearse = os.environ.get("FD_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_verts, n_ctrl, mesh_kind, desc = CONFIGS[args.config]
     P_host = synth.sphere_mesh(n_verts) if mesh_kind == "sphere" else synth.head_mesh(n_verts)
@@ -208,7 +216,7 @@ def main():
         lat.append(time.perf_counter() - t1)
     latency_ms = float(np.median(lat)) * 1e3
 
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -196,6 +196,10 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
     const int tid = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * (kBlock * V);
 
+    // positions are held in normalised coordinates x' = (x - x0) * inv_s (inv_s is a power of
+    // two); the raw position is re-read in the epilogue
+    const float nx = p.model->norm32[0], ny = p.model->norm32[1], nz = p.model->norm32[2];
+    const float inv_s = p.model->norm32[3];
     LaneT px[Q], py[Q], pz[Q];
     float d2v[V];
     bool live[V];
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
     for (int v = 0; v < V; ++v) {
         const int64_t i = base + v * kBlock + tid;
         const int64_t ic = i < p.N ? i : p.N - 1;
-        L::set(px[v / W], v % W, p.P_in[3 * ic]);
-        L::set(py[v / W], v % W, p.P_in[3 * ic + 1]);
-        L::set(pz[v / W], v % W, p.P_in[3 * ic + 2]);
+        L::set(px[v / W], v % W, (p.P_in[3 * ic] - nx) * inv_s);
+        L::set(py[v / W], v % W, (p.P_in[3 * ic + 1] - ny) * inv_s);
+        L::set(pz[v / W], v % W, (p.P_in[3 * ic + 2] - nz) * inv_s);
         d2v[v] = p.dist2 ? p.dist2[ic] : 0.f;
         live[v] = (i < p.N) && !(d2v[v] > p.radius2);   // gate on squares, :402,:408
         any_live |= live[v];
@@ -216,12 +220,14 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
     double accx[V], accy[V], accz[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        // affine part V*[1;x] first (rows M..M+3 of the weights)
-        const float *a = p.model->affine32;
+        // polynomial part first: C0 + L.x' + q |x'|^2 per output (affine term of the weights,
+        // plus thin-plate's change-of-unit correction)
+        const float *a = p.model->poly32;
         const float x = L::get(px[v / W], v % W), y = L::get(py[v / W], v % W), z = L::get(pz[v / W], v % W);
-        accx[v] = (double)__builtin_fmaf(a[3], z, __builtin_fmaf(a[2], y, __builtin_fmaf(a[1], x, a[0])));
-        accy[v] = (double)__builtin_fmaf(a[7], z, __builtin_fmaf(a[6], y, __builtin_fmaf(a[5], x, a[4])));
-        accz[v] = (double)__builtin_fmaf(a[11], z, __builtin_fmaf(a[10], y, __builtin_fmaf(a[9], x, a[8])));
+        const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        accx[v] = (double)__builtin_fmaf(a[4], xx, __builtin_fmaf(a[3], z, __builtin_fmaf(a[2], y, __builtin_fmaf(a[1], x, a[0]))));
+        accy[v] = (double)__builtin_fmaf(a[9], xx, __builtin_fmaf(a[8], z, __builtin_fmaf(a[7], y, __builtin_fmaf(a[6], x, a[5]))));
+        accz[v] = (double)__builtin_fmaf(a[14], xx, __builtin_fmaf(a[13], z, __builtin_fmaf(a[12], y, __builtin_fmaf(a[11], x, a[10]))));
     }
 
     // wave-uniform skip: every vertex of this wave is gated out or out of range
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
     for (int v = 0; v < V; ++v) {
         const int64_t i = base + v * kBlock + tid;
         if (i >= p.N) continue;
-        const float pos[3] = {L::get(px[v / W], v % W), L::get(py[v / W], v % W), L::get(pz[v / W], v % W)};
+        const float pos[3] = {p.P_in[3 * i], p.P_in[3 * i + 1], p.P_in[3 * i + 2]};
         if (!live[v] || !built) {
             if (p.P_out != p.P_in) {
                 p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];

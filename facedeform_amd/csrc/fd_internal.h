@@ -36,9 +36,15 @@ struct DevModel {
     unsigned long long amax_bits;  // max |A_ij| as raw double bits (atomicMax)
     unsigned long long pivmin_bits;
     unsigned long long pivmax_bits;
-    // affine[c*4 + 0] = constant of output c; affine[c*4 + 1..3] = x,y,z coefficients
-    float affine32[12];
+    // fp64 evaluation, raw coordinates: affine64[c*4 + 0] = constant of output c,
+    // affine64[c*4 + 1..3] = x,y,z coefficients
     double affine64[12];
+    // fp32 evaluation works in normalised coordinates x' = (x - x0) * inv_s, inv_s a power of
+    // two (exact): norm32 = {x0.x, x0.y, x0.z, inv_s}.  poly32[c*5 + 0..4] = {C0, Lx, Ly, Lz, q}
+    // of output c: affine part re-expressed in x' plus, for thin-plate, the exact correction
+    // kappa * sum_j w_j |x' - c'_j|^2 that the change of length unit brings (kappa = s^2 ln s).
+    float norm32[4];
+    float poly32[15];
 };
 
 // Blob header for fd_export_model / fd_import_model.

@@ -296,3 +296,26 @@ def test_sop_cook_matches_oracle_and_reports_like_reference(hip_lib, oracle):
     bad = rest.copy(); bad[4] = bad[0]
     res4 = node2.cook(P, bad, deform)
     assert res4.errors == ["Can't solve the problem."] and np.array_equal(res4.P, P)
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (100.0, 0.0), (100.0, 500.0), (0.01, 3.0), (1.0, 10.0)])
+def test_length_unit_and_origin_do_not_cost_accuracy(hip_lib, oracle, scale, offset):
+    """Thin-plate's log makes fp32 accuracy depend on the length unit unless the evaluation
+    normalises its coordinates (a cm-scale asset far from the origin must still hold 1e-5)."""
+    base_P = synth.head_mesh(200_000)[::50].astype(np.float64)
+    base_rest = synth.control_points(256, "head").astype(np.float64)
+    P = (base_P * scale + offset).astype(np.float32)
+    rest = (base_rest * scale + offset).astype(np.float32)
+    deform = (rest + synth.smooth_deltas(base_rest.astype(np.float32)) * np.float32(scale)).astype(np.float32)
+    for kind, okind, params, term, tol in (
+            (capi.KERNEL_THIN_PLATE, fo.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, TOL_FP32),
+            (capi.KERNEL_THIN_PLATE, fo.KERNEL_THIN_PLATE, [], capi.TERM_CONST, TOL_FP32),
+            (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, [1.0, 5.0], capi.TERM_LINEAR, TOL_FP32),
+            (capi.KERNEL_BIHARMONIC, fo.KERNEL_BIHARMONIC, [], capi.TERM_LINEAR, TOL_FP32)):
+        e = _engine(kind, params, term, rest, deform)
+        e.build()
+        out, _ = e.deform(P)
+        table, W, radii = _oracle_model(oracle, okind, params, term, rest, deform)
+        ref, _ = oracle.deform(table, okind, radii, W, P)
+        assert parity_ratio(out, ref, P, tol) <= 1.0, (scale, offset, kind, term, parity_ratio(out, ref, P, tol))
+        e.close()
