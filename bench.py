@@ -37,6 +37,8 @@ CONFIGS = {
     "c1": (10_000, 32, "sphere", "C1: 10k-vert sphere, 32 control points"),
     "c2": (1_000_000, 256, "head", "C2: 1M-vert head mesh, 256 control points"),
     "c3": (1_000_000, 2048, "head", "C3: 1M-vert head mesh, 2048 control points (solve-bound)"),
+    # one mesh split into vertex ranges over the ranks, model broadcast once per step
+    "c5": (10_000_000, 512, "head", "C5: 10M-vert mesh, 512 control points, vertex ranges split across the GPUs"),
 }
 METRIC = "deformed Mverts/sec at 256 ctrl pts, 1/2/4/8 MI355X vs host-CPU ref"
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA dense peak
@@ -103,6 +105,107 @@ def cpu_baseline(cfg_name, P, rest, deform, max_pairs):
     }
 
 
+def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev, rehearse):
+    """BASELINE config 5: ONE mesh, contiguous page-aligned vertex ranges per rank.  Per step:
+    rank 0 assembles + solves, exports the model blob into device memory, ONE broadcast (RCCL
+    over xGMI with the nccl backend), every rank imports it and evaluates its own range.  The
+    mesh is resident on every rank; only the ~26 KB blob moves.  Strong scaling."""
+    from facedeform_amd import dist as fdist
+    n_verts, n_ctrl, mesh_kind, desc = CONFIGS["c5"]
+    lo, hi = fdist.vertex_range(n_verts, rank, world)
+    n_mine = hi - lo
+    P_host = synth.head_mesh(n_verts)
+    rest_host = synth.control_points(n_ctrl, mesh_kind)
+    deltas_host = np.stack([synth.smooth_deltas(rest_host, f) for f in range(N_FRAMES)])
+    d_P = torch.from_numpy(P_host[lo:hi]).to(dev)
+    d_out = torch.empty_like(d_P)
+    d_fall = torch.zeros(max(n_mine, 1), device=dev, dtype=torch.float32)
+    d_rest = torch.from_numpy(rest_host).to(dev)
+    d_deltas = torch.from_numpy(deltas_host).to(dev)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    eng = capi.Engine(device=local_rank, variant=args.variant)
+    eng.set_stream(stream.cuda_stream)
+    eng.set_kernel(capi.KERNEL_THIN_PLATE)
+    eng.set_term(capi.TERM_LINEAR)
+    eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr(), n_ctrl)
+    eng.build()
+    nbytes = eng.model_bytes()
+    blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    blob_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory() if rehearse else None
+    delta_stride = n_ctrl * 3 * 4
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+    def step(i, e=None):
+        frame = i % N_FRAMES
+        if e: e[0].record(stream)
+        if rank == 0:
+            eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr() + frame * delta_stride, n_ctrl)
+            eng.build_async()
+            if world > 1:
+                eng.export_model_dev(blob.data_ptr(), nbytes)      # waits for the build status
+        if e: e[1].record(stream)
+        if world > 1:
+            if rehearse:                                            # gloo: through host memory
+                if rank == 0:
+                    blob_host.copy_(blob, non_blocking=False)
+                dist.broadcast(blob_host, src=0)
+                if rank != 0:
+                    blob.copy_(blob_host, non_blocking=False)
+            else:
+                dist.broadcast(blob, src=0)
+            if rank != 0:
+                eng.import_model_dev(blob.data_ptr(), nbytes, n_ctrl)
+        if e: e[2].record(stream)
+        if n_mine > 0:
+            eng.deform_dev(n_mine, d_P.data_ptr(), d_out.data_ptr(), d_falloff=d_fall.data_ptr())
+        if e: e[3].record(stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, ev[i])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        build_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        bcast_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        eval_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+        flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_mine
+        tf = flops / (eval_ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "deformed Mverts/sec, one 10M-vert mesh at 512 ctrl pts split across the GPUs",
+            "value": args.steps * n_verts / elapsed / 1e6, "unit": "Mverts/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc + ", thin-plate kernel, linear term, model rebuilt on rank 0 every step, "
+                                   "one model broadcast per step", "n_verts": n_verts, "n_ctrl": n_ctrl,
+                       "verts_on_rank0": n_mine, "model_blob_bytes": nbytes,
+                       "parallelism": f"vertex ranges over {world} GPU(s), 1 broadcast/step"},
+            "roofline": {"bound": "mfma", "kernel": "k_deform32", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
+                         "flops_per_launch": flops, "avg_launch_ms": eval_ms},
+            "phases_ms": {"build_rank0": build_ms, "broadcast_and_import": bcast_ms, "evaluate": eval_ms},
+        }), flush=True)
+    eng.set_stream(None)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     import torch
@@ -131,6 +234,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_verts, n_ctrl, mesh_kind, desc = CONFIGS[args.config]
+    if args.config == "c5":
+        return run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev, rehearse)
     P_host = synth.sphere_mesh(n_verts) if mesh_kind == "sphere" else synth.head_mesh(n_verts)
     rest_host = synth.control_points(n_ctrl, mesh_kind)
     deltas_host = np.stack([synth.smooth_deltas(rest_host, f) for f in range(N_FRAMES)])
