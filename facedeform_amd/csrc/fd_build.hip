@@ -733,6 +733,51 @@ __global__ __launch_bounds__(256) void k_pack(const double *X, int npad, const d
     }
 }
 
+// ---- thin-plate only: centre tiles for the matrix-pipe evaluation ------------------------
+// An fp32 value splits EXACTLY into three bf16 pieces hi + mid + lo (8 significant bits each,
+// by truncation).  d2 = |x'|^2 - 2 x'.c' + |c'|^2 then runs on the bf16 MFMA to fp32 accuracy:
+// per coordinate the six products (hi,hi) (hi,mid) (mid,hi) (mid,mid) (hi,lo) (lo,hi) -- the
+// three dropped ones are below 2^-24 relative -- and |c'|^2 against 1 in three more slots.
+__device__ __forceinline__ void split3_bf16(float x, unsigned &hi, unsigned &mid, unsigned &lo)
+{
+    const unsigned u = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(u & 0xffff0000u);     // exact
+    const unsigned u1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);   // exact, at most 8 significant bits left
+    hi = u >> 16; mid = u1 >> 16; lo = __float_as_uint(r2) >> 16;
+}
+
+__global__ __launch_bounds__(64) void k_pack_tiles(const Rec32 *rec32, int Mpad, MfmaTile *tiles)
+{
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int g = lane >> 4, i = lane & 15;
+    const Rec32 r = rec32[16 * tile + i];          // Mpad is a multiple of 16; padding records are zero
+    unsigned h, m, l;
+    unsigned k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g < 3) {
+        const float c = g == 0 ? r.cx : (g == 1 ? r.cy : r.cz);
+        split3_bf16(c, h, m, l);
+        k[0] = h; k[1] = h; k[2] = m; k[3] = m; k[4] = h; k[5] = l;     // against x: hi mid hi mid lo hi
+    } else {
+        const float cc = fmaf(r.cz, r.cz, fmaf(r.cy, r.cy, r.cx * r.cx));
+        split3_bf16(cc, h, m, l);
+        k[0] = h; k[1] = m; k[2] = l;                                   // against 1, 1, 1
+    }
+    MfmaTile &t = tiles[tile];
+    t.a[lane][0] = k[0] | (k[1] << 16);
+    t.a[lane][1] = k[2] | (k[3] << 16);
+    t.a[lane][2] = k[4] | (k[5] << 16);
+    t.a[lane][3] = k[6] | (k[7] << 16);
+    if (i < 12) {
+        // slot i of group g: pair p = i / 6 (rows 2p, 2p+1), output c = (i % 6) / 2, half = i % 2
+        const int pair = i / 6, c = (i % 6) / 2, half = i % 2;
+        const Rec32 rw = rec32[16 * tile + 4 * g + 2 * pair + half];
+        t.w[g][i] = c == 0 ? rw.wx : (c == 1 ? rw.wy : rw.wz);
+    }
+    if (lane < 16) t.pad[lane] = 0.f;
+    (void)Mpad;
+}
+
 template <int NB>
 void lu_step(const BuildBuffers &b, int k0, hipStream_t stream)
 {
@@ -814,6 +859,8 @@ hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream)
     const double *X = b.d_X;
     hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, stream, X, b.npad, b.d_centres, b.d_radii, b.M,
                        b.Mpad, b.T, b.kind, b.d_W, b.d_rec32, b.d_rec64, b.d_model, 0);
+    if (b.kind == FD_KERNEL_THIN_PLATE)
+        hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16), dim3(64), 0, stream, b.d_rec32, b.Mpad, b.d_tiles);
     return hipGetLastError();
 }
 
@@ -822,6 +869,8 @@ hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream)
     hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, stream, (const double *)nullptr, b.npad,
                        b.d_centres, b.d_radii, b.M, b.Mpad, b.T, b.kind, b.d_W, b.d_rec32, b.d_rec64,
                        b.d_model, 1);
+    if (b.kind == FD_KERNEL_THIN_PLATE)
+        hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16), dim3(64), 0, stream, b.d_rec32, b.Mpad, b.d_tiles);
     return hipGetLastError();
 }
 

@@ -35,6 +35,7 @@ struct fd_ctx {
     int *d_ipiv = nullptr, *d_moves = nullptr;
     Rec32 *d_rec32 = nullptr;
     Rec64 *d_rec64 = nullptr;
+    MfmaTile *d_tiles = nullptr;
     DevModel *d_model = nullptr;
     DevModel *h_model = nullptr;  // pinned mirror
     ModelHeader *h_header = nullptr;  // pinned, for device-side export
@@ -114,6 +115,7 @@ static int ensure_model_capacity(fd_ctx *ctx, int M)
         if ((rc = dev_alloc(ctx, &ctx->d_W, (size_t)(M + 4) * 3))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_rec32, (size_t)Mpad))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_rec64, (size_t)Mpad))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_tiles, (size_t)Mpad / 16))) return rc;
         ctx->cap_M = M;
     }
     return FD_OK;
@@ -198,7 +200,7 @@ void fd_destroy(fd_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_rest, ctx->d_delta, ctx->d_centres, ctx->d_radii, ctx->d_W, ctx->d_A,
-                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_model,
+                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_model,
                     ctx->d_P, ctx->d_dist2, ctx->d_fall, ctx->d_tu, ctx->d_tv, ctx->d_nrm};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (ctx->h_model) (void)hipHostFree(ctx->h_model);
@@ -320,7 +322,7 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.d_A = ctx->d_A; b.d_X = ctx->d_X;
     b.d_ipiv = ctx->d_ipiv; b.d_moves = ctx->d_moves;
     b.d_W = ctx->d_W;
-    b.d_rec32 = ctx->d_rec32; b.d_rec64 = ctx->d_rec64;
+    b.d_rec32 = ctx->d_rec32; b.d_rec64 = ctx->d_rec64; b.d_tiles = ctx->d_tiles;
     b.Mpad = round_up(ctx->M, kRecPad);
     b.d_model = ctx->d_model;
 }
@@ -454,7 +456,7 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
     a.tu = d_tu; a.tv = d_tv; a.nrm = d_nrm;
     a.radius2 = radius2; a.falloffrate = falloffrate;
     a.M = ctx->M; a.Mpad = round_up(ctx->M, kRecPad); a.kind = ctx->kind;
-    a.rec32 = ctx->d_rec32; a.rec64 = ctx->d_rec64;
+    a.rec32 = ctx->d_rec32; a.rec64 = ctx->d_rec64; a.tiles = ctx->d_tiles;
     a.model = ctx->d_model;
     a.precision = ctx->eval_precision;
     a.variant = ctx->eval_variant;

@@ -49,6 +49,7 @@ struct EvalParams {
     int Mpad;
     const Rec32 *rec32;
     const Rec64 *rec64;
+    const MfmaTile *tiles;
     const DevModel *model;
 };
 
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
                 for (int q = 0; q < Q; ++q) az[q] = vfma(t[q], L::splat(wz), az[q]);
             }
         };
-        static_assert(kGroup == 2 && kRecPad == 8, "four stages of two records per iteration");
+        static_assert(kGroup == 2 && kRecPad % 8 == 0, "four stages of two records per iteration");
         // Four stages per iteration; each requests the next pair of records before it consumes
         // the current pair.  Scalar loads return out of order, so every wait on them is
         // lgkmcnt(0): the wait for the pair about to be consumed comes BEFORE the next request,
@@ -349,6 +350,168 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
         }
         float disp[3] = {(float)accx[v], (float)accy[v], (float)accz[v]};
         epilogue_store(p, i, pos, disp, d2v[v]);
+    }
+}
+
+// ---- thin-plate evaluation with d2 on the bf16 matrix pipe --------------------------------
+// The six VALU operations per pair that build d2 (3 sub, 3 fma) are the largest slice of the
+// all-VALU kernel after the logarithm.  Here one v_mfma_f32_16x16x32_bf16 produces the 256
+// squared distances of a 16-centre x 16-vertex tile:
+//     d2[i][j] = |x'_j|^2 (C operand) + sum_k A[i][k] * B[k][j]
+// with every fp32 coordinate split exactly into three bf16 pieces (k_pack_tiles above; the
+// vertex side is split here).  Accuracy equals the direct fp32 form (measured 1.4e-6 absolute
+// on [-1,1]^3 against 1.0e-6; tools/mfma_d2_test.hip).  The accumulator layout -- vertex on
+// the lane (col = lane & 15), centres 4*(lane>>4)+r in the four registers -- leaves the
+// reduction over centres in-lane; the four lane groups are summed once at the end.
+// VALU per tile and lane: 2 max + 4 log + 2 pk_mul + 6 pk_fma instead of 20 packed ops + 4 log.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTileChunk = 48;   // centre tiles staged in LDS at a time (48 * 1280 B = 60 KiB)
+
+template <int TV>
+__global__ __launch_bounds__(kBlock) void k_deform32_tps_mfma(const EvalParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MfmaTile *lds_tiles = reinterpret_cast<const MfmaTile *>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int64_t vbase = ((int64_t)blockIdx.x * 4 + wave) * (16 * TV);
+    const int ntiles = p.Mpad / 16;
+    const float n0 = p.model->norm32[0], n1 = p.model->norm32[1], n2 = p.model->norm32[2];
+    const float inv_s = p.model->norm32[3];
+    const bool built = p.model->terminationtype == 1;
+
+    // B operand (vertex side) and C operand (|x'|^2) of every vertex tile of this wave
+    bf16x8 bop[TV];
+    f32x4 cin[TV];
+    bool wave_live = false;
+#pragma unroll
+    for (int t = 0; t < TV; ++t) {
+        const int64_t vi = vbase + 16 * t + j;
+        const int64_t vc = vi < p.N ? vi : p.N - 1;
+        const float nsel = g == 0 ? n0 : (g == 1 ? n1 : n2);
+        const float comp = g < 3 ? (p.P_in[3 * vc + g] - nsel) * inv_s : 0.f;
+        float xx = comp * comp;
+        xx += __shfl_xor(xx, 16);
+        xx += __shfl_xor(xx, 32);
+        cin[t] = (f32x4){xx, xx, xx, xx};
+        unsigned h, m, l;
+        {
+            const float v2 = -2.f * comp;
+            const unsigned u = __float_as_uint(v2);
+            const float r1 = v2 - __uint_as_float(u & 0xffff0000u);
+            const unsigned u1 = __float_as_uint(r1);
+            const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+            h = u >> 16; m = u1 >> 16; l = __float_as_uint(r2) >> 16;
+        }
+        bf16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (g < 3) { b[0] = (short)h; b[1] = (short)m; b[2] = (short)h; b[3] = (short)m; b[4] = (short)l; b[5] = (short)h; }
+        else { b[0] = 0x3f80; b[1] = 0x3f80; b[2] = 0x3f80; }
+        bop[t] = b;
+        const float d2v = p.dist2 ? p.dist2[vc] : 0.f;
+        wave_live |= (vi < p.N) && !(d2v > p.radius2);
+    }
+    const bool wave_work = __any(wave_live) && built;
+
+    f32x2 acc[TV][3];
+    double accd[TV][3];
+#pragma unroll
+    for (int t = 0; t < TV; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { acc[t][c] = (f32x2){0.f, 0.f}; accd[t][c] = 0.0; }
+
+    for (int ct0 = 0; ct0 < ntiles; ct0 += kTileChunk) {
+        const int nct = ntiles - ct0 < kTileChunk ? ntiles - ct0 : kTileChunk;
+        // stage this chunk of centre tiles (16 B per lane, coalesced); every wave takes part
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.tiles + ct0);
+            uint4 *dst = reinterpret_cast<uint4 *>(smem);
+            const int n16 = nct * (int)(sizeof(MfmaTile) / 16);
+            __syncthreads();
+            for (int q = tid; q < n16; q += kBlock) dst[q] = src[q];
+            __syncthreads();
+        }
+        if (wave_work) {
+            for (int ct = 0; ct < nct; ++ct) {
+                const MfmaTile &tile = lds_tiles[ct];
+                const bf16x8 aop = *reinterpret_cast<const bf16x8 *>(&tile.a[lane][0]);
+                const float4 w0 = *reinterpret_cast<const float4 *>(&tile.w[g][0]);
+                const float4 w1 = *reinterpret_cast<const float4 *>(&tile.w[g][4]);
+                const float4 w2 = *reinterpret_cast<const float4 *>(&tile.w[g][8]);
+                const f32x2 wA[3] = {(f32x2){w0.x, w0.y}, (f32x2){w0.z, w0.w}, (f32x2){w1.x, w1.y}};   // rows 0,1
+                const f32x2 wB[3] = {(f32x2){w1.z, w1.w}, (f32x2){w2.x, w2.y}, (f32x2){w2.z, w2.w}};   // rows 2,3
+                f32x4 d[TV];
+#pragma unroll
+                for (int t = 0; t < TV; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop[t], cin[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < TV; ++t) {
+                    // rounding can leave a vertex that sits on a centre at a tiny negative d2
+                    const float d0 = fmaxf(d[t][0], 1e-30f), d1 = fmaxf(d[t][1], 1e-30f);
+                    const float d2 = fmaxf(d[t][2], 1e-30f), d3 = fmaxf(d[t][3], 1e-30f);
+                    const f32x2 dA = {d0, d1}, dB = {d2, d3};
+                    const f32x2 lA = {__builtin_amdgcn_logf(d0), __builtin_amdgcn_logf(d1)};
+                    const f32x2 lB = {__builtin_amdgcn_logf(d2), __builtin_amdgcn_logf(d3)};
+                    const f32x2 tA = dA * lA, tB = dB * lB;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        acc[t][c] = vfma(tA, wA[c], acc[t][c]);
+                        acc[t][c] = vfma(tB, wB[c], acc[t][c]);
+                    }
+                }
+                // fold the fp32 partial sums into fp64 every 32 centre tiles (128 terms per lane)
+                if (((ct0 + ct + 1) & 31) == 0) {
+#pragma unroll
+                    for (int t = 0; t < TV; ++t)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            accd[t][c] += (double)acc[t][c].x + (double)acc[t][c].y;
+                            acc[t][c] = (f32x2){0.f, 0.f};
+                        }
+                }
+            }
+        }
+    }
+
+    // sum over the two register halves and the four lane groups; afterwards every lane of
+    // column j holds the total of vertex j
+    double tot[TV][3];
+#pragma unroll
+    for (int t = 0; t < TV; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = accd[t][c] + (double)acc[t][c].x + (double)acc[t][c].y;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            tot[t][c] = v;
+        }
+
+    // epilogue: lane group g finishes the vertices of tiles g, g + 4, ...
+#pragma unroll
+    for (int t = 0; t < TV; ++t) {
+        if ((t & 3) != g) continue;
+        const int64_t i = vbase + 16 * t + j;
+        if (i >= p.N) continue;
+        const float pos[3] = {p.P_in[3 * i], p.P_in[3 * i + 1], p.P_in[3 * i + 2]};
+        const float d2v = p.dist2 ? p.dist2[i] : 0.f;
+        if (d2v > p.radius2 || !built) {
+            if (p.P_out != p.P_in) {
+                p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
+            }
+            continue;
+        }
+        const float x = (pos[0] - n0) * inv_s, y = (pos[1] - n1) * inv_s, z = (pos[2] - n2) * inv_s;
+        const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        const float *a = p.model->poly32;
+        float disp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float poly = __builtin_fmaf(a[5 * c + 4], xx, __builtin_fmaf(a[5 * c + 3], z,
+                                 __builtin_fmaf(a[5 * c + 2], y, __builtin_fmaf(a[5 * c + 1], x, a[5 * c]))));
+            disp[c] = (float)((double)poly + tot[t][c]);
+        }
+        epilogue_store(p, i, pos, disp, d2v);
     }
 }
 
@@ -431,6 +594,19 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
     // variant = lanes * 100 + source * 10 + log2(V):  lanes 0 scalar / 1 packed,
     // source 0 scalar-loaded records / 1 LDS-staged records.  0 = the default below.
     int variant = a.variant > 0 ? a.variant : kDefaultVariant;
+    if (variant == 200) {
+        if constexpr (KIND == FD_KERNEL_THIN_PLATE) {
+            constexpr int TV = 4;
+            const int64_t per = (int64_t)kBlock / 64 * 16 * TV;     // vertices per workgroup
+            const unsigned grid = (unsigned)((a.N + per - 1) / per);
+            const int ntiles = a.Mpad / 16;
+            const size_t lds = sizeof(MfmaTile) * (size_t)(ntiles < kTileChunk ? ntiles : kTileChunk);
+            hipLaunchKernelGGL((k_deform32_tps_mfma<TV>), dim3(grid), dim3(kBlock), lds, stream, p);
+            return hipGetLastError();
+        } else {
+            variant = kDefaultVariant;   // the matrix-pipe path exists for thin-plate only
+        }
+    }
     const size_t lds_bytes = (size_t)a.Mpad * sizeof(Rec32);
     if ((variant / 10) % 10 == 1 && lds_bytes > 64 * 1024) variant -= 10;   // one LDS tile must hold them all
     // Even placement: with every workgroup resident at once the dispatcher may stack 5 on one
@@ -476,7 +652,7 @@ hipError_t launch_deform(const DeformArgs &a, hipStream_t stream)
     p.tu = a.tu; p.tv = a.tv; p.nrm = a.nrm;
     p.radius2 = a.radius2; p.falloffrate = a.falloffrate;
     p.Mpad = a.Mpad;
-    p.rec32 = a.rec32; p.rec64 = a.rec64;
+    p.rec32 = a.rec32; p.rec64 = a.rec64; p.tiles = a.tiles;
     p.model = a.model;
     switch (a.kind) {
     case FD_KERNEL_GAUSSIAN:

@@ -24,7 +24,17 @@ struct Rec64 {
 };
 
 // Centres are padded with zero-weight records to a multiple of this.
-constexpr int kRecPad = 8;
+constexpr int kRecPad = 16;   // also the centre-tile height of the matrix-pipe evaluation
+
+// Centre tile of the thin-plate matrix-pipe evaluation (16 centres): the A operand of one
+// v_mfma_f32_16x16x32_bf16 as every lane reads it, and the weights of the tile arranged per
+// 16-lane group the way the accumulate consumes them.  1280 B, 16-byte aligned.
+struct MfmaTile {
+    unsigned int a[64][4];   // lane l: 8 bf16 = k-slots 8*(l>>4) .. +7 of centre (l&15)
+    float w[4][12];          // group g: {c0:(r0,r1) c1:(r0,r1) c2:(r0,r1) c0:(r2,r3) c1:(r2,r3) c2:(r2,r3)}, centre = 4g + r
+    float pad[16];
+};
+static_assert(sizeof(MfmaTile) == 1280, "tile image must stay 1280 bytes");
 
 // Device-resident build status + affine part; read by the deform kernel so that
 // an asynchronous build needs no host round trip before the deform launch.
@@ -80,6 +90,7 @@ struct BuildBuffers {
     double *d_W;                      // (M+4) x 3
     Rec32 *d_rec32;
     Rec64 *d_rec64;
+    MfmaTile *d_tiles;                // Mpad / 16 tiles (thin-plate only)
     int Mpad;
     DevModel *d_model;
 };
@@ -97,6 +108,7 @@ struct DeformArgs {
     float radius2, falloffrate;
     int M, Mpad, kind;
     const Rec32 *rec32; const Rec64 *rec64;
+    const MfmaTile *tiles;
     const DevModel *model;
     int precision, variant;
 };

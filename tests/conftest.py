@@ -68,8 +68,12 @@ def case_kind_term(name: str):
     raise KeyError(name)
 
 
-def parity_ratio(out, ref_out, P, tol):
+def parity_ratio(out, ref_out, P, tol, scale_out=None):
     """Worst per-component |out - ref| / allowed, where allowed = tol * max(|d_ref|, floor) + 1 ulp(ref).
+
+    scale_out: take the displacement magnitude from this output instead of ref_out.  Used when
+    the tangent projection is on: it can shrink a displacement a hundredfold, and the bar is
+    relative to the RBF displacement, not to what is left of it after projection.
 
     The reference adds the fp32 displacement to the fp32 position (src/SOP_FaceDeform.cpp:438),
     so two displacements that agree to `tol` may still round P + d to neighbouring floats; the
@@ -77,7 +81,7 @@ def parity_ratio(out, ref_out, P, tol):
     <= 1 passes."""
     out = np.asarray(out, np.float64)
     ref = np.asarray(ref_out, np.float64)
-    d_ref = ref - np.asarray(P, np.float64)
+    d_ref = (ref if scale_out is None else np.asarray(scale_out, np.float64)) - np.asarray(P, np.float64)
     nr = np.linalg.norm(d_ref, axis=1)
     floor = 1e-5 * (nr.max() if nr.size else 0.0)
     allowed = tol * np.maximum(nr, floor)[:, None] + np.spacing(np.abs(np.asarray(ref_out, np.float32))).astype(np.float64)

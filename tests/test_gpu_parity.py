@@ -73,7 +73,7 @@ def test_golden_points_deform_all_kernels(hip_lib, oracle, golden, precision, to
         e.close()
 
 
-@pytest.mark.parametrize("variant", [0, 2, 12, 101, 103, 112])
+@pytest.mark.parametrize("variant", [0, 2, 12, 101, 103, 112, 200])
 def test_c1_sphere_matches_oracle(hip_lib, oracle, variant):
     """BASELINE config 1: 10k-vertex sphere, 32 control points, thin-plate, linear term."""
     P = synth.sphere_mesh(10_000)
@@ -318,4 +318,37 @@ def test_length_unit_and_origin_do_not_cost_accuracy(hip_lib, oracle, scale, off
         table, W, radii = _oracle_model(oracle, okind, params, term, rest, deform)
         ref, _ = oracle.deform(table, okind, radii, W, P)
         assert parity_ratio(out, ref, P, tol) <= 1.0, (scale, offset, kind, term, parity_ratio(out, ref, P, tol))
+        e.close()
+
+
+@pytest.mark.parametrize("M,N", [(32, 10_007), (48, 4_099), (256, 20_000), (800, 3_001)])
+def test_matrix_pipe_variant_matches_oracle(hip_lib, oracle, M, N):
+    """Variant 200: d2 on the bf16 MFMA (thin-plate).  Ragged N, M that is not a multiple of
+    16, more centre tiles than one LDS chunk holds (M = 800 -> 50 tiles), vertices sitting
+    exactly on centres (d2 == 0, where rounding may go negative), gate, fall-off, tangents."""
+    rng = np.random.default_rng(M)
+    P = synth.head_mesh(max(N, 200_000))[:: max(N, 200_000) // N][:N].copy()
+    rest = synth.control_points(M, "head")
+    P[:8] = rest[:8]                                   # coincident with centres
+    deform = synth.deformed_rig(rest, 2)
+    tu, tv, nn = synth.tangent_frames(P)
+    r2 = np.float32(0.49)
+    dist2 = (rng.random(N) * 0.6).astype(np.float32)
+    dist2[::9] = -1.0
+    table, W, radii = _oracle_model(oracle, fo.KERNEL_THIN_PLATE, [], 0, rest, deform)
+    for kw in (dict(), dict(dist2=dist2, radius2=r2, falloffrate=1.5), dict(dist2=dist2, tangents=(tu, tv, nn), radius2=r2)):
+        e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, deform, variant=200)
+        e.build()
+        out, fall = e.deform(P, **kw)
+        ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, **kw)
+        # with the projection on, the bar stays relative to the unprojected RBF displacement
+        plain = None
+        if "tangents" in kw:
+            plain, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, **{k: v for k, v in kw.items() if k != "tangents"})
+        ratio = parity_ratio(out, ref, P, TOL_FP32, scale_out=plain)
+        assert ratio <= 1.0, (M, N, list(kw), ratio)
+        assert np.allclose(fall, ref_fall, rtol=2e-6, atol=1e-7)
+        if "dist2" in kw:
+            gated = dist2 > r2
+            assert np.array_equal(out[gated], P[gated])
         e.close()
