@@ -11,6 +11,9 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfacedeform_hip.so")
 SOURCES = ["fd_eval.hip", "fd_build.hip", "fd_capi.hip", "fd_sop_host.cpp"]
+# per-file extras: keep the bf16 MFMA results of the evaluation kernel in VGPRs (the default puts
+# them in AGPRs and pays one v_accvgpr_read per value)
+EXTRA_FLAGS = {"fd_eval.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HEADERS = [os.path.join(CSRC, "fd_internal.h"), os.path.join(_ROOT, "include", "facedeform_hip.h")]
 
 
@@ -43,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        cmd = [cc] + common + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + common + EXTRA_FLAGS.get(src, []) + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

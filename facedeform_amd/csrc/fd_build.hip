@@ -737,7 +737,8 @@ __global__ __launch_bounds__(256) void k_pack(const double *X, int npad, const d
 // An fp32 value splits EXACTLY into three bf16 pieces hi + mid + lo (8 significant bits each,
 // by truncation).  d2 = |x'|^2 - 2 x'.c' + |c'|^2 then runs on the bf16 MFMA to fp32 accuracy:
 // per coordinate the six products (hi,hi) (hi,mid) (mid,hi) (mid,mid) (hi,lo) (lo,hi) -- the
-// three dropped ones are below 2^-24 relative -- and |c'|^2 against 1 in three more slots.
+// three dropped ones are below 2^-24 relative -- and, in lane group 3, |c'|^2 against 1 and 1
+// against |x'|^2 in three slots each.
 __device__ __forceinline__ void split3_bf16(float x, unsigned &hi, unsigned &mid, unsigned &lo)
 {
     const unsigned u = __float_as_uint(x);
@@ -762,6 +763,7 @@ __global__ __launch_bounds__(64) void k_pack_tiles(const Rec32 *rec32, int Mpad,
         const float cc = fmaf(r.cz, r.cz, fmaf(r.cy, r.cy, r.cx * r.cx));
         split3_bf16(cc, h, m, l);
         k[0] = h; k[1] = m; k[2] = l;                                   // against 1, 1, 1
+        k[3] = 0x3f80; k[4] = 0x3f80; k[5] = 0x3f80;                    // 1 against the pieces of |x'|^2
     }
     MfmaTile &t = tiles[tile];
     t.a[lane][0] = k[0] | (k[1] << 16);

@@ -357,161 +357,207 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
 // The six VALU operations per pair that build d2 (3 sub, 3 fma) are the largest slice of the
 // all-VALU kernel after the logarithm.  Here one v_mfma_f32_16x16x32_bf16 produces the 256
 // squared distances of a 16-centre x 16-vertex tile:
-//     d2[i][j] = |x'_j|^2 (C operand) + sum_k A[i][k] * B[k][j]
-// with every fp32 coordinate split exactly into three bf16 pieces (k_pack_tiles above; the
-// vertex side is split here).  Accuracy equals the direct fp32 form (measured 1.4e-6 absolute
-// on [-1,1]^3 against 1.0e-6; tools/mfma_d2_test.hip).  The accumulator layout -- vertex on
-// the lane (col = lane & 15), centres 4*(lane>>4)+r in the four registers -- leaves the
-// reduction over centres in-lane; the four lane groups are summed once at the end.
-// VALU per tile and lane: 2 max + 4 log + 2 pk_mul + 6 pk_fma instead of 20 packed ops + 4 log.
+//     d2[i][j] = sum_k A[i][k] * B[k][j] = |x'_j|^2 - 2 x'_j . c'_i + |c'_i|^2
+// with every fp32 value split exactly into three bf16 pieces (k_pack_tiles packs the centre
+// side; the vertex side is split here).  K = 32 holds, per lane group g: the six cross products
+// of coordinate g (g < 3), and for g = 3 the three pieces of |c'|^2 against 1 and 1 against the
+// three pieces of |x'|^2.  Accuracy equals the direct fp32 form (measured 1.4e-6 absolute on
+// [-1,1]^3 against 1.0e-6; tools/mfma_d2_test.hip).  The accumulator layout -- vertex on the
+// lane (col = lane & 15), centres 4*(lane>>4)+r in the four registers -- leaves the reduction
+// over centres in-lane; the four lane groups are summed once at the end.
+// VALU per tile and lane: 4 log + 4 mul + 6 pk_fma instead of 20 packed ops + 4 log.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTileChunk = 48;   // centre tiles staged in LDS at a time (48 * 1280 B = 60 KiB)
+constexpr int kTileChunk = 24;   // centre tiles staged in LDS at a time (24 * 1280 B = 30 KiB)
+
+// d2 * log2|d2| with the DX9 multiply (0 * anything = 0): rounding can leave a vertex that sits
+// on a centre at exactly zero or at a tiny negative d2; the first gives 0 * -inf = 0 here and the
+// second an error of order 1e-7 * 23, the size of the rounding of d2 itself.  No clamp needed.
+extern "C" __device__ float fd_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+__device__ __forceinline__ float d2_log_d2(float d)
+{
+    return fd_fmul_legacy(d, __builtin_amdgcn_logf(__builtin_fabsf(d)));
+}
+
+// Inputs of one vertex group as a lane holds them: the coordinate its B-operand slot needs for
+// each of the wave's TV vertex tiles, and position + dist2 of the one vertex per tile quartet
+// whose epilogue this lane runs (tile g of the quartet, column j).
+template <int TV>
+struct GroupIn {
+    float comp[TV];
+    float pos[TV / 4][3];
+    float d2v[TV / 4];
+};
 
 template <int TV>
-__global__ __launch_bounds__(kBlock) void k_deform32_tps_mfma(const EvalParams p)
+__device__ __forceinline__ GroupIn<TV> load_group(const EvalParams &p, int64_t vbase, int g, int j)
 {
+    GroupIn<TV> in;
+    const int gc = g < 3 ? g : 0;
+#pragma unroll
+    for (int t = 0; t < TV; ++t) {
+        const int64_t vi = vbase + 16 * t + j;
+        const int64_t vc = vi < p.N ? vi : p.N - 1;
+        in.comp[t] = p.P_in[3 * vc + gc];
+    }
+#pragma unroll
+    for (int q = 0; q < TV / 4; ++q) {
+        const int64_t vi = vbase + 16 * (4 * q + g) + j;
+        const int64_t vc = vi < p.N ? vi : p.N - 1;
+        in.pos[q][0] = p.P_in[3 * vc]; in.pos[q][1] = p.P_in[3 * vc + 1]; in.pos[q][2] = p.P_in[3 * vc + 2];
+        in.d2v[q] = p.dist2 ? p.dist2[vc] : 0.f;
+    }
+    return in;
+}
+
+template <int TV>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_deform32_tps_mfma(const EvalParams p, int ngroups)
+{
+    static_assert(TV % 4 == 0, "a lane group finishes one tile of every quartet");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MfmaTile *lds_tiles = reinterpret_cast<const MfmaTile *>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
-    const int64_t vbase = ((int64_t)blockIdx.x * 4 + wave) * (16 * TV);
     const int ntiles = p.Mpad / 16;
     const float n0 = p.model->norm32[0], n1 = p.model->norm32[1], n2 = p.model->norm32[2];
     const float inv_s = p.model->norm32[3];
+    const float nsel = g == 0 ? n0 : (g == 1 ? n1 : n2);
     const bool built = p.model->terminationtype == 1;
+    const bool resident = ntiles <= kTileChunk;     // the whole model fits: stage it once
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // B operand (vertex side) and C operand (|x'|^2) of every vertex tile of this wave
-    bf16x8 bop[TV];
-    f32x4 cin[TV];
-    bool wave_live = false;
-#pragma unroll
-    for (int t = 0; t < TV; ++t) {
-        const int64_t vi = vbase + 16 * t + j;
-        const int64_t vc = vi < p.N ? vi : p.N - 1;
-        const float nsel = g == 0 ? n0 : (g == 1 ? n1 : n2);
-        const float comp = g < 3 ? (p.P_in[3 * vc + g] - nsel) * inv_s : 0.f;
-        float xx = comp * comp;
-        xx += __shfl_xor(xx, 16);
-        xx += __shfl_xor(xx, 32);
-        cin[t] = (f32x4){xx, xx, xx, xx};
-        unsigned h, m, l;
+    auto stage = [&](int ct0, int nct) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.tiles + ct0);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const int n16 = nct * (int)(sizeof(MfmaTile) / 16);
+        __syncthreads();
+        for (int q = tid; q < n16; q += kBlock) dst[q] = src[q];
+        __syncthreads();
+    };
+
+    // a block walks vertex groups blockIdx.x, blockIdx.x + gridDim.x, ... (64 * TV vertices each);
+    // the next group's inputs are in flight while this one is computed
+    int grp = blockIdx.x;
+    GroupIn<TV> nxt = load_group<TV>(p, ((int64_t)grp * 4 + wave) * (16 * TV), g, j);
+    if (resident) stage(0, ntiles);
+
+    for (; grp < ngroups; grp += gridDim.x) {
+        const int64_t vbase = ((int64_t)grp * 4 + wave) * (16 * TV);
+        const GroupIn<TV> in = nxt;
         {
-            const float v2 = -2.f * comp;
+            const int gn = grp + (int)gridDim.x < ngroups ? grp + (int)gridDim.x : grp;
+            nxt = load_group<TV>(p, ((int64_t)gn * 4 + wave) * (16 * TV), g, j);
+        }
+
+        // B operand (vertex side) of every vertex tile of this wave
+        bf16x8 bop[TV];
+#pragma unroll
+        for (int t = 0; t < TV; ++t) {
+            const float comp = g < 3 ? (in.comp[t] - nsel) * inv_s : 0.f;
+            float xx = comp * comp;
+            xx += __shfl_xor(xx, 16);
+            xx += __shfl_xor(xx, 32);
+            const float v2 = g < 3 ? -2.f * comp : xx;
             const unsigned u = __float_as_uint(v2);
             const float r1 = v2 - __uint_as_float(u & 0xffff0000u);
             const unsigned u1 = __float_as_uint(r1);
             const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-            h = u >> 16; m = u1 >> 16; l = __float_as_uint(r2) >> 16;
+            const short h = (short)(u >> 16), m = (short)(u1 >> 16), l = (short)(__float_as_uint(r2) >> 16);
+            const short one = (short)0x3f80;
+            bf16x8 b;
+            if (g < 3) b = (bf16x8){h, m, h, m, l, h, 0, 0};
+            else b = (bf16x8){one, one, one, h, m, l, 0, 0};
+            bop[t] = b;
         }
-        bf16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (g < 3) { b[0] = (short)h; b[1] = (short)m; b[2] = (short)h; b[3] = (short)m; b[4] = (short)l; b[5] = (short)h; }
-        else { b[0] = 0x3f80; b[1] = 0x3f80; b[2] = 0x3f80; }
-        bop[t] = b;
-        const float d2v = p.dist2 ? p.dist2[vc] : 0.f;
-        wave_live |= (vi < p.N) && !(d2v > p.radius2);
-    }
-    const bool wave_work = __any(wave_live) && built;
+        bool lane_live = false;
+#pragma unroll
+        for (int q = 0; q < TV / 4; ++q)
+            lane_live |= (vbase + 16 * (4 * q + g) + j < p.N) && !(in.d2v[q] > p.radius2);
+        const bool wave_work = __any(lane_live) && built;
 
-    f32x2 acc[TV][3];
-    double accd[TV][3];
+        f32x2 acc[TV][3];
+        float acc2[TV][3];
 #pragma unroll
-    for (int t = 0; t < TV; ++t)
+        for (int t = 0; t < TV; ++t)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { acc[t][c] = (f32x2){0.f, 0.f}; accd[t][c] = 0.0; }
+            for (int c = 0; c < 3; ++c) { acc[t][c] = (f32x2){0.f, 0.f}; acc2[t][c] = 0.f; }
 
-    for (int ct0 = 0; ct0 < ntiles; ct0 += kTileChunk) {
-        const int nct = ntiles - ct0 < kTileChunk ? ntiles - ct0 : kTileChunk;
-        // stage this chunk of centre tiles (16 B per lane, coalesced); every wave takes part
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.tiles + ct0);
-            uint4 *dst = reinterpret_cast<uint4 *>(smem);
-            const int n16 = nct * (int)(sizeof(MfmaTile) / 16);
-            __syncthreads();
-            for (int q = tid; q < n16; q += kBlock) dst[q] = src[q];
-            __syncthreads();
-        }
-        if (wave_work) {
-            for (int ct = 0; ct < nct; ++ct) {
-                const MfmaTile &tile = lds_tiles[ct];
-                const bf16x8 aop = *reinterpret_cast<const bf16x8 *>(&tile.a[lane][0]);
-                const float4 w0 = *reinterpret_cast<const float4 *>(&tile.w[g][0]);
-                const float4 w1 = *reinterpret_cast<const float4 *>(&tile.w[g][4]);
-                const float4 w2 = *reinterpret_cast<const float4 *>(&tile.w[g][8]);
-                const f32x2 wA[3] = {(f32x2){w0.x, w0.y}, (f32x2){w0.z, w0.w}, (f32x2){w1.x, w1.y}};   // rows 0,1
-                const f32x2 wB[3] = {(f32x2){w1.z, w1.w}, (f32x2){w2.x, w2.y}, (f32x2){w2.z, w2.w}};   // rows 2,3
-                f32x4 d[TV];
+        for (int ct0 = 0; ct0 < ntiles; ct0 += kTileChunk) {
+            const int nct = ntiles - ct0 < kTileChunk ? ntiles - ct0 : kTileChunk;
+            if (!resident) stage(ct0, nct);
+            if (wave_work) {
+                for (int ct = 0; ct < nct; ++ct) {
+                    const MfmaTile &tile = lds_tiles[ct];
+                    const bf16x8 aop = *reinterpret_cast<const bf16x8 *>(&tile.a[lane][0]);
+                    const float4 w0 = *reinterpret_cast<const float4 *>(&tile.w[g][0]);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(&tile.w[g][4]);
+                    const float4 w2 = *reinterpret_cast<const float4 *>(&tile.w[g][8]);
+                    const f32x2 wA[3] = {(f32x2){w0.x, w0.y}, (f32x2){w0.z, w0.w}, (f32x2){w1.x, w1.y}};   // rows 0,1
+                    const f32x2 wB[3] = {(f32x2){w1.z, w1.w}, (f32x2){w2.x, w2.y}, (f32x2){w2.z, w2.w}};   // rows 2,3
+                    f32x4 d[TV];
 #pragma unroll
-                for (int t = 0; t < TV; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop[t], cin[t], 0, 0, 0);
+                    for (int t = 0; t < TV; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop[t], zero4, 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < TV; ++t) {
-                    // rounding can leave a vertex that sits on a centre at a tiny negative d2
-                    const float d0 = fmaxf(d[t][0], 1e-30f), d1 = fmaxf(d[t][1], 1e-30f);
-                    const float d2 = fmaxf(d[t][2], 1e-30f), d3 = fmaxf(d[t][3], 1e-30f);
-                    const f32x2 dA = {d0, d1}, dB = {d2, d3};
-                    const f32x2 lA = {__builtin_amdgcn_logf(d0), __builtin_amdgcn_logf(d1)};
-                    const f32x2 lB = {__builtin_amdgcn_logf(d2), __builtin_amdgcn_logf(d3)};
-                    const f32x2 tA = dA * lA, tB = dB * lB;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        acc[t][c] = vfma(tA, wA[c], acc[t][c]);
-                        acc[t][c] = vfma(tB, wB[c], acc[t][c]);
-                    }
-                }
-                // fold the fp32 partial sums into fp64 every 32 centre tiles (128 terms per lane)
-                if (((ct0 + ct + 1) & 31) == 0) {
-#pragma unroll
-                    for (int t = 0; t < TV; ++t)
+                    for (int t = 0; t < TV; ++t) {
+                        const f32x2 tA = {d2_log_d2(d[t][0]), d2_log_d2(d[t][1])};
+                        const f32x2 tB = {d2_log_d2(d[t][2]), d2_log_d2(d[t][3])};
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            accd[t][c] += (double)acc[t][c].x + (double)acc[t][c].y;
-                            acc[t][c] = (f32x2){0.f, 0.f};
+                            acc[t][c] = vfma(tA, wA[c], acc[t][c]);
+                            acc[t][c] = vfma(tB, wB[c], acc[t][c]);
                         }
+                    }
                 }
+                // second-level fp32 sums: a run is at most 4 * kTileChunk = 96 terms per slot
+#pragma unroll
+                for (int t = 0; t < TV; ++t)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        acc2[t][c] += acc[t][c].x + acc[t][c].y;
+                        acc[t][c] = (f32x2){0.f, 0.f};
+                    }
             }
         }
-    }
 
-    // sum over the two register halves and the four lane groups; afterwards every lane of
-    // column j holds the total of vertex j
-    double tot[TV][3];
+        // sum over the four lane groups; afterwards every lane of column j holds the total of
+        // vertex j, and lane group g finishes tile g of every quartet
 #pragma unroll
-    for (int t = 0; t < TV; ++t)
+        for (int q = 0; q < TV / 4; ++q) {
+            float mine[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double v = accd[t][c] + (double)acc[t][c].x + (double)acc[t][c].y;
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            tot[t][c] = v;
-        }
-
-    // epilogue: lane group g finishes the vertices of tiles g, g + 4, ...
+            for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-    for (int t = 0; t < TV; ++t) {
-        if ((t & 3) != g) continue;
-        const int64_t i = vbase + 16 * t + j;
-        if (i >= p.N) continue;
-        const float pos[3] = {p.P_in[3 * i], p.P_in[3 * i + 1], p.P_in[3 * i + 2]};
-        const float d2v = p.dist2 ? p.dist2[i] : 0.f;
-        if (d2v > p.radius2 || !built) {
-            if (p.P_out != p.P_in) {
-                p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
+                for (int c = 0; c < 3; ++c) {
+                    float v = acc2[4 * q + tt][c];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (tt == g) mine[c] = v;
+                }
+            const int64_t i = vbase + 16 * (4 * q + g) + j;
+            if (i >= p.N) continue;
+            const float pos[3] = {in.pos[q][0], in.pos[q][1], in.pos[q][2]};
+            const float d2v = in.d2v[q];
+            if (d2v > p.radius2 || !built) {
+                if (p.P_out != p.P_in) {
+                    p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
+                }
+                continue;
             }
-            continue;
-        }
-        const float x = (pos[0] - n0) * inv_s, y = (pos[1] - n1) * inv_s, z = (pos[2] - n2) * inv_s;
-        const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
-        const float *a = p.model->poly32;
-        float disp[3];
+            const float x = (pos[0] - n0) * inv_s, y = (pos[1] - n1) * inv_s, z = (pos[2] - n2) * inv_s;
+            const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+            const float *a = p.model->poly32;
+            float disp[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float poly = __builtin_fmaf(a[5 * c + 4], xx, __builtin_fmaf(a[5 * c + 3], z,
-                                 __builtin_fmaf(a[5 * c + 2], y, __builtin_fmaf(a[5 * c + 1], x, a[5 * c]))));
-            disp[c] = (float)((double)poly + tot[t][c]);
+            for (int c = 0; c < 3; ++c) {
+                const float poly = __builtin_fmaf(a[5 * c + 4], xx, __builtin_fmaf(a[5 * c + 3], z,
+                                     __builtin_fmaf(a[5 * c + 2], y, __builtin_fmaf(a[5 * c + 1], x, a[5 * c]))));
+                disp[c] = poly + mine[c];
+            }
+            epilogue_store(p, i, pos, disp, d2v);
         }
-        epilogue_store(p, i, pos, disp, d2v);
     }
 }
 
@@ -598,10 +644,19 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
         if constexpr (KIND == FD_KERNEL_THIN_PLATE) {
             constexpr int TV = 4;
             const int64_t per = (int64_t)kBlock / 64 * 16 * TV;     // vertices per workgroup
-            const unsigned grid = (unsigned)((a.N + per - 1) / per);
+            const int64_t ngroups = (a.N + per - 1) / per;
+            // at most ~8 workgroups per CU in the grid; beyond that a workgroup walks several
+            // vertex groups and stages a resident model only once
+            static const int64_t max_grid = [] {
+                const char *e = getenv("FD_MFMA_GRID");
+                const long v = e ? atol(e) : 0;
+                return (int64_t)(v > 0 ? v : 2048);
+            }();
+            const int64_t rounds = (ngroups + max_grid - 1) / max_grid;
+            const unsigned grid = (unsigned)((ngroups + rounds - 1) / rounds);
             const int ntiles = a.Mpad / 16;
             const size_t lds = sizeof(MfmaTile) * (size_t)(ntiles < kTileChunk ? ntiles : kTileChunk);
-            hipLaunchKernelGGL((k_deform32_tps_mfma<TV>), dim3(grid), dim3(kBlock), lds, stream, p);
+            hipLaunchKernelGGL((k_deform32_tps_mfma<TV>), dim3(grid), dim3(kBlock), lds, stream, p, (int)ngroups);
             return hipGetLastError();
         } else {
             variant = kDefaultVariant;   // the matrix-pipe path exists for thin-plate only
