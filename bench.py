@@ -195,7 +195,7 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
                                    "one model broadcast per step", "n_verts": n_verts, "n_ctrl": n_ctrl,
                        "verts_on_rank0": n_mine, "model_blob_bytes": nbytes,
                        "parallelism": f"vertex ranges over {world} GPU(s), 1 broadcast/step"},
-            "roofline": {"bound": "mfma", "kernel": "k_deform32", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_deform32_tps_mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
                          "flops_per_launch": flops, "avg_launch_ms": eval_ms},
             "phases_ms": {"build_rank0": build_ms, "broadcast_and_import": bcast_ms, "evaluate": eval_ms},
@@ -365,7 +365,9 @@ def main():
             "roofline": {
                 # the evaluation kernel is compute-bound at this M (intensity ~182 flop/B vs ridge ~20):
                 # its roof is the fp32 rate, 157.3 TFLOP/s for VALU and MFMA alike on gfx950
-                "bound": "mfma", "kernel": "k_deform32",
+                "bound": "mfma",
+                "kernel": "k_deform32_tps_mfma" if (precision == capi.EVAL_FP32 and n_ctrl >= 49) else
+                          ("k_deform32" if precision == capi.EVAL_FP32 else "k_deform64"),
                 "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
                 "flops_per_launch": flops, "avg_launch_ms": eval_ms,

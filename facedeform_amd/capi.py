@@ -49,6 +49,8 @@ EXPORTS = [
     "fd_set_points_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize",
+    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error",
+    "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
     "fdsop_get_float", "fdsop_get_int", "fdsop_parm_count", "fdsop_parm_token", "fdsop_cook",
     "fdsop_messages", "fdsop_effective_float", "fdsop_engine",
@@ -96,6 +98,14 @@ def load() -> C.CDLL:
     L.fd_export_model.argtypes = [vp, vp, sz, i32]; L.fd_export_model.restype = i32
     L.fd_import_model.argtypes = [vp, vp, sz, i32]; L.fd_import_model.restype = i32
     L.fd_synchronize.argtypes = [vp]; L.fd_synchronize.restype = i32
+    L.fd_batch_create.argtypes = [C.POINTER(vp), i32]; L.fd_batch_create.restype = vp
+    L.fd_batch_destroy.argtypes = [vp]; L.fd_batch_destroy.restype = None
+    L.fd_batch_size.argtypes = [vp]; L.fd_batch_size.restype = i32
+    L.fd_batch_last_error.argtypes = [vp]; L.fd_batch_last_error.restype = C.c_char_p
+    L.fd_batch_set_points_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32]
+    L.fd_batch_set_points_dev.restype = i32
+    L.fd_batch_build_async.argtypes = [vp, vp]; L.fd_batch_build_async.restype = i32
+    L.fd_batch_build_result.argtypes = [vp, C.POINTER(FdReport)]; L.fd_batch_build_result.restype = i32
     L.fdsop_create.argtypes = [C.POINTER(FdConfig)]; L.fdsop_create.restype = vp
     L.fdsop_destroy.argtypes = [vp]; L.fdsop_destroy.restype = None
     L.fdsop_set_float.argtypes = [vp, C.c_char_p, i32, C.c_double]; L.fdsop_set_float.restype = i32
@@ -257,3 +267,58 @@ class Engine:
 
     def synchronize(self):
         self._check(self.L.fd_synchronize(self.ctx))
+
+
+MAX_BATCH = 32
+
+
+class Batch:
+    """fd_batch: contexts with the same M / kernel / term built by one launch chain."""
+
+    def __init__(self, engines):
+        self.L = load()
+        self.engines = list(engines)
+        arr = (C.c_void_p * len(self.engines))(*[e.ctx for e in self.engines])
+        self.h = self.L.fd_batch_create(arr, len(self.engines))
+        if not self.h:
+            raise FdError(FD_E_INVALID, self.L.fd_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fd_batch_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != FD_OK:
+            raise FdError(rc, self.L.fd_batch_last_error(self.h).decode())
+
+    def __len__(self):
+        return self.L.fd_batch_size(self.h)
+
+    def set_points_dev(self, d_rest_ptrs, d_delta_ptrs, M: int):
+        """Device pointers (ints), one pair per context; read in place by the next build."""
+        n = len(self.engines)
+        if len(d_rest_ptrs) != n or len(d_delta_ptrs) != n:
+            raise ValueError("one pointer pair per context")
+        r = (C.c_void_p * n)(*d_rest_ptrs)
+        d = (C.c_void_p * n)(*d_delta_ptrs)
+        self._check(self.L.fd_batch_set_points_dev(self.h, r, d, M))
+        for e in self.engines:
+            e.M = M
+
+    def build_async(self, stream_ptr: int | None = None):
+        self._check(self.L.fd_batch_build_async(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def build_result(self, check: bool = True):
+        n = len(self.engines)
+        reps = (FdReport * n)()
+        rc = self.L.fd_batch_build_result(self.h, reps)
+        if check:
+            self._check(rc)
+        return list(reps)

@@ -48,10 +48,18 @@ __device__ __forceinline__ double phi_d(int kind, double d2, double inv_r2)
 
 // ---- prepare: centres, RHS columns, status reset ------------------------------
 // reference src/SOP_FaceDeform.cpp:268-287 (table), widened to fp64
-__global__ void k_prepare(const float *rest, const float *delta, int M, int npad, int lda,
-                          double *centres, double *radii, double gauss_R, double *A,
-                          DevModel *model)
+// Every build kernel finds its buffers in tab[blockIdx.z]: one launch chain assembles and
+// factorises all the models of a batch (a single build is a batch of one).  With use_src the
+// control points come straight from the caller's device arrays (and are mirrored into the
+// context's own copy so that a later single rebuild still finds them).
+__global__ void k_prepare(const BatchSlot *tab, const PointSrc src, int use_src, int M, int npad, int lda,
+                          int ncols, double gauss_R)
 {
+    const BatchSlot &s = tab[blockIdx.z];
+    const float *rest = use_src ? src.rest[blockIdx.z] : s.rest;
+    const float *delta = use_src ? src.delta[blockIdx.z] : s.delta;
+    double *centres = s.centres, *radii = s.radii, *A = s.A;
+    DevModel *model = s.model;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         model->terminationtype = 0;
@@ -68,8 +76,13 @@ __global__ void k_prepare(const float *rest, const float *delta, int M, int npad
             if (i < M && c < 3) v = (double)delta[3 * i + c];
             A[(size_t)(npad + c) * lda + i] = v;
         }
+        // the 16 columns past the RHS block absorb the trailing update's block overrun
+        for (int c = 0; c < 16; ++c) A[(size_t)(ncols + c) * lda + i] = 0.0;
     }
     if (i < M) {
+        if (use_src) {
+            for (int c = 0; c < 3; ++c) { s.rest[3 * i + c] = rest[3 * i + c]; s.delta[3 * i + c] = delta[3 * i + c]; }
+        }
         centres[3 * i] = (double)rest[3 * i];
         centres[3 * i + 1] = (double)rest[3 * i + 1];
         centres[3 * i + 2] = (double)rest[3 * i + 2];
@@ -78,8 +91,10 @@ __global__ void k_prepare(const float *rest, const float *delta, int M, int npad
 }
 
 // QNN radii: R_i = q * distance to the nearest other centre
-__global__ void k_qnn_nearest(const double *centres, int M, double q, double *radii)
+__global__ void k_qnn_nearest(const BatchSlot *tab, int M, double q)
 {
+    const double *centres = tab[blockIdx.z].centres;
+    double *radii = tab[blockIdx.z].radii;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const double x = centres[3 * i], y = centres[3 * i + 1], z = centres[3 * i + 2];
@@ -94,8 +109,10 @@ __global__ void k_qnn_nearest(const double *centres, int M, double q, double *ra
 }
 
 // lower median by rank selection, then R_i = min(R_i, z * median)
-__global__ void k_qnn_median(const double *radii, int M, double *median_out)
+__global__ void k_qnn_median(const BatchSlot *tab, int M)
 {
+    const double *radii = tab[blockIdx.z].radii;
+    double *median_out = tab[blockIdx.z].W;      // scratch: W is rewritten by the pack kernel
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const double r = radii[i];
@@ -106,8 +123,10 @@ __global__ void k_qnn_median(const double *radii, int M, double *median_out)
     }
     if (rank == (M - 1) / 2) *median_out = r;
 }
-__global__ void k_qnn_cap(double *radii, int M, double z, const double *median)
+__global__ void k_qnn_cap(const BatchSlot *tab, int M, double z)
 {
+    double *radii = tab[blockIdx.z].radii;
+    const double *median = tab[blockIdx.z].W;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const double cap = z * (*median);
@@ -115,10 +134,13 @@ __global__ void k_qnn_cap(double *radii, int M, double z, const double *median)
 }
 
 // ---- assembly -----------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_assemble(const double *centres, const double *radii, int M,
+__global__ __launch_bounds__(256) void k_assemble(const BatchSlot *tab, int M,
                                                    int n, int npad, int lda, int kind, int T,
-                                                   double lambda, double *A, DevModel *model)
+                                                   double lambda)
 {
+    const double *centres = tab[blockIdx.z].centres, *radii = tab[blockIdx.z].radii;
+    double *A = tab[blockIdx.z].A;
+    DevModel *model = tab[blockIdx.z].model;
     // 16 x 16 element tile per workgroup; consecutive threads walk a column (coalesced)
     const int i = blockIdx.x * 16 + (threadIdx.x & 15);
     const int j = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -225,9 +247,12 @@ __device__ unsigned long long g_panel_stamps[16];
 // touches only the live columns j..NB-1 (a rolled loop with a rotating register row was
 // measured slower: it has to mask and move all NB columns every step).
 template <int NB, int TMAX>
-__global__ __launch_bounds__(TMAX) void k_lu_panel(double *A, int lda, int npad, int n_real,
-                                                   int k0, int *ipiv, int *moves, DevModel *model)
+__global__ __launch_bounds__(TMAX) void k_lu_panel(const BatchSlot *tab, int lda, int npad, int n_real,
+                                                   int k0)
 {
+    double *A = tab[blockIdx.z].A;
+    int *ipiv = tab[blockIdx.z].ipiv, *moves = tab[blockIdx.z].moves;
+    DevModel *model = tab[blockIdx.z].model;
     constexpr int R = 32 / NB;          // rows per lane: R * NB = 32 doubles in registers
     // live part of the pivot row of the current column, one slot per wave's candidate
     __shared__ __attribute__((aligned(16))) double s_row[2][16][NB];
@@ -383,9 +408,10 @@ __global__ __launch_bounds__(TMAX) void k_lu_panel(double *A, int lda, int npad,
 
 // ---- LU trailing update ---------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(256) void k_lu_trail(double *A, int lda, int npad, int k0,
-                                                  const int *moves)
+__global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda, int npad, int k0)
 {
+    double *A = tab[blockIdx.z].A;
+    const int *moves = tab[blockIdx.z].moves;
     constexpr int S = NB / 4;           // k-steps of the f64 16x16x4 MFMA
     __shared__ double sL[NB][NB + 1];   // L11 (unit lower), +1 pad: column reads conflict-free
     __builtin_amdgcn_s_setprio(3);
@@ -494,8 +520,10 @@ __global__ __launch_bounds__(256) void k_lu_trail(double *A, int lda, int npad, 
 // the 32 x 32 triangle (rows in registers, x_k travels by v_readlane: no LDS round trip,
 // no barrier inside), so global latency hides behind the solve.
 template <int T>
-__global__ __launch_bounds__(T) void k_backsub_all(const double *A, int lda, int npad, double *X)
+__global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda, int npad)
 {
+    const double *A = tab[blockIdx.z].A;
+    double *X = tab[blockIdx.z].X;
     extern __shared__ __attribute__((aligned(16))) double s_y[];   // [3][npad]
     __shared__ double s_u[2][32][33];
     __shared__ double s_x[32][3];
@@ -614,11 +642,16 @@ __device__ __forceinline__ double block_max(double v, double *scratch, int tid)
     return a > b ? a : b;
 }
 
-__global__ __launch_bounds__(256) void k_pack(const double *X, int npad, const double *centres,
-                                              const double *radii, int M, int Mpad, int T, int kind,
-                                              double *W, Rec32 *rec32, Rec64 *rec64, DevModel *model,
+__global__ __launch_bounds__(256) void k_pack(const BatchSlot *tab, int npad, int M, int Mpad, int T, int kind,
                                               int from_w)
 {
+    const BatchSlot &slot = tab[blockIdx.z];
+    const double *X = from_w ? nullptr : slot.X;
+    const double *centres = slot.centres, *radii = slot.radii;
+    double *W = slot.W;
+    Rec32 *rec32 = slot.rec32;
+    Rec64 *rec64 = slot.rec64;
+    DevModel *model = slot.model;
     __shared__ int s_bad;
     __shared__ double s_red[4];
     const int tid = threadIdx.x;
@@ -748,8 +781,10 @@ __device__ __forceinline__ void split3_bf16(float x, unsigned &hi, unsigned &mid
     hi = u >> 16; mid = u1 >> 16; lo = __float_as_uint(r2) >> 16;
 }
 
-__global__ __launch_bounds__(64) void k_pack_tiles(const Rec32 *rec32, int Mpad, MfmaTile *tiles)
+__global__ __launch_bounds__(64) void k_pack_tiles(const BatchSlot *tab, int Mpad)
 {
+    const Rec32 *rec32 = tab[blockIdx.z].rec32;
+    MfmaTile *tiles = tab[blockIdx.z].tiles;
     const int tile = blockIdx.x, lane = threadIdx.x;
     const int g = lane >> 4, i = lane & 15;
     const Rec32 r = rec32[16 * tile + i];          // Mpad is a multiple of 16; padding records are zero
@@ -785,43 +820,51 @@ void lu_step(const BuildBuffers &b, int k0, hipStream_t stream)
 {
     constexpr int R = 32 / NB;
     const int nrem = b.npad - k0;
+    const unsigned nb = (unsigned)b.nbatch;
     int threads = round_up((nrem + R - 1) / R, 64);
     if (threads < 64) threads = 64;
     if (threads <= 512)
-        hipLaunchKernelGGL((k_lu_panel<NB, 512>), dim3(1), dim3(threads), 0, stream, b.d_A, b.lda, b.npad,
-                           b.n, k0, b.d_ipiv, b.d_moves, b.d_model);
+        hipLaunchKernelGGL((k_lu_panel<NB, 512>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda,
+                           b.npad, b.n, k0);
     else
-        hipLaunchKernelGGL((k_lu_panel<NB, 1024>), dim3(1), dim3(threads), 0, stream, b.d_A, b.lda, b.npad,
-                           b.n, k0, b.d_ipiv, b.d_moves, b.d_model);
+        hipLaunchKernelGGL((k_lu_panel<NB, 1024>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda,
+                           b.npad, b.n, k0);
     // the last block may run into the 16 zero columns allocated past ncols
     const int ncb = (b.ncols - (k0 + NB) + kColBlock - 1) / kColBlock;
     if (ncb > 0)
-        hipLaunchKernelGGL((k_lu_trail<NB>), dim3(ncb), dim3(256), 0, stream, b.d_A, b.lda, b.npad,
-                           k0, b.d_moves);
+        hipLaunchKernelGGL((k_lu_trail<NB>), dim3(ncb, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0);
 }
 
 }  // namespace
 
+// centres, right-hand sides, status reset.  src == nullptr: read the contexts' own copies of
+// the control points; otherwise straight from the caller's arrays (one pointer pair per model).
+hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
+{
+    static const PointSrc none{};
+    const int threads = 256;
+    const int blocks = (b.npad + threads - 1) / threads;
+    hipLaunchKernelGGL(k_prepare, dim3(blocks, 1, b.nbatch), dim3(threads), 0, stream, b.d_slots,
+                       src ? *src : none, src ? 1 : 0, b.M, b.npad, b.lda, b.ncols, b.gauss_R);
+    return hipGetLastError();
+}
+
+// everything after k_prepare: radii, assembly, LU, back-substitution, packing
 hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
 {
     const int M = b.M;
+    const unsigned nb = (unsigned)b.nbatch;
     {
         const int threads = 256;
-        const int blocks = (b.npad + threads - 1) / threads;
-        hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(threads), 0, stream, b.d_rest, b.d_delta, M,
-                           b.npad, b.lda, b.d_centres, b.d_radii, b.gauss_R, b.d_A, b.d_model);
         if (b.kind == FD_KERNEL_GAUSSIAN_QNN) {
             const int mb = (M + threads - 1) / threads;
-            double *median = b.d_W;  // scratch: W is rewritten by the pack kernel
-            hipLaunchKernelGGL(k_qnn_nearest, dim3(mb), dim3(threads), 0, stream, b.d_centres, M,
-                               b.qnn_q, b.d_radii);
-            hipLaunchKernelGGL(k_qnn_median, dim3(mb), dim3(threads), 0, stream, b.d_radii, M, median);
-            hipLaunchKernelGGL(k_qnn_cap, dim3(mb), dim3(threads), 0, stream, b.d_radii, M, b.qnn_z,
-                               median);
+            hipLaunchKernelGGL(k_qnn_nearest, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, M, b.qnn_q);
+            hipLaunchKernelGGL(k_qnn_median, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, M);
+            hipLaunchKernelGGL(k_qnn_cap, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, M, b.qnn_z);
         }
-        const dim3 grid(b.npad / 16, b.npad / 16);
-        hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, stream, b.d_centres, b.d_radii, M, b.n,
-                           b.npad, b.lda, b.kind, b.T, b.lambda, b.d_A, b.d_model);
+        const dim3 grid(b.npad / 16, b.npad / 16, nb);
+        hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, stream, b.d_slots, M, b.n, b.npad, b.lda, b.kind,
+                           b.T, b.lambda);
     }
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
 
@@ -833,14 +876,13 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
         else if (nrem <= 4096) { lu_step<8>(b, k0, stream); k0 += 8; }
         else { lu_step<4>(b, k0, stream); k0 += 4; }
     }
-    double *X = b.d_X;
     {
         // Y (3 x npad fp64) stays in LDS: 3 * 8192 * 8 B = 192 KiB would not fit, but the panel
         // kernel already limits the order to kMaxOrder and 3 * npad * 8 <= 160 KiB - 18 KiB
         // holds up to npad = 5900; larger systems are rejected in fd_set_points
         const size_t ybytes = sizeof(double) * 3 * (size_t)b.npad;
         if (b.npad <= 512)
-            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1), dim3(256), ybytes, stream, b.d_A, b.lda, b.npad, X);
+            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), ybytes, stream, b.d_slots, b.lda, b.npad);
         else {
             static bool attr_set = false;   // > 64 KiB of dynamic LDS has to be requested once
             if (!attr_set) {
@@ -848,7 +890,7 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
                 attr_set = true;
             }
-            hipLaunchKernelGGL((k_backsub_all<1024>), dim3(1), dim3(1024), ybytes, stream, b.d_A, b.lda, b.npad, X);
+            hipLaunchKernelGGL((k_backsub_all<1024>), dim3(1, 1, nb), dim3(1024), ybytes, stream, b.d_slots, b.lda, b.npad);
         }
     }
     hipError_t e = launch_pack(b, stream);
@@ -858,21 +900,19 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
 
 hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream)
 {
-    const double *X = b.d_X;
-    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, stream, X, b.npad, b.d_centres, b.d_radii, b.M,
-                       b.Mpad, b.T, b.kind, b.d_W, b.d_rec32, b.d_rec64, b.d_model, 0);
+    const unsigned nb = (unsigned)b.nbatch;
+    hipLaunchKernelGGL(k_pack, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.npad, b.M, b.Mpad, b.T, b.kind, 0);
     if (b.kind == FD_KERNEL_THIN_PLATE)
-        hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16), dim3(64), 0, stream, b.d_rec32, b.Mpad, b.d_tiles);
+        hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16, 1, nb), dim3(64), 0, stream, b.d_slots, b.Mpad);
     return hipGetLastError();
 }
 
 hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, stream, (const double *)nullptr, b.npad,
-                       b.d_centres, b.d_radii, b.M, b.Mpad, b.T, b.kind, b.d_W, b.d_rec32, b.d_rec64,
-                       b.d_model, 1);
+    const unsigned nb = (unsigned)b.nbatch;
+    hipLaunchKernelGGL(k_pack, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.npad, b.M, b.Mpad, b.T, b.kind, 1);
     if (b.kind == FD_KERNEL_THIN_PLATE)
-        hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16), dim3(64), 0, stream, b.d_rec32, b.Mpad, b.d_tiles);
+        hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16, 1, nb), dim3(64), 0, stream, b.d_slots, b.Mpad);
     return hipGetLastError();
 }
 

@@ -38,6 +38,15 @@ struct fd_ctx {
     MfmaTile *d_tiles = nullptr;
     DevModel *d_model = nullptr;
     DevModel *h_model = nullptr;  // pinned mirror
+    // where the build kernels find the buffers above: a one-entry device table (a single build
+    // is a batch of one); re-uploaded whenever a buffer is reallocated
+    BatchSlot *d_slot = nullptr;
+    BatchSlot h_slot{};
+    uint64_t alloc_gen = 0;
+    // set while the model comes from a batched build on another stream (fd_batch_build_async)
+    hipEvent_t wait_event = nullptr;
+    hipStream_t wait_stream = nullptr;
+    hipEvent_t tev0 = nullptr, tev_mid = nullptr, tev1 = nullptr;   // events the report's timings come from
     ModelHeader *h_header = nullptr;  // pinned, for device-side export
 
     // staging for the host-pointer deform
@@ -135,6 +144,30 @@ static int ensure_solver_capacity(fd_ctx *ctx, int npad)
     return FD_OK;
 }
 
+static int sync_slot(fd_ctx *ctx)
+{
+    BatchSlot t{};
+    t.rest = ctx->d_rest; t.delta = ctx->d_delta;
+    t.centres = ctx->d_centres; t.radii = ctx->d_radii;
+    t.A = ctx->d_A; t.X = ctx->d_X; t.W = ctx->d_W;
+    t.ipiv = ctx->d_ipiv; t.moves = ctx->d_moves;
+    t.rec32 = ctx->d_rec32; t.rec64 = ctx->d_rec64; t.tiles = ctx->d_tiles;
+    t.model = ctx->d_model;
+    if (ctx->alloc_gen != 0 && memcmp(&t, &ctx->h_slot, sizeof(t)) == 0) return FD_OK;
+    // a buffer moved: hipFree in dev_alloc has drained the device, nothing reads the old table
+    FD_HIP(ctx, hipMemcpy(ctx->d_slot, &t, sizeof(t), hipMemcpyHostToDevice));
+    ctx->h_slot = t;
+    ++ctx->alloc_gen;
+    return FD_OK;
+}
+
+// a model that a batched build is producing on another stream: make `s` wait for it
+static int order_after_batch(fd_ctx *ctx, hipStream_t s)
+{
+    if (ctx->wait_event && s != ctx->wait_stream) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->wait_event, 0));
+    return FD_OK;
+}
+
 extern "C" {
 
 int fd_abi_version(void) { return FD_ABI_VERSION; }
@@ -180,6 +213,7 @@ fd_ctx *fd_create(const fd_config *cfg)
     ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev_mid) == hipSuccess &&
          hipEventCreate(&ctx->ev1) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_model, sizeof(DevModel)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_slot, sizeof(BatchSlot)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_model, sizeof(DevModel), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_header, sizeof(ModelHeader), hipHostMallocDefault) == hipSuccess;
     if (ok) ok = hipMemset(ctx->d_model, 0, sizeof(DevModel)) == hipSuccess;
@@ -190,6 +224,7 @@ fd_ctx *fd_create(const fd_config *cfg)
         return nullptr;
     }
     ctx->stream = ctx->own_stream;
+    ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
     ctx->use_graph = getenv("FD_NO_GRAPH") == nullptr;
     return ctx;
 }
@@ -200,7 +235,7 @@ void fd_destroy(fd_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_rest, ctx->d_delta, ctx->d_centres, ctx->d_radii, ctx->d_W, ctx->d_A,
-                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_model,
+                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_model, ctx->d_slot,
                     ctx->d_P, ctx->d_dist2, ctx->d_fall, ctx->d_tu, ctx->d_tv, ctx->d_nrm};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (ctx->h_model) (void)hipHostFree(ctx->h_model);
@@ -317,14 +352,9 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.gauss_R = ctx->kind == FD_KERNEL_GAUSSIAN ? ctx->params[0] : 1.0;
     b.qnn_q = ctx->params[0];
     b.qnn_z = ctx->params[1];
-    b.d_rest = ctx->d_rest; b.d_delta = ctx->d_delta;
-    b.d_centres = ctx->d_centres; b.d_radii = ctx->d_radii;
-    b.d_A = ctx->d_A; b.d_X = ctx->d_X;
-    b.d_ipiv = ctx->d_ipiv; b.d_moves = ctx->d_moves;
-    b.d_W = ctx->d_W;
-    b.d_rec32 = ctx->d_rec32; b.d_rec64 = ctx->d_rec64; b.d_tiles = ctx->d_tiles;
     b.Mpad = round_up(ctx->M, kRecPad);
-    b.d_model = ctx->d_model;
+    b.d_slots = ctx->d_slot;
+    b.nbatch = 1;
 }
 
 int fd_build_async(fd_ctx *ctx)
@@ -336,6 +366,7 @@ int fd_build_async(fd_ctx *ctx)
     const int npad = round_up(order_of(ctx), 32);
     const bool grew = npad > ctx->cap_npad;
     if ((rc = ensure_solver_capacity(ctx, npad))) return rc;
+    if ((rc = sync_slot(ctx))) return rc;
     BuildBuffers b;
     fill_build_buffers(ctx, b);
     if (grew) {
@@ -343,9 +374,6 @@ int fd_build_async(fd_ctx *ctx)
         const size_t cols = (size_t)ctx->cap_npad + kRhsCols + 16;
         FD_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, sizeof(double) * (size_t)ctx->cap_npad * cols, ctx->stream));
     }
-    double *pad_cols = ctx->d_A + (size_t)b.lda * b.ncols;
-    const size_t pad_bytes = sizeof(double) * (size_t)b.lda * 16;
-
     fd_ctx::GraphKey key{};
     key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term; key.nparams = ctx->nparams;
     memcpy(key.params, ctx->params, sizeof(key.params));
@@ -355,7 +383,7 @@ int fd_build_async(fd_ctx *ctx)
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            hipError_t e1 = hipMemsetAsync(pad_cols, 0, pad_bytes, ctx->stream);
+            hipError_t e1 = launch_prepare(b, ctx->stream, nullptr);
             hipError_t e2 = launch_build(b, ctx->stream, nullptr);
             e = hipStreamEndCapture(ctx->stream, &graph);
             if (e == hipSuccess && (e1 != hipSuccess || e2 != hipSuccess)) e = e1 != hipSuccess ? e1 : e2;
@@ -375,10 +403,12 @@ int fd_build_async(fd_ctx *ctx)
         FD_HIP(ctx, hipEventRecord(ctx->ev_mid, ctx->stream));   // phases are not split inside a graph
         FD_HIP(ctx, hipGraphLaunch(ctx->build_exec, ctx->stream));
     } else {
-        FD_HIP(ctx, hipMemsetAsync(pad_cols, 0, pad_bytes, ctx->stream));
+        FD_HIP(ctx, launch_prepare(b, ctx->stream, nullptr));
         FD_HIP(ctx, launch_build(b, ctx->stream, ctx->ev_mid));
     }
     FD_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->wait_event = nullptr; ctx->wait_stream = nullptr;
+    ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
     ctx->build_pending = true;
     ctx->built = false;
     ctx->have_report = false;
@@ -391,8 +421,10 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
     int rc = use_device(ctx);
     if (rc) return rc;
     if (ctx->build_pending) {
+        if ((rc = order_after_batch(ctx, ctx->stream))) return rc;
         FD_HIP(ctx, hipMemcpyAsync(ctx->h_model, ctx->d_model, sizeof(DevModel), hipMemcpyDeviceToHost, ctx->stream));
         FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->wait_event = nullptr; ctx->wait_stream = nullptr;   // the batched build it named is complete
         fd_report r{};
         r.terminationtype = ctx->h_model->terminationtype;
         r.iterationscount = ctx->h_model->iterations;
@@ -402,8 +434,8 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
         memcpy(&pmax, &ctx->h_model->pivmax_bits, 8);
         r.pivot_ratio = (pmax > 0.0 && pmin <= pmax) ? pmin / pmax : 0.0;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_mid) == hipSuccess) r.t_assemble_ms = ms;
-        if (hipEventElapsedTime(&ms, ctx->ev_mid, ctx->ev1) == hipSuccess) r.t_solve_ms = ms;
+        if (hipEventElapsedTime(&ms, ctx->tev0, ctx->tev_mid) == hipSuccess) r.t_assemble_ms = ms;
+        if (hipEventElapsedTime(&ms, ctx->tev_mid, ctx->tev1) == hipSuccess) r.t_solve_ms = ms;
         ctx->report = r;
         ctx->have_report = true;
         ctx->build_pending = false;
@@ -460,6 +492,7 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
     a.model = ctx->d_model;
     a.precision = ctx->eval_precision;
     a.variant = ctx->eval_variant;
+    if ((rc = order_after_batch(ctx, launch_stream))) return rc;
     FD_HIP(ctx, launch_deform(a, launch_stream));
     return FD_OK;
 }
@@ -599,9 +632,11 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     FD_HIP(ctx, hipMemcpyAsync(ctx->d_radii, p, sizeof(double) * (size_t)M, kd, ctx->stream));
     p += sizeof(double) * (size_t)M;
     FD_HIP(ctx, hipMemcpyAsync(ctx->d_W, p, sizeof(double) * 3 * (size_t)(M + 4), kd, ctx->stream));
+    if ((rc = sync_slot(ctx))) return rc;
     BuildBuffers b;
     fill_build_buffers(ctx, b);
     FD_HIP(ctx, launch_pack_from_weights(b, ctx->stream));
+    ctx->wait_event = nullptr; ctx->wait_stream = nullptr;
     if (!on_device) FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->points_set = false;   // no rest/delta on this context: it can deform, not rebuild
     ctx->build_pending = false;
@@ -613,5 +648,204 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     ctx->have_report = true;
     return FD_OK;
 }
+
+// ---- batched build ----------------------------------------------------------------
+// Several contexts with the same M, kernel, parameters and term -- frames of one rig, or the
+// nodes of one cook graph -- are assembled and factorised by ONE launch chain: grid z selects
+// the context.  A lone build of this size keeps one CU busy through ~25 dependent launches and
+// the device overlaps only two or three such chains, so throughput-oriented callers batch.
+struct fd_batch {
+    int n = 0;
+    int device = 0;
+    fd_ctx *ctxs[kMaxBatch] = {};
+    uint64_t gens[kMaxBatch] = {};
+    BatchSlot *d_slots = nullptr;
+    PointSrc src{};
+    bool have_src = false;
+    hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool use_graph = true;
+    struct Key { int M, kind, term, nparams; double params[4]; } key{};
+    char err[512] = {0};
+};
+
+static void batch_err(fd_batch *b, const char *fmt, ...)
+{
+    char *dst = b ? b->err : g_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+}
+
+fd_batch *fd_batch_create(fd_ctx *const *ctxs, int n)
+{
+    if (!ctxs || n <= 0 || n > kMaxBatch) { set_err(nullptr, "fd_batch_create: need 1..%d contexts", kMaxBatch); return nullptr; }
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device) { set_err(nullptr, "fd_batch_create: contexts must exist and share one device"); return nullptr; }
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) { set_err(nullptr, "fd_batch_create: context listed twice"); return nullptr; }
+    }
+    fd_batch *b = new (std::nothrow) fd_batch();
+    if (!b) { set_err(nullptr, "fd_batch_create: out of host memory"); return nullptr; }
+    b->n = n;
+    b->device = ctxs[0]->device;
+    for (int i = 0; i < n; ++i) b->ctxs[i] = ctxs[i];
+    bool ok = hipSetDevice(b->device) == hipSuccess;
+    ok = ok && hipMalloc((void **)&b->d_slots, sizeof(BatchSlot) * (size_t)n) == hipSuccess;
+    ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev_mid) == hipSuccess &&
+         hipEventCreate(&b->ev1) == hipSuccess;
+    if (!ok) {
+        set_err(nullptr, "fd_batch_create: device resource allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        fd_batch_destroy(b);
+        return nullptr;
+    }
+    b->use_graph = getenv("FD_NO_GRAPH") == nullptr;
+    return b;
+}
+
+void fd_batch_destroy(fd_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        if (c && c->wait_event == b->ev1) {
+            if (c->wait_stream) (void)hipStreamSynchronize(c->wait_stream);
+            c->wait_event = nullptr; c->wait_stream = nullptr;
+        }
+        if (c && c->tev0 == b->ev0) { c->tev0 = c->ev0; c->tev_mid = c->ev_mid; c->tev1 = c->ev1; }
+    }
+    if (b->exec) (void)hipGraphExecDestroy(b->exec);
+    if (b->d_slots) (void)hipFree(b->d_slots);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    delete b;
+}
+
+const char *fd_batch_last_error(const fd_batch *b) { return b ? b->err : g_err; }
+
+int fd_batch_set_points_dev(fd_batch *b, const float *const *d_rest_xyz, const float *const *d_delta_xyz, int M)
+{
+    if (!b || !d_rest_xyz || !d_delta_xyz) return FD_E_INVALID;
+    if (M <= 0 || M + 4 > kMaxOrder) { batch_err(b, "fd_batch_set_points_dev: M = %d outside 1..%d", M, kMaxOrder - 4); return FD_E_INVALID; }
+    for (int i = 0; i < b->n; ++i)
+        if (!d_rest_xyz[i] || !d_delta_xyz[i]) { batch_err(b, "fd_batch_set_points_dev: null array for context %d", i); return FD_E_INVALID; }
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        int rc = use_device(c);
+        if (!rc) rc = ensure_model_capacity(c, M);
+        if (rc) { batch_err(b, "context %d: %s", i, c->err); return rc; }
+        c->M = M;
+        c->points_set = true;
+        c->built = false;
+        c->build_pending = false;
+        b->src.rest[i] = d_rest_xyz[i];
+        b->src.delta[i] = d_delta_xyz[i];
+    }
+    b->have_src = true;
+    return FD_OK;
+}
+
+int fd_batch_build_async(fd_batch *b, void *hip_stream)
+{
+    if (!b) return FD_E_INVALID;
+    fd_ctx *c0 = b->ctxs[0];
+    int rc = use_device(c0);
+    if (rc) { batch_err(b, "%s", c0->err); return rc; }
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c0->stream;
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        if (!c->points_set) { batch_err(b, "fd_batch_build: context %d has no control points", i); return FD_E_INVALID; }
+        if (c->M != c0->M || c->kind != c0->kind || c->term != c0->term || c->nparams != c0->nparams ||
+            memcmp(c->params, c0->params, sizeof(c->params)) != 0) {
+            batch_err(b, "fd_batch_build: context %d differs from context 0 in M, kernel, parameters or term", i);
+            return FD_E_INVALID;
+        }
+    }
+    const int npad = round_up(order_of(c0), 32);
+    bool table_stale = false;
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        const bool grew = npad > c->cap_npad;
+        if ((rc = ensure_solver_capacity(c, npad)) || (rc = sync_slot(c))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
+        if (grew) {
+            const size_t cols = (size_t)c->cap_npad + kRhsCols + 16;
+            hipError_t e = hipMemsetAsync(c->d_A, 0, sizeof(double) * (size_t)c->cap_npad * cols, stream);
+            if (e != hipSuccess) { batch_err(b, "hipMemsetAsync failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+        }
+        if (b->gens[i] != c->alloc_gen) table_stale = true;
+    }
+    if (table_stale) {
+        BatchSlot tab[kMaxBatch];
+        for (int i = 0; i < b->n; ++i) { tab[i] = b->ctxs[i]->h_slot; b->gens[i] = b->ctxs[i]->alloc_gen; }
+        // buffers only move through hipFree, which has drained the device: nobody reads the old table
+        hipError_t e = hipMemcpy(b->d_slots, tab, sizeof(BatchSlot) * (size_t)b->n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { batch_err(b, "slot table upload failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    }
+    BuildBuffers bb;
+    fill_build_buffers(c0, bb);
+    bb.d_slots = b->d_slots;
+    bb.nbatch = b->n;
+
+    fd_batch::Key key{};
+    key.M = c0->M; key.kind = c0->kind; key.term = c0->term; key.nparams = c0->nparams;
+    memcpy(key.params, c0->params, sizeof(key.params));
+    if (b->use_graph && (!b->exec || memcmp(&key, &b->key, sizeof(key)) != 0)) {
+        if (b->exec) { (void)hipGraphExecDestroy(b->exec); b->exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            hipError_t e2 = launch_build(bb, stream, nullptr);
+            e = hipStreamEndCapture(stream, &graph);
+            if (e == hipSuccess && e2 != hipSuccess) e = e2;
+        }
+        if (e == hipSuccess && graph) e = hipGraphInstantiate(&b->exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { (void)hipGetLastError(); b->exec = nullptr; b->use_graph = false; }
+        else b->key = key;
+    }
+#define FD_BHIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) { batch_err(b, "%s failed: %s", #call, hipGetErrorString(e_)); return FD_E_DEVICE; } \
+    } while (0)
+    FD_BHIP(hipEventRecord(b->ev0, stream));
+    // the control points are kernel arguments (they change every call), so k_prepare stays
+    // outside the captured graph
+    FD_BHIP(launch_prepare(bb, stream, b->have_src ? &b->src : nullptr));
+    b->have_src = false;
+    if (b->use_graph && b->exec) {
+        FD_BHIP(hipEventRecord(b->ev_mid, stream));
+        FD_BHIP(hipGraphLaunch(b->exec, stream));
+    } else {
+        FD_BHIP(launch_build(bb, stream, b->ev_mid));
+    }
+    FD_BHIP(hipEventRecord(b->ev1, stream));
+#undef FD_BHIP
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        c->wait_event = b->ev1; c->wait_stream = stream;
+        c->tev0 = b->ev0; c->tev_mid = b->ev_mid; c->tev1 = b->ev1;
+        c->build_pending = true;
+        c->built = false;
+        c->have_report = false;
+    }
+    return FD_OK;
+}
+
+int fd_batch_build_result(fd_batch *b, fd_report *reports)
+{
+    if (!b) return FD_E_INVALID;
+    int first = FD_OK;
+    for (int i = 0; i < b->n; ++i) {
+        const int rc = fd_build_result(b->ctxs[i], reports ? &reports[i] : nullptr);
+        if (rc && !first) { first = rc; batch_err(b, "context %d: %s", i, b->ctxs[i]->err); }
+    }
+    return first;
+}
+
+int fd_batch_size(const fd_batch *b) { return b ? b->n : 0; }
 
 }  // extern "C"

@@ -640,6 +640,9 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
     // variant = lanes * 100 + source * 10 + log2(V):  lanes 0 scalar / 1 packed,
     // source 0 scalar-loaded records / 1 LDS-staged records.  0 = the default below.
     int variant = a.variant > 0 ? a.variant : kDefaultVariant;
+    // thin-plate with at least four centre tiles: d2 on the matrix pipe (variant 200) is the
+    // faster kernel (C2 68 vs 80 us, C3 429 vs 540 us); below that its per-group set-up shows
+    if (a.variant <= 0 && KIND == FD_KERNEL_THIN_PLATE && a.tiles != nullptr && a.Mpad >= 64) variant = 200;
     if (variant == 200) {
         if constexpr (KIND == FD_KERNEL_THIN_PLATE) {
             constexpr int TV = 4;

@@ -75,26 +75,43 @@ constexpr int kPanelThreads = 1024;   // one workgroup factors a panel
 constexpr int kMaxOrder = 5632;       // back-substitution keeps Y (3 x order fp64) in LDS
 constexpr int kRhsCols = 16;          // 3 right-hand sides padded to one MFMA tile
 
+constexpr int kMaxBatch = 32;         // models one launch chain may build together
+
+// Device-side table entry: the buffers of one model.  Every build kernel indexes the table
+// with blockIdx.z, so a batch of contexts is assembled and factorised by one launch chain.
+struct BatchSlot {
+    float *rest, *delta;              // M x 3, the context's own copy of the control points
+    double *centres;                  // M x 3
+    double *radii;                    // M
+    double *A;                        // lda x (ncols + 16): 16 zero columns absorb block overrun
+    double *X;                        // 3 x npad solution, column per right-hand side
+    double *W;                        // (M+4) x 3
+    int *ipiv;                        // npad
+    int *moves;                       // [0] = count, then (dst, src) pairs, per panel
+    Rec32 *rec32;
+    Rec64 *rec64;
+    MfmaTile *tiles;                  // Mpad / 16 tiles (thin-plate only)
+    DevModel *model;
+};
+
+// Caller-owned device arrays of control points, one pair per model of a batch (kernel argument).
+struct PointSrc {
+    const float *rest[kMaxBatch];
+    const float *delta[kMaxBatch];
+};
+
+// Dimensions and parameters shared by all models of a launch chain + where their slots are.
 struct BuildBuffers {
     int M, T, n, npad, lda, ncols;    // A is lda x ncols column-major; cols npad.. hold the RHS
     int kind, term;
     double lambda;
     double gauss_R, qnn_q, qnn_z;
-    const float *d_rest, *d_delta;    // M x 3
-    double *d_centres;                // M x 3
-    double *d_radii;                  // M
-    double *d_A;                      // lda x (ncols + 16): 16 zero columns absorb block overrun
-    double *d_X;                      // 3 x npad solution, column per right-hand side
-    int *d_ipiv;                      // npad
-    int *d_moves;                     // [0] = count, then (dst, src) pairs, per panel
-    double *d_W;                      // (M+4) x 3
-    Rec32 *d_rec32;
-    Rec64 *d_rec64;
-    MfmaTile *d_tiles;                // Mpad / 16 tiles (thin-plate only)
     int Mpad;
-    DevModel *d_model;
+    const BatchSlot *d_slots;         // device table, nbatch entries
+    int nbatch;
 };
 
+hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
 hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream);
 hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream);

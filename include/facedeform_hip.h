@@ -170,6 +170,37 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device);
 /* Block until everything enqueued on the context's stream has finished. */
 int fd_synchronize(fd_ctx *ctx);
 
+/* ---- batched build ------------------------------------------------------------
+ * The reference cooks one node at a time: one rbfbuildmodel per cookMySop
+ * (src/SOP_FaceDeform.cpp:363).  A dense system of order 260 keeps one CU of a
+ * 256-CU device busy, and the device overlaps only two or three such launch
+ * chains.  Contexts that share M, kernel, parameters and term -- the frames of
+ * one rig, or several facedeform nodes of one cook graph -- can therefore be
+ * assembled and factorised together: one launch chain, one workgroup column per
+ * context.  Each context ends up exactly as after its own fd_build_async (the
+ * kernels and their arithmetic are the same; results are bit-identical) and is
+ * evaluated with the usual fd_deform* calls; those wait for the batch where
+ * they run on another stream.  Destroy the batch before its contexts. */
+typedef struct fd_batch fd_batch;
+#define FD_MAX_BATCH 32
+fd_batch *fd_batch_create(fd_ctx *const *ctxs, int n);          /* 1..FD_MAX_BATCH contexts of one device */
+void fd_batch_destroy(fd_batch *batch);
+int fd_batch_size(const fd_batch *batch);
+const char *fd_batch_last_error(const fd_batch *batch);
+/* Control points of all contexts from caller-owned DEVICE arrays, one pointer
+ * pair per context (host arrays of n device pointers).  No copy is enqueued:
+ * the next fd_batch_build_async reads them in place, so they must stay valid
+ * and unchanged until that build has executed.  Optional -- contexts whose
+ * points were set with fd_set_points(_dev) are built from their own copies. */
+int fd_batch_set_points_dev(fd_batch *batch, const float *const *d_rest_xyz,
+                            const float *const *d_delta_xyz, int M);
+/* Enqueue the build of every context on hip_stream (NULL: the stream of
+ * context 0).  FD_E_INVALID if the contexts differ in M, kernel or term. */
+int fd_batch_build_async(fd_batch *batch, void *hip_stream);
+/* Wait and report per context (reports may be NULL, else n entries).  Returns
+ * the first non-zero per-context code. */
+int fd_batch_build_result(fd_batch *batch, fd_report *reports);
+
 /* ---- host-side cook: the HDK-free mirror of cookMySop ----------------------
  * fdsop_* mirrors the SOP's parm surface (src/SOP_FaceDeform.cpp:99-137) and
  * the cook sequence (:215-489) over plain arrays standing in for GU_Detail:

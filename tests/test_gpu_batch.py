@@ -1,0 +1,141 @@
+"""GPU: the batched build (fd_batch_*) against single builds and the oracle.
+
+One launch chain factorises all contexts of a batch; the kernels and their arithmetic are the
+ones a single fd_build runs, so the bar is bit-identical weights, not a tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import parity_ratio
+from facedeform_amd import capi, synth
+from oracle import fd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _rig(M, frame, shift=0.0):
+    """Rest rig and the fp32 deltas the SOP would hand over (deformed - rest, src/SOP_FaceDeform.cpp:276-281)."""
+    rest = (synth.control_points(M, "head") + np.float32(shift)).astype(np.float32)
+    deform = (rest + synth.smooth_deltas(rest, frame)).astype(np.float32)
+    return rest, (deform - rest).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind,params,term", [
+    (capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR),
+    (capi.KERNEL_GAUSSIAN_QNN, [1.0, 5.0], capi.TERM_LINEAR),
+    (capi.KERNEL_GAUSSIAN, [0.7, 1e-3], capi.TERM_CONST),
+    (capi.KERNEL_BIHARMONIC, [], capi.TERM_ZERO),
+])
+def test_batch_equals_single_builds(hip_lib, oracle, kind, params, term):
+    M, nb = 77, 5
+    singles, batched = [], []
+    for f in range(nb):
+        rest, delta = _rig(M, f, 0.003 * f)            # different systems, not only different RHS
+        for lst in (singles, batched):
+            e = capi.Engine()
+            e.set_points(rest, delta); e.set_kernel(kind, params); e.set_term(term)
+            lst.append(e)
+    for e in singles:
+        assert e.build().terminationtype == 1
+    b = capi.Batch(batched)
+    assert len(b) == nb
+    b.build_async()
+    reps = b.build_result()
+    assert [r.terminationtype for r in reps] == [1] * nb
+    assert all(r.n == M + (4, 1, 0)[term] for r in reps)
+    for es, eb in zip(singles, batched):
+        Ws, rs = es.get_weights()
+        Wb, rb = eb.get_weights()
+        assert np.array_equal(Ws, Wb) and np.array_equal(rs, rb)
+    # and against the oracle for one of them
+    rest, delta = _rig(M, 2, 0.003 * 2)
+    table = oracle.control_table(rest, rest + delta)
+    rc, tt, W_ref, _ = oracle.build(table, kind, params, term)
+    assert rc == 0 and tt == 1
+    Wb, _ = batched[2].get_weights()
+    assert np.abs(Wb - W_ref).max() <= 1e-8 * np.abs(W_ref).max()
+    b.close()
+    for e in singles + batched:
+        e.close()
+
+
+def test_batch_points_in_place_other_stream_and_deform(hip_lib, oracle):
+    """Control points read from caller-owned device arrays; build on a stream that is not the
+    contexts' own; evaluation on each context's stream has to wait for the batch."""
+    M, nb, N = 256, 8, 30_011
+    dev = torch.device("cuda", 0)
+    P = synth.head_mesh(N)
+    d_P = torch.from_numpy(P).to(dev)
+    rest = synth.control_points(M, "head")
+    d_rest = torch.from_numpy(rest).to(dev)
+    deltas = np.stack([(rest + synth.smooth_deltas(rest, f)).astype(np.float32) - rest for f in range(nb)]).astype(np.float32)
+    d_deltas = torch.from_numpy(deltas).to(dev)
+    torch.cuda.synchronize()
+    engines = []
+    for _ in range(nb):
+        e = capi.Engine()
+        e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
+        engines.append(e)
+    b = capi.Batch(engines)
+    side = torch.cuda.Stream(device=dev)
+    outs = [torch.empty_like(d_P) for _ in range(nb)]
+    for rnd in range(2):                                     # second round replays the captured graph
+        order = list(range(nb)) if rnd == 0 else list(reversed(range(nb)))
+        b.set_points_dev([d_rest.data_ptr()] * nb, [d_deltas[f].data_ptr() for f in order], M)
+        b.build_async(side.cuda_stream)
+        for e, o in zip(engines, outs):
+            e.deform_dev(N, d_P.data_ptr(), o.data_ptr())     # on e's own stream
+        reps = b.build_result()
+        assert [r.terminationtype for r in reps] == [1] * nb
+        for e in engines:
+            e.synchronize()
+        for k, f in enumerate(order):
+            table = oracle.control_table(rest, rest + deltas[f])
+            rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+            ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P[::7])
+            out = outs[k].cpu().numpy()[::7]
+            assert parity_ratio(out, ref, P[::7], 1e-5) <= 1.0, (rnd, k)
+    # a context of the batch can still be rebuilt on its own: the batch mirrored its points
+    e = engines[3]
+    W_before, _ = e.get_weights()
+    assert e.build().terminationtype == 1
+    W_after, _ = e.get_weights()
+    assert np.array_equal(W_before, W_after)
+    b.close()
+    for e in engines:
+        e.close()
+
+
+def test_batch_rejects_mismatched_contexts(hip_lib):
+    rest, delta = _rig(40, 0)
+    a, c = capi.Engine(), capi.Engine()
+    a.set_points(rest, delta); a.set_kernel(capi.KERNEL_THIN_PLATE); a.set_term(0)
+    c.set_points(rest[:30], delta[:30]); c.set_kernel(capi.KERNEL_THIN_PLATE); c.set_term(0)
+    b = capi.Batch([a, c])
+    with pytest.raises(capi.FdError) as ei:
+        b.build_async()
+    assert ei.value.code == capi.FD_E_INVALID and "differs" in str(ei.value)
+    c.set_points(rest, delta); c.set_term(capi.TERM_CONST)
+    with pytest.raises(capi.FdError):
+        b.build_async()
+    with pytest.raises(capi.FdError):
+        capi.Batch([a, a])
+    b.close(); a.close(); c.close()
+
+
+def test_batch_reports_singular_member(hip_lib):
+    """One coincident-point rig in the batch: that context reports -5, the others solve."""
+    rest, delta = _rig(48, 1)
+    bad = rest.copy(); bad[7] = bad[3]
+    es = []
+    for r in (rest, bad, rest):
+        e = capi.Engine()
+        e.set_points(r, delta); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+        es.append(e)
+    b = capi.Batch(es)
+    b.build_async()
+    reps = b.build_result(check=False)
+    assert [r.terminationtype for r in reps] == [1, -5, 1]
+    b.close()
+    for e in es:
+        e.close()
