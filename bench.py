@@ -57,8 +57,14 @@ def parse_args():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--variant", type=int, default=0, help="evaluation kernel variant (0 = auto)")
     ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
-    ap.add_argument("--inflight", type=int, default=16,
-                    help="independent frames in flight per GPU (one engine context + stream each)")
+    ap.add_argument("--inflight", type=int, default=32,
+                    help="frames per batched build (one engine context each; at most 32)")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="groups of frames in flight per GPU (one stream + one fd_batch each)")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="bracket every k-th evaluation with HIP events (each pair costs ~5 us of stream time)")
+    ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
+                    help="evaluations on one stream for all lanes (default) or on each lane's build stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=float, default=3.0e8,
                     help="bound on (vertex, centre) pairs in the CPU baseline sample")
@@ -245,43 +251,77 @@ def main():
     d_deltas = torch.from_numpy(deltas_host).to(dev)
 
     precision = capi.EVAL_FP64 if args.precision == "fp64" else capi.EVAL_FP32
-    # Independent frames overlap inside one GPU: each frame in flight has its own engine
-    # context, stream and output buffers (the mesh and the rest rig are shared, read-only).
+    # Independent frames are cooked in groups: a lane holds `inflight` engine contexts (one per
+    # frame), one stream and one fd_batch.  Per group the lane enqueues ONE batched build (the
+    # assemble + LU + back-substitution launch chain with one workgroup column per frame) on its
+    # stream; the evaluations of all lanes go, one per frame, to a single evaluation stream that
+    # waits for the group's build.  So the build chains (a few CUs each) run ahead and overlap
+    # the evaluations (the whole device), while evaluations never compete with each other.
+    # Why batches: a lone order-260 build keeps one CU busy through ~25 dependent launches, and
+    # the device was measured to overlap only two or three such chains however many HIP streams
+    # they come from (tools/inflight_sweep.py; DESIGN.md "Batched build").
     # Streams of our own: torch's default stream has handle 0, which fd_set_stream reads as
     # "use the context's stream", and HIP events only time the stream they are recorded on.
-    n_inflight = max(1, args.inflight)
-    # Every frame in flight is self-contained: its own engine context, stream and output
-    # buffers; build and evaluation of one frame are ordered by that stream alone.  (A single
-    # evaluation stream fed by build streams through events was measured slower: 2.8 vs 6.2
-    # Gverts/s -- the cross-queue waits leave bubbles.)
+    B = max(1, min(args.inflight, capi.MAX_BATCH))
+    n_lanes = max(1, args.lanes)
+    eval_stream = torch.cuda.Stream(device=dev)
     lanes = []
-    for _ in range(n_inflight):
-        eng = capi.Engine(device=local_rank, precision=precision, variant=args.variant)
+    for _ in range(n_lanes):
         stream = torch.cuda.Stream(device=dev)
-        eng.set_stream(stream.cuda_stream)
-        eng.set_kernel(capi.KERNEL_THIN_PLATE)
-        eng.set_term(capi.TERM_LINEAR)
-        lanes.append({"eng": eng, "stream": stream, "out": torch.empty_like(d_P),
-                      "fall": torch.zeros(n_verts, device=dev, dtype=torch.float32)})
+        engines = []
+        for _ in range(B):
+            eng = capi.Engine(device=local_rank, precision=precision, variant=args.variant)
+            eng.set_stream(stream.cuda_stream)
+            eng.set_kernel(capi.KERNEL_THIN_PLATE)
+            eng.set_term(capi.TERM_LINEAR)
+            engines.append(eng)
+        lanes.append({"engines": engines, "stream": stream, "batches": {B: capi.Batch(engines)},
+                      "evals_done": torch.cuda.Event(),
+                      "out": [torch.empty_like(d_P) for _ in range(B)],
+                      "fall": [torch.zeros(n_verts, device=dev, dtype=torch.float32) for _ in range(B)]})
     torch.cuda.synchronize()
 
     delta_stride = n_ctrl * 3 * 4
+    ev_idx_set = set()
 
-    def step(i, ev=None):
-        ln = lanes[i % n_inflight]
-        ln["used"] = True
-        eng, stream = ln["eng"], ln["stream"]
-        frame = (i * world + rank) % N_FRAMES
-        eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr() + frame * delta_stride, n_ctrl)
+    def group(g, first, count, ev=None):
+        """Cook steps first .. first+count-1 (count <= B frames) on lane g % n_lanes."""
+        ln = lanes[g % n_lanes]
+        ln["used"] = max(ln.get("used", 0), count)
+        stream = ln["stream"]
+        if count not in ln["batches"]:
+            ln["batches"][count] = capi.Batch(ln["engines"][:count])
+        batch = ln["batches"][count]
+        frames = [((first + k) * world + rank) % N_FRAMES for k in range(count)]
+        # the lane's previous group must have been evaluated before its models are overwritten
+        stream.wait_event(ln["evals_done"])
+        batch.set_points_dev([d_rest.data_ptr()] * count,
+                             [d_deltas.data_ptr() + f * delta_stride for f in frames], n_ctrl)
         if ev:
-            ev[0].record(stream)
-        eng.build_async()
+            ev[first][0].record(stream)
+        batch.build_async(stream.cuda_stream)
         if ev:
-            ev[1].record(stream)
-            ev[2].record(stream)
-        eng.deform_dev(n_verts, d_P.data_ptr(), ln["out"].data_ptr(), d_falloff=ln["fall"].data_ptr())
-        if ev:
-            ev[3].record(stream)
+            ev[first][1].record(stream)
+        es = eval_stream if args.eval_stream == "shared" else stream
+        for k in range(count):
+            timed = ev is not None and (first + k) in ev_idx_set
+            if timed:
+                ev[first + k][2].record(es)
+            # fd_deform_dev_stream makes es wait for the batch that builds this model
+            ln["engines"][k].deform_dev_stream(es.cuda_stream, n_verts, d_P.data_ptr(),
+                                               ln["out"][k].data_ptr(), d_falloff=ln["fall"][k].data_ptr())
+            if timed:
+                ev[first + k][3].record(es)
+        ln["evals_done"].record(es)
+
+    def run_steps(nsteps, ev=None, g0=0):
+        g, i = g0, 0
+        while i < nsteps:
+            count = min(B, nsteps - i)
+            group(g, i, count, ev)
+            g += 1
+            i += count
+        return g
 
     def sync_all():
         torch.cuda.synchronize()
@@ -291,33 +331,45 @@ def main():
 
     def check_builds():
         for ln in lanes:
-            if not ln.get("used"):
-                continue
-            rep = ln["eng"].build_result()
-            if rep.terminationtype != 1:
-                raise SystemExit(f"build failed: terminationtype {rep.terminationtype}")
+            for eng in ln["engines"][: ln.get("used", 0)]:
+                rep = eng.build_result()
+                if rep.terminationtype != 1:
+                    raise SystemExit(f"build failed: terminationtype {rep.terminationtype}")
 
-    for i in range(args.warmup):
-        step(i)
+    g_next = run_steps(args.warmup)
+    if args.warmup < B * n_lanes:                      # touch every lane and capture its graph once
+        g_next = run_steps(B * n_lanes, g0=g_next)
+    if args.steps % B:                                 # the ragged last group has its own batch object
+        run_steps(args.steps % B, g0=args.steps // B)
     check_builds()
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    # evaluations that get an event pair: every k-th step, never the first of a group (its pair
+    # would also contain the wait for the group's build)
+    ev_idx = [i for i in range(args.steps) if i % B != 0 and i % max(1, args.event_every) == 1 % max(1, args.event_every)]
+    if not ev_idx:
+        ev_idx = list(range(args.steps))
+    ev_idx_set.update(ev_idx)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, events[i])
+    run_steps(args.steps, events, g0=0)
     sync_all()
     elapsed = time.perf_counter() - t0
     check_builds()
 
     # one cook at a time, host-synchronised: the latency a single interactive cook sees
+    # (unbatched fd_set_points_dev + fd_build_async + fd_deform_dev on one context)
     lat = []
+    ln0 = lanes[0]
     for i in range(10):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        step(i)
-        lanes[i % n_inflight]["eng"].build_result()
-        lanes[i % n_inflight]["stream"].synchronize()
+        eng = ln0["engines"][0]
+        eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr() + (i % N_FRAMES) * delta_stride, n_ctrl)
+        eng.build_async()
+        eng.deform_dev(n_verts, d_P.data_ptr(), ln0["out"][0].data_ptr(), d_falloff=ln0["fall"][0].data_ptr())
+        eng.build_result()
+        eng.synchronize()
         lat.append(time.perf_counter() - t1)
     latency_ms = float(np.median(lat)) * 1e3
 
@@ -326,9 +378,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    build_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    eval_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
+    # a batched build is timed once per group (events on the group's first step)
+    group_firsts = list(range(0, args.steps, B))
+    build_group_ms = float(np.mean([events[i][0].elapsed_time(events[i][1]) for i in group_firsts]))
+    build_ms = build_group_ms / min(B, args.steps)
+    eval_ms = float(np.mean([events[i][2].elapsed_time(events[i][3]) for i in ev_idx]))
 
+    if rank == 0 and os.environ.get("FD_BENCH_GAPS") and args.eval_stream == "shared":
+        # idle time on the evaluation stream between consecutive evaluations (diagnostic)
+        pairs = [(a, b) for a, b in zip(ev_idx[:-1], ev_idx[1:]) if a // B == b // B]
+        gaps = np.array([(events[a][3].elapsed_time(events[b][2]) * 1e3 - (b - a - 1) * eval_ms * 1e3) / (b - a)
+                         for a, b in pairs])
+        print(f"[gaps us] idle per evaluation within a group: mean {gaps.mean():.1f} median {np.median(gaps):.1f} "
+              f"max {gaps.max():.1f}", file=sys.stderr, flush=True)
+    if rank == 0 and os.environ.get("FD_BENCH_GAPS"):
+        base = events[0][0]
+        for i in range(0, args.steps, B)[:10]:
+            print(f"[timeline ms] group {i // B}: build {base.elapsed_time(events[i][0]):8.3f} -> "
+                  f"{base.elapsed_time(events[i][1]):8.3f}", file=sys.stderr, flush=True)
     if rank == 0:
         total_verts = world * args.steps * n_verts
         flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_verts
@@ -358,9 +425,9 @@ def main():
                 "workload": f"{desc}, thin-plate kernel, linear term, {args.precision} evaluation, "
                             "fp64 dense solve rebuilt every step (assemble + LU + evaluate), one frame per step",
                 "n_verts": n_verts, "n_ctrl": n_ctrl,
-                "frames_in_flight_per_gpu": n_inflight,
-                "parallelism": f"independent frames: {world} GPU(s) x {n_inflight} in flight (one stream each), "
-                               "no collective",
+                "frames_per_batched_build": B, "lanes_per_gpu": n_lanes,
+                "parallelism": f"independent frames: {world} GPU(s) x {n_lanes} lanes x {B} frames per batched "
+                               "build (one build stream per lane, one evaluation stream), no collective",
             },
             "roofline": {
                 # the evaluation kernel is compute-bound at this M (intensity ~182 flop/B vs ridge ~20):
@@ -374,7 +441,8 @@ def main():
                 "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_launch": BYTES_PER_VERTEX * n_verts},
             },
-            "phases_ms": {"build": build_ms, "evaluate": eval_ms, "single_cook_latency": latency_ms},
+            "phases_ms": {"build_per_frame_batched": build_ms, "build_batch": build_group_ms,
+                          "evaluate": eval_ms, "single_cook_latency": latency_ms},
             "eval_only_mverts_s": n_verts / (eval_ms * 1e-3) / 1e6,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -382,9 +450,13 @@ def main():
                                                 (rest_host + deltas_host[0]).astype(np.float32), args.cpu_pairs)
         print(json.dumps(line), flush=True)
 
+    torch.cuda.synchronize()
     for ln in lanes:
-        ln["eng"].set_stream(None)
-        ln["eng"].close()
+        for batch in ln["batches"].values():
+            batch.close()
+        for eng in ln["engines"]:
+            eng.set_stream(None)
+            eng.close()
     if world > 1:
         dist.destroy_process_group()
 

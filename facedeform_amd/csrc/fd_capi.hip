@@ -10,10 +10,11 @@
 
 using namespace fd;
 
+struct fd_batch;
 struct fd_ctx {
     int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;   // created on first use when the caller sets no stream
+    hipStream_t stream_ = nullptr;          // fd_set_stream; nullptr: own_stream
     int eval_precision = FD_EVAL_FP32;
     int eval_variant = 0;
 
@@ -46,6 +47,7 @@ struct fd_ctx {
     // set while the model comes from a batched build on another stream (fd_batch_build_async)
     hipEvent_t wait_event = nullptr;
     hipStream_t wait_stream = nullptr;
+    struct fd_batch *wait_batch = nullptr;
     hipEvent_t tev0 = nullptr, tev_mid = nullptr, tev1 = nullptr;   // events the report's timings come from
     ModelHeader *h_header = nullptr;  // pinned, for device-side export
 
@@ -68,6 +70,25 @@ struct fd_ctx {
     char err[512] = {0};
 };
 
+struct fd_batch {
+    int n = 0;
+    int device = 0;
+    fd_ctx *ctxs[kMaxBatch] = {};
+    uint64_t gens[kMaxBatch] = {};
+    BatchSlot *d_slots = nullptr;
+    PointSrc src{};
+    bool have_src = false;
+    hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool use_graph = true;
+    struct Key { int M, kind, term, nparams; double params[4]; } key{};
+    // a stream that already waits for the current build (set by the first evaluation that
+    // needed it): the other contexts' evaluations on that stream need no wait of their own
+    hipStream_t waited_stream = nullptr;
+    char err[512] = {0};
+};
+
+
 static thread_local char g_err[512] = {0};
 
 static void set_err(fd_ctx *ctx, const char *fmt, ...)
@@ -77,6 +98,20 @@ static void set_err(fd_ctx *ctx, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(dst, 512, fmt, ap);
     va_end(ap);
+}
+
+// The stream work is enqueued on: the caller's (fd_set_stream) or the context's own, which is
+// created on first use -- a process with many contexts on caller streams should not spend a
+// hardware queue per context (HIP maps streams onto GPU_MAX_HW_QUEUES queues round-robin, and
+// two streams on one queue serialise).
+static hipStream_t cur_stream(fd_ctx *ctx)
+{
+    if (ctx->stream_) return ctx->stream_;
+    if (!ctx->own_stream && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->own_stream = nullptr;     // falls back to the null stream
+    }
+    return ctx->own_stream;
 }
 
 #define FD_HIP(ctx, call)                                                               \
@@ -164,7 +199,10 @@ static int sync_slot(fd_ctx *ctx)
 // a model that a batched build is producing on another stream: make `s` wait for it
 static int order_after_batch(fd_ctx *ctx, hipStream_t s)
 {
-    if (ctx->wait_event && s != ctx->wait_stream) FD_HIP(ctx, hipStreamWaitEvent(s, ctx->wait_event, 0));
+    if (!ctx->wait_event || s == ctx->wait_stream) return FD_OK;
+    if (ctx->wait_batch && ctx->wait_batch->waited_stream == s) return FD_OK;
+    FD_HIP(ctx, hipStreamWaitEvent(s, ctx->wait_event, 0));
+    if (ctx->wait_batch) ctx->wait_batch->waited_stream = s;
     return FD_OK;
 }
 
@@ -209,7 +247,7 @@ fd_ctx *fd_create(const fd_config *cfg)
         delete ctx;
         return nullptr;
     }
-    bool ok = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = true;
     ok = ok && hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev_mid) == hipSuccess &&
          hipEventCreate(&ctx->ev1) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_model, sizeof(DevModel)) == hipSuccess;
@@ -223,7 +261,6 @@ fd_ctx *fd_create(const fd_config *cfg)
         fd_destroy(ctx);
         return nullptr;
     }
-    ctx->stream = ctx->own_stream;
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
     ctx->use_graph = getenv("FD_NO_GRAPH") == nullptr;
     return ctx;
@@ -233,7 +270,7 @@ void fd_destroy(fd_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_ || ctx->own_stream) (void)hipStreamSynchronize(cur_stream(ctx));
     void *bufs[] = {ctx->d_rest, ctx->d_delta, ctx->d_centres, ctx->d_radii, ctx->d_W, ctx->d_A,
                     ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_model, ctx->d_slot,
                     ctx->d_P, ctx->d_dist2, ctx->d_fall, ctx->d_tu, ctx->d_tv, ctx->d_nrm};
@@ -253,8 +290,8 @@ int fd_set_stream(fd_ctx *ctx, void *hip_stream)
     if (!ctx) return FD_E_INVALID;
     int rc = use_device(ctx);
     if (rc) return rc;
-    FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (ctx->stream_ || ctx->own_stream) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+    ctx->stream_ = (hipStream_t)hip_stream;
     return FD_OK;
 }
 
@@ -263,7 +300,7 @@ int fd_synchronize(fd_ctx *ctx)
     if (!ctx) return FD_E_INVALID;
     int rc = use_device(ctx);
     if (rc) return rc;
-    FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     return FD_OK;
 }
 
@@ -276,9 +313,9 @@ static int set_points_common(fd_ctx *ctx, const float *rest, const float *delta,
     if (rc) return rc;
     if ((rc = ensure_model_capacity(ctx, M))) return rc;
     const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    FD_HIP(ctx, hipMemcpyAsync(ctx->d_rest, rest, sizeof(float) * 3 * (size_t)M, k, ctx->stream));
-    FD_HIP(ctx, hipMemcpyAsync(ctx->d_delta, delta, sizeof(float) * 3 * (size_t)M, k, ctx->stream));
-    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller may reuse its arrays
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_rest, rest, sizeof(float) * 3 * (size_t)M, k, cur_stream(ctx)));
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_delta, delta, sizeof(float) * 3 * (size_t)M, k, cur_stream(ctx)));
+    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));  // caller may reuse its arrays
     ctx->M = M;
     ctx->points_set = true;
     ctx->built = false;
@@ -372,7 +409,7 @@ int fd_build_async(fd_ctx *ctx)
     if (grew) {
         // the 16 overrun columns past the RHS block must read as zero forever
         const size_t cols = (size_t)ctx->cap_npad + kRhsCols + 16;
-        FD_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, sizeof(double) * (size_t)ctx->cap_npad * cols, ctx->stream));
+        FD_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, sizeof(double) * (size_t)ctx->cap_npad * cols, cur_stream(ctx)));
     }
     fd_ctx::GraphKey key{};
     key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term; key.nparams = ctx->nparams;
@@ -381,11 +418,11 @@ int fd_build_async(fd_ctx *ctx)
     if (ctx->use_graph && (!ctx->build_exec || memcmp(&key, &ctx->graph_key, sizeof(key)) != 0)) {
         if (ctx->build_exec) { (void)hipGraphExecDestroy(ctx->build_exec); ctx->build_exec = nullptr; }
         hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        hipError_t e = hipStreamBeginCapture(cur_stream(ctx), hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            hipError_t e1 = launch_prepare(b, ctx->stream, nullptr);
-            hipError_t e2 = launch_build(b, ctx->stream, nullptr);
-            e = hipStreamEndCapture(ctx->stream, &graph);
+            hipError_t e1 = launch_prepare(b, cur_stream(ctx), nullptr);
+            hipError_t e2 = launch_build(b, cur_stream(ctx), nullptr);
+            e = hipStreamEndCapture(cur_stream(ctx), &graph);
             if (e == hipSuccess && (e1 != hipSuccess || e2 != hipSuccess)) e = e1 != hipSuccess ? e1 : e2;
         }
         if (e == hipSuccess && graph) e = hipGraphInstantiate(&ctx->build_exec, graph, nullptr, nullptr, 0);
@@ -398,16 +435,16 @@ int fd_build_async(fd_ctx *ctx)
             ctx->graph_key = key;
         }
     }
-    FD_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    FD_HIP(ctx, hipEventRecord(ctx->ev0, cur_stream(ctx)));
     if (ctx->use_graph && ctx->build_exec) {
-        FD_HIP(ctx, hipEventRecord(ctx->ev_mid, ctx->stream));   // phases are not split inside a graph
-        FD_HIP(ctx, hipGraphLaunch(ctx->build_exec, ctx->stream));
+        FD_HIP(ctx, hipEventRecord(ctx->ev_mid, cur_stream(ctx)));   // phases are not split inside a graph
+        FD_HIP(ctx, hipGraphLaunch(ctx->build_exec, cur_stream(ctx)));
     } else {
-        FD_HIP(ctx, launch_prepare(b, ctx->stream, nullptr));
-        FD_HIP(ctx, launch_build(b, ctx->stream, ctx->ev_mid));
+        FD_HIP(ctx, launch_prepare(b, cur_stream(ctx), nullptr));
+        FD_HIP(ctx, launch_build(b, cur_stream(ctx), ctx->ev_mid));
     }
-    FD_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->wait_event = nullptr; ctx->wait_stream = nullptr;
+    FD_HIP(ctx, hipEventRecord(ctx->ev1, cur_stream(ctx)));
+    ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
     ctx->build_pending = true;
     ctx->built = false;
@@ -421,10 +458,10 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
     int rc = use_device(ctx);
     if (rc) return rc;
     if (ctx->build_pending) {
-        if ((rc = order_after_batch(ctx, ctx->stream))) return rc;
-        FD_HIP(ctx, hipMemcpyAsync(ctx->h_model, ctx->d_model, sizeof(DevModel), hipMemcpyDeviceToHost, ctx->stream));
-        FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->wait_event = nullptr; ctx->wait_stream = nullptr;   // the batched build it named is complete
+        if ((rc = order_after_batch(ctx, cur_stream(ctx)))) return rc;
+        FD_HIP(ctx, hipMemcpyAsync(ctx->h_model, ctx->d_model, sizeof(DevModel), hipMemcpyDeviceToHost, cur_stream(ctx)));
+        FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+        ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;   // the batched build it named is complete
         fd_report r{};
         r.terminationtype = ctx->h_model->terminationtype;
         r.iterationscount = ctx->h_model->iterations;
@@ -464,7 +501,7 @@ int fd_deform_dev(fd_ctx *ctx, int64_t N, const float *d_P_in, float *d_P_out, c
                   float radius2, float falloffrate)
 {
     if (!ctx) return FD_E_INVALID;
-    return fd_deform_dev_stream(ctx, ctx->stream, N, d_P_in, d_P_out, d_dist2, d_falloff_out, d_tu, d_tv,
+    return fd_deform_dev_stream(ctx, cur_stream(ctx), N, d_P_in, d_P_out, d_dist2, d_falloff_out, d_tu, d_tv,
                                 d_nrm, radius2, falloffrate);
 }
 
@@ -473,7 +510,7 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
                          const float *d_tv, const float *d_nrm, float radius2, float falloffrate)
 {
     if (!ctx) return FD_E_INVALID;
-    hipStream_t launch_stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t launch_stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(ctx);
     if (N < 0 || (N > 0 && (!d_P_in || !d_P_out))) { set_err(ctx, "fd_deform: bad N / P pointers"); return FD_E_INVALID; }
     const int ntan = (d_tu != nullptr) + (d_tv != nullptr) + (d_nrm != nullptr);
     if (ntan != 0 && ntan != 3) { set_err(ctx, "fd_deform: tu, tv, nrm must be all set or all NULL"); return FD_E_INVALID; }
@@ -524,7 +561,7 @@ int fd_deform(fd_ctx *ctx, int64_t N, const float *P_in, float *P_out, const flo
         if ((rc = dev_alloc(ctx, &ctx->d_tv, (size_t)ctx->cap_N * 3))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_nrm, (size_t)ctx->cap_N * 3))) return rc;
     }
-    hipStream_t s = ctx->stream;
+    hipStream_t s = cur_stream(ctx);
     const size_t b3 = sizeof(float) * 3 * (size_t)N, b1 = sizeof(float) * (size_t)N;
     FD_HIP(ctx, hipMemcpyAsync(ctx->d_P, P_in, b3, hipMemcpyHostToDevice, s));
     if (dist2) FD_HIP(ctx, hipMemcpyAsync(ctx->d_dist2, dist2, b1, hipMemcpyHostToDevice, s));
@@ -560,9 +597,9 @@ int fd_get_weights(fd_ctx *ctx, double *W, double *radii)
     int rc = use_device(ctx);
     if (rc) return rc;
     if ((rc = require_built(ctx, "fd_get_weights"))) return rc;
-    FD_HIP(ctx, hipMemcpyAsync(W, ctx->d_W, sizeof(double) * 3 * (size_t)(ctx->M + 4), hipMemcpyDeviceToHost, ctx->stream));
-    if (radii) FD_HIP(ctx, hipMemcpyAsync(radii, ctx->d_radii, sizeof(double) * (size_t)ctx->M, hipMemcpyDeviceToHost, ctx->stream));
-    FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(W, ctx->d_W, sizeof(double) * 3 * (size_t)(ctx->M + 4), hipMemcpyDeviceToHost, cur_stream(ctx)));
+    if (radii) FD_HIP(ctx, hipMemcpyAsync(radii, ctx->d_radii, sizeof(double) * (size_t)ctx->M, hipMemcpyDeviceToHost, cur_stream(ctx)));
+    FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     return FD_OK;
 }
 
@@ -582,7 +619,7 @@ int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device)
     const int M = ctx->M;
     if (capacity < model_bytes_for(M)) { set_err(ctx, "fd_export_model: buffer too small"); return FD_E_INVALID; }
     // the pinned header may still be the source of an earlier in-flight copy
-    FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     ModelHeader *h = ctx->h_header;
     memset(h, 0, sizeof(*h));
     h->magic = kModelMagic;
@@ -592,14 +629,14 @@ int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device)
     char *p = (char *)buf;
     const hipMemcpyKind kh = on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
     const hipMemcpyKind kd = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    FD_HIP(ctx, hipMemcpyAsync(p, h, sizeof(*h), kh, ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(p, h, sizeof(*h), kh, cur_stream(ctx)));
     p += sizeof(*h);
-    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_centres, sizeof(double) * 3 * (size_t)M, kd, ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_centres, sizeof(double) * 3 * (size_t)M, kd, cur_stream(ctx)));
     p += sizeof(double) * 3 * (size_t)M;
-    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_radii, sizeof(double) * (size_t)M, kd, ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_radii, sizeof(double) * (size_t)M, kd, cur_stream(ctx)));
     p += sizeof(double) * (size_t)M;
-    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_W, sizeof(double) * 3 * (size_t)(M + 4), kd, ctx->stream));
-    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(p, ctx->d_W, sizeof(double) * 3 * (size_t)(M + 4), kd, cur_stream(ctx)));
+    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     return FD_OK;
 }
 
@@ -610,8 +647,8 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     if (rc) return rc;
     ModelHeader h;
     if (on_device) {
-        FD_HIP(ctx, hipMemcpyAsync(ctx->h_header, buf, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FD_HIP(ctx, hipMemcpyAsync(ctx->h_header, buf, sizeof(h), hipMemcpyDeviceToHost, cur_stream(ctx)));
+        FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
         h = *ctx->h_header;
     } else {
         memcpy(&h, buf, sizeof(h));
@@ -627,17 +664,17 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     memcpy(ctx->params, h.params, sizeof(h.params));
     const char *p = (const char *)buf + sizeof(ModelHeader);
     const hipMemcpyKind kd = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    FD_HIP(ctx, hipMemcpyAsync(ctx->d_centres, p, sizeof(double) * 3 * (size_t)M, kd, ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_centres, p, sizeof(double) * 3 * (size_t)M, kd, cur_stream(ctx)));
     p += sizeof(double) * 3 * (size_t)M;
-    FD_HIP(ctx, hipMemcpyAsync(ctx->d_radii, p, sizeof(double) * (size_t)M, kd, ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_radii, p, sizeof(double) * (size_t)M, kd, cur_stream(ctx)));
     p += sizeof(double) * (size_t)M;
-    FD_HIP(ctx, hipMemcpyAsync(ctx->d_W, p, sizeof(double) * 3 * (size_t)(M + 4), kd, ctx->stream));
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_W, p, sizeof(double) * 3 * (size_t)(M + 4), kd, cur_stream(ctx)));
     if ((rc = sync_slot(ctx))) return rc;
     BuildBuffers b;
     fill_build_buffers(ctx, b);
-    FD_HIP(ctx, launch_pack_from_weights(b, ctx->stream));
-    ctx->wait_event = nullptr; ctx->wait_stream = nullptr;
-    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FD_HIP(ctx, launch_pack_from_weights(b, cur_stream(ctx)));
+    ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
+    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     ctx->points_set = false;   // no rest/delta on this context: it can deform, not rebuild
     ctx->build_pending = false;
     ctx->built = true;
@@ -654,21 +691,6 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
 // nodes of one cook graph -- are assembled and factorised by ONE launch chain: grid z selects
 // the context.  A lone build of this size keeps one CU busy through ~25 dependent launches and
 // the device overlaps only two or three such chains, so throughput-oriented callers batch.
-struct fd_batch {
-    int n = 0;
-    int device = 0;
-    fd_ctx *ctxs[kMaxBatch] = {};
-    uint64_t gens[kMaxBatch] = {};
-    BatchSlot *d_slots = nullptr;
-    PointSrc src{};
-    bool have_src = false;
-    hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
-    hipGraphExec_t exec = nullptr;
-    bool use_graph = true;
-    struct Key { int M, kind, term, nparams; double params[4]; } key{};
-    char err[512] = {0};
-};
-
 static void batch_err(fd_batch *b, const char *fmt, ...)
 {
     char *dst = b ? b->err : g_err;
@@ -712,7 +734,7 @@ void fd_batch_destroy(fd_batch *b)
         fd_ctx *c = b->ctxs[i];
         if (c && c->wait_event == b->ev1) {
             if (c->wait_stream) (void)hipStreamSynchronize(c->wait_stream);
-            c->wait_event = nullptr; c->wait_stream = nullptr;
+            c->wait_event = nullptr; c->wait_stream = nullptr; c->wait_batch = nullptr;
         }
         if (c && c->tev0 == b->ev0) { c->tev0 = c->ev0; c->tev_mid = c->ev_mid; c->tev1 = c->ev1; }
     }
@@ -754,7 +776,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     fd_ctx *c0 = b->ctxs[0];
     int rc = use_device(c0);
     if (rc) { batch_err(b, "%s", c0->err); return rc; }
-    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c0->stream;
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(c0);
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];
         if (!c->points_set) { batch_err(b, "fd_batch_build: context %d has no control points", i); return FD_E_INVALID; }
@@ -823,10 +845,11 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         FD_BHIP(launch_build(bb, stream, b->ev_mid));
     }
     FD_BHIP(hipEventRecord(b->ev1, stream));
+    b->waited_stream = nullptr;
 #undef FD_BHIP
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];
-        c->wait_event = b->ev1; c->wait_stream = stream;
+        c->wait_event = b->ev1; c->wait_stream = stream; c->wait_batch = b;
         c->tev0 = b->ev0; c->tev_mid = b->ev_mid; c->tev1 = b->ev1;
         c->build_pending = true;
         c->built = false;
