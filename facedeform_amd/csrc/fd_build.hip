@@ -134,6 +134,10 @@ __global__ void k_qnn_cap(const BatchSlot *tab, int M, double z)
 }
 
 // ---- assembly -----------------------------------------------------------------
+// A workgroup fills a (16 TS) x (16 TS) tile, 16 x 16 elements at a time (consecutive threads
+// walk a column: coalesced), and contributes ONE atomicMax to max|A|: with a 16 x 16 tile per
+// workgroup the 67 600 same-address atomics of an order-2080 system took 0.7 ms by themselves.
+template <int TS>
 __global__ __launch_bounds__(256) void k_assemble(const BatchSlot *tab, int M,
                                                    int n, int npad, int lda, int kind, int T,
                                                    double lambda)
@@ -141,42 +145,59 @@ __global__ __launch_bounds__(256) void k_assemble(const BatchSlot *tab, int M,
     const double *centres = tab[blockIdx.z].centres, *radii = tab[blockIdx.z].radii;
     double *A = tab[blockIdx.z].A;
     DevModel *model = tab[blockIdx.z].model;
-    // 16 x 16 element tile per workgroup; consecutive threads walk a column (coalesced)
-    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int j = blockIdx.y * 16 + (threadIdx.x >> 4);
-    double v = 0.0;
-    bool real = false;
-    if (i < npad && j < npad) {
-        if (i < M && j < M) {
-            const double dx = centres[3 * i] - centres[3 * j];
-            const double dy = centres[3 * i + 1] - centres[3 * j + 1];
-            const double dz = centres[3 * i + 2] - centres[3 * j + 2];
-            const double d2 = dx * dx + dy * dy + dz * dz;
+    __shared__ double s_max[4];
+    double m = 0.0;                      // max |A_ij| over the real system, for the singularity threshold
+    bool dup = false;
+#pragma unroll
+    for (int tj = 0; tj < TS; ++tj) {
+        const int j = (blockIdx.y * TS + tj) * 16 + (threadIdx.x >> 4);
+        if (j >= npad) continue;
+        double cjx = 0.0, cjy = 0.0, cjz = 0.0, inv_r2 = 1.0;
+        if (j < M) {
+            cjx = centres[3 * j]; cjy = centres[3 * j + 1]; cjz = centres[3 * j + 2];
             const double r = radii[j];
-            v = phi_d(kind, d2, 1.0 / (r * r));
-            if (i == j) v += lambda;
-            else if (d2 == 0.0) model->dup_flag = 1;  // coincident centres -> -5
-            real = true;
-        } else if (i < n && j < n) {
-            // polynomial block: column M is 1, columns M+1..M+3 are x, y, z
-            const int row = i < M ? i : j;      // the centre index
-            const int col = (i < M ? j : i) - M;
-            if (i < M || j < M) v = col == 0 ? 1.0 : centres[3 * row + col - 1];
-            real = true;
-            (void)T;
-        } else {
-            v = (i == j) ? 1.0 : 0.0;           // identity padding
+            inv_r2 = 1.0 / (r * r);
         }
-        A[(size_t)j * lda + i] = v;
+#pragma unroll
+        for (int ti = 0; ti < TS; ++ti) {
+            const int i = (blockIdx.x * TS + ti) * 16 + (threadIdx.x & 15);
+            if (i >= npad) continue;
+            double v = 0.0;
+            bool real = false;
+            if (i < M && j < M) {
+                const double dx = centres[3 * i] - cjx;
+                const double dy = centres[3 * i + 1] - cjy;
+                const double dz = centres[3 * i + 2] - cjz;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                v = phi_d(kind, d2, inv_r2);
+                if (i == j) v += lambda;
+                else if (d2 == 0.0) dup = true;     // coincident centres -> -5
+                real = true;
+            } else if (i < n && j < n) {
+                // polynomial block: column M is 1, columns M+1..M+3 are x, y, z
+                const int row = i < M ? i : j;      // the centre index
+                const int col = (i < M ? j : i) - M;
+                if (i < M || j < M) v = col == 0 ? 1.0 : centres[3 * row + col - 1];
+                real = true;
+                (void)T;
+            } else {
+                v = (i == j) ? 1.0 : 0.0;           // identity padding
+            }
+            A[(size_t)j * lda + i] = v;
+            if (real) m = fmax(m, fabs(v));
+        }
     }
-    // max |A_ij| over the real system, for the singularity threshold
-    double m = real ? fabs(v) : 0.0;
+    if (dup) model->dup_flag = 1;
     for (int off = 32; off >= 1; off >>= 1) {
         const double o = __shfl_xor(m, off);
         m = o > m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0 && m > 0.0)
-        atomicMax(&model->amax_bits, (unsigned long long)__double_as_longlong(m));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+        if (m > 0.0) atomicMax(&model->amax_bits, (unsigned long long)__double_as_longlong(m));
+    }
 }
 
 // ---- LU panel -------------------------------------------------------------------
@@ -514,39 +535,44 @@ __global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda,
 }
 
 // ---- back substitution, one workgroup, bottom-up over 32-row blocks ----------------
-// Solves U * X = Y (Y = columns npad.. of A after forward elimination).  Y lives in LDS
-// for the whole kernel; the diagonal block of the NEXT step is fetched while the current
-// one is solved; every thread issues the loads of its U row segment before wave 0 starts
-// the 32 x 32 triangle (rows in registers, x_k travels by v_readlane: no LDS round trip,
-// no barrier inside), so global latency hides behind the solve.
+// Solves U * X = Y (Y = columns npad.. of A after forward elimination) for the rows
+// [row_lo, row_hi): Y of that range lives in LDS for the whole kernel; the diagonal block of the
+// NEXT step is fetched while the current one is solved; every thread issues the loads of its U
+// row segment before wave 0 starts the 32 x 32 triangle (rows in registers, x_k travels by
+// v_readlane: no LDS round trip, no barrier inside), so global latency hides behind the solve.
+// Small systems (npad <= 512) are one call over [0, npad).  Larger ones go top-down in 256-row
+// ranges: this kernel on the range, then k_backsub_update pushes the solved block into the Y
+// rows above it with as many workgroups as there are rows (one workgroup walking all 2080 rows
+// per 32-column step took 2.4 ms at M = 2048).
 template <int T>
-__global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda, int npad)
+__global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda, int npad, int row_lo, int row_hi)
 {
-    const double *A = tab[blockIdx.z].A;
+    double *A = tab[blockIdx.z].A;
     double *X = tab[blockIdx.z].X;
-    extern __shared__ __attribute__((aligned(16))) double s_y[];   // [3][npad]
+    extern __shared__ __attribute__((aligned(16))) double s_y[];   // [3][w]
     __shared__ double s_u[2][32][33];
     __shared__ double s_x[32][3];
     constexpr int E = 1024 / T;          // diagonal-block elements per thread
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int w = row_hi - row_lo;
 
-    for (int e = tid; e < 3 * npad; e += T) s_y[e] = A[(size_t)(npad + e / npad) * lda + e % npad];
+    for (int e = tid; e < 3 * w; e += T) s_y[e] = A[(size_t)(npad + e / w) * lda + row_lo + e % w];
     double dnext[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
         const int e = tid + q * T;
-        dnext[q] = A[(size_t)(npad - 32 + (e >> 5)) * lda + npad - 32 + (e & 31)];
+        dnext[q] = A[(size_t)(row_hi - 32 + (e >> 5)) * lda + row_hi - 32 + (e & 31)];
     }
     int buf = 0;
-    for (int b0 = npad - 32; b0 >= 0; b0 -= 32, buf ^= 1) {
+    for (int b0 = row_hi - 32; b0 >= row_lo; b0 -= 32, buf ^= 1) {
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             const int e = tid + q * T;
             s_u[buf][e & 31][e >> 5] = dnext[q];
         }
-        if (b0 >= 32) {
+        if (b0 - 32 >= row_lo) {
 #pragma unroll
             for (int q = 0; q < E; ++q) {
                 const int e = tid + q * T;
@@ -556,7 +582,7 @@ __global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda
         // my first row's segment of U for the update below (does not depend on x); only the
         // small-system variant has the registers to hold it across the solve
         constexpr bool kPrefetch = T <= 256;
-        const int i0 = tid;
+        const int i0 = row_lo + tid;
         double uik[32];
         if (kPrefetch && i0 < b0) {
 #pragma unroll
@@ -564,12 +590,13 @@ __global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda
         }
         __syncthreads();                 // diagonal block and the Y rows of this block are in LDS
 
+        const int l0 = b0 - row_lo;      // this block's offset inside s_y
         if (tid < 64) {
             const int i = lane & 31;
             double ub[32];
 #pragma unroll
             for (int cc = 0; cc < 32; ++cc) ub[cc] = s_u[buf][i][cc];
-            double y0 = s_y[b0 + i], y1 = s_y[npad + b0 + i], y2 = s_y[2 * npad + b0 + i];
+            double y0 = s_y[l0 + i], y1 = s_y[w + l0 + i], y2 = s_y[2 * w + l0 + i];
             const double dinv = 1.0 / s_u[buf][i][i];
 #pragma unroll
             for (int k = 31; k >= 0; --k) {
@@ -587,7 +614,7 @@ __global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda
             }
             if (lane < 32) {
                 s_x[i][0] = y0; s_x[i][1] = y1; s_x[i][2] = y2;
-                s_y[b0 + i] = y0; s_y[npad + b0 + i] = y1; s_y[2 * npad + b0 + i] = y2;
+                s_y[l0 + i] = y0; s_y[w + l0 + i] = y1; s_y[2 * w + l0 + i] = y2;
             }
         }
         __syncthreads();
@@ -603,13 +630,44 @@ __global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda
                 a1 = fma(uik[k], s_x[k][1], a1);
                 a2 = fma(uik[k], s_x[k][2], a2);
             }
-            s_y[i] -= a0; s_y[npad + i] -= a1; s_y[2 * npad + i] -= a2;
+            const int li = i - row_lo;
+            s_y[li] -= a0; s_y[w + li] -= a1; s_y[2 * w + li] -= a2;
         }
         // no barrier here: the next iteration's barrier orders these writes before its solve,
         // and s_x / s_u[buf] are not rewritten before that barrier either (s_u alternates)
     }
     __syncthreads();
-    for (int e = tid; e < 3 * npad; e += T) X[e] = s_y[e];
+    for (int e = tid; e < 3 * w; e += T) X[(size_t)(e / w) * npad + row_lo + e % w] = s_y[e];
+}
+
+// Y[i] -= U[i, row_lo .. row_lo + w) * X[row_lo .. row_lo + w) for every row i < row_lo: one row
+// per thread (consecutive threads walk a column of U: coalesced), the solved block in LDS.
+__global__ __launch_bounds__(256) void k_backsub_update(const BatchSlot *tab, int lda, int npad, int row_lo, int w)
+{
+    double *A = tab[blockIdx.z].A;
+    const double *X = tab[blockIdx.z].X;
+    __shared__ double s_x[3][256];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 3 * w; e += 256) s_x[e / w][e % w] = X[(size_t)(e / w) * npad + row_lo + e % w];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= row_lo) return;
+    const double *u = A + (size_t)row_lo * lda + i;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int k0 = 0; k0 < w; k0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = u[(size_t)(k0 + k) * lda];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            a0 = fma(v[k], s_x[0][k0 + k], a0);
+            a1 = fma(v[k], s_x[1][k0 + k], a1);
+            a2 = fma(v[k], s_x[2][k0 + k], a2);
+        }
+    }
+    A[(size_t)npad * lda + i] -= a0;
+    A[(size_t)(npad + 1) * lda + i] -= a1;
+    A[(size_t)(npad + 2) * lda + i] -= a2;
 }
 
 // ---- pack: solution -> weights, evaluation records, status -----------------------
@@ -862,9 +920,15 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
             hipLaunchKernelGGL(k_qnn_median, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, M);
             hipLaunchKernelGGL(k_qnn_cap, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, M, b.qnn_z);
         }
-        const dim3 grid(b.npad / 16, b.npad / 16, nb);
-        hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, stream, b.d_slots, M, b.n, b.npad, b.lda, b.kind,
-                           b.T, b.lambda);
+        if (b.npad <= 512) {
+            const unsigned g = (unsigned)(b.npad + 31) / 32;
+            hipLaunchKernelGGL((k_assemble<2>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
+                               b.lda, b.kind, b.T, b.lambda);
+        } else {
+            const unsigned g = (unsigned)(b.npad + 63) / 64;
+            hipLaunchKernelGGL((k_assemble<4>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
+                               b.lda, b.kind, b.T, b.lambda);
+        }
     }
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
 
@@ -877,20 +941,20 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
         else { lu_step<4>(b, k0, stream); k0 += 4; }
     }
     {
-        // Y (3 x npad fp64) stays in LDS: 3 * 8192 * 8 B = 192 KiB would not fit, but the panel
-        // kernel already limits the order to kMaxOrder and 3 * npad * 8 <= 160 KiB - 18 KiB
-        // holds up to npad = 5900; larger systems are rejected in fd_set_points
-        const size_t ybytes = sizeof(double) * 3 * (size_t)b.npad;
-        if (b.npad <= 512)
-            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), ybytes, stream, b.d_slots, b.lda, b.npad);
-        else {
-            static bool attr_set = false;   // > 64 KiB of dynamic LDS has to be requested once
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backsub_all<1024>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-                attr_set = true;
+        if (b.npad <= 512) {
+            const size_t ybytes = sizeof(double) * 3 * (size_t)b.npad;
+            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), ybytes, stream, b.d_slots, b.lda,
+                               b.npad, 0, b.npad);
+        } else {
+            constexpr int W = 256;      // rows per diagonal range (a multiple of 32, like npad)
+            for (int hi = b.npad; hi > 0; hi -= W) {
+                const int lo = hi > W ? hi - W : 0;
+                hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)(hi - lo),
+                                   stream, b.d_slots, b.lda, b.npad, lo, hi);
+                if (lo > 0)
+                    hipLaunchKernelGGL(k_backsub_update, dim3((lo + 255) / 256, 1, nb), dim3(256), 0, stream,
+                                       b.d_slots, b.lda, b.npad, lo, hi - lo);
             }
-            hipLaunchKernelGGL((k_backsub_all<1024>), dim3(1, 1, nb), dim3(1024), ybytes, stream, b.d_slots, b.lda, b.npad);
         }
     }
     hipError_t e = launch_pack(b, stream);
