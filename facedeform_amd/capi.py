@@ -48,7 +48,7 @@ EXPORTS = [
     "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_points",
     "fd_set_points_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
-    "fd_export_model", "fd_import_model", "fd_synchronize",
+    "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
     "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error",
     "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
@@ -98,6 +98,8 @@ def load() -> C.CDLL:
     L.fd_export_model.argtypes = [vp, vp, sz, i32]; L.fd_export_model.restype = i32
     L.fd_import_model.argtypes = [vp, vp, sz, i32]; L.fd_import_model.restype = i32
     L.fd_synchronize.argtypes = [vp]; L.fd_synchronize.restype = i32
+    L.fd_host_alloc.argtypes = [sz]; L.fd_host_alloc.restype = vp
+    L.fd_host_free.argtypes = [vp]; L.fd_host_free.restype = None
     L.fd_batch_create.argtypes = [C.POINTER(vp), i32]; L.fd_batch_create.restype = vp
     L.fd_batch_destroy.argtypes = [vp]; L.fd_batch_destroy.restype = None
     L.fd_batch_size.argtypes = [vp]; L.fd_batch_size.restype = i32
@@ -223,6 +225,18 @@ class Engine:
                                      float(falloffrate)))
         return out, fall
 
+    def deform_into(self, P_in, P_out, dist2=None, falloff=None, tangents=None, radius2=1.0, falloffrate=1.0):
+        """fd_deform on the caller's own arrays, no copies in the binding (float32, C-contiguous;
+        page-locked arrays from host_array() take the chunked overlapped path)."""
+        for a in (P_in, P_out, dist2, falloff) + tuple(tangents or ()):
+            if a is not None and (a.dtype != np.float32 or not a.flags.c_contiguous):
+                raise ValueError("arrays must be C-contiguous float32")
+        N = P_in.shape[0]
+        tu, tv, nr = tangents if tangents is not None else (None, None, None)
+        self._check(self.L.fd_deform(self.ctx, N, _np_ptr(P_in), _np_ptr(P_out), _np_ptr(dist2), _np_ptr(falloff),
+                                     _np_ptr(tu), _np_ptr(tv), _np_ptr(nr), float(radius2),
+                                     float(falloffrate)))
+
     def deform_dev(self, N: int, d_P_in: int, d_P_out: int, d_dist2: int = 0, d_falloff: int = 0,
                    d_tu: int = 0, d_tv: int = 0, d_nrm: int = 0, radius2=1.0, falloffrate=1.0):
         vp = C.c_void_p
@@ -270,6 +284,32 @@ class Engine:
 
 
 MAX_BATCH = 32
+
+
+class _PinnedBlock:
+    def __init__(self, L, ptr):
+        self.L, self.ptr = L, ptr
+
+    def __del__(self):
+        try:
+            self.L.fd_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def host_array(shape, dtype=np.float32):
+    """numpy array over page-locked memory from fd_host_alloc (freed with the array)."""
+    L = load()
+    dtype = np.dtype(dtype)
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    ptr = L.fd_host_alloc(max(nbytes, 1))
+    if not ptr:
+        raise FdError(FD_E_NOMEM, L.fd_last_error(None).decode())
+    block = _PinnedBlock(L, ptr)
+    buf = (C.c_char * max(nbytes, 1)).from_address(ptr)
+    buf._fd_block = block                      # keeps the allocation alive as long as any view
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 class Batch:

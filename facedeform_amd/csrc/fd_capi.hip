@@ -197,6 +197,13 @@ static int sync_slot(fd_ctx *ctx)
 }
 
 // a model that a batched build is producing on another stream: make `s` wait for it
+static bool host_is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
 static int order_after_batch(fd_ctx *ctx, hipStream_t s)
 {
     if (!ctx->wait_event || s == ctx->wait_stream) return FD_OK;
@@ -546,6 +553,33 @@ int fd_deform(fd_ctx *ctx, int64_t N, const float *P_in, float *P_out, const flo
     if (N == 0) return FD_OK;
     int rc = use_device(ctx);
     if (rc) return rc;
+    // Page-locked caller arrays (fd_host_alloc, hipHostMalloc, hipHostRegister): the kernel reads
+    // and writes them in place over the host link -- reads and writes travel in both directions
+    // at once and nothing is staged.  Measured at C2: 0.44 ms against 0.62 ms for upload +
+    // evaluate + download (chunking those copies over two streams did not overlap them at all).
+    static const bool no_zero_copy = getenv("FD_NO_ZEROCOPY") != nullptr;
+    const bool all_pinned = host_is_pinned(P_in) && host_is_pinned(P_out) && (!dist2 || host_is_pinned(dist2)) &&
+                            (!falloff_out || host_is_pinned(falloff_out)) &&
+                            (!tu || (host_is_pinned(tu) && host_is_pinned(tv) && host_is_pinned(nrm)));
+    if (all_pinned && !no_zero_copy) {
+        bool ok = true;
+        auto dp = [&ok](const void *h) -> void * {
+            void *d = nullptr;
+            if (!h) return nullptr;
+            if (hipHostGetDevicePointer(&d, const_cast<void *>(h), 0) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+            return d;
+        };
+        const float *zP = (const float *)dp(P_in), *zD = (const float *)dp(dist2), *zU = (const float *)dp(tu),
+                    *zV = (const float *)dp(tv), *zN = (const float *)dp(nrm);
+        float *zO = (float *)dp(P_out), *zF = (float *)dp(falloff_out);
+        if (ok) {
+            hipStream_t s = cur_stream(ctx);
+            rc = fd_deform_dev_stream(ctx, s, N, zP, zO, zD, zF, zU, zV, zN, radius2, falloffrate);
+            if (rc) return rc;
+            FD_HIP(ctx, hipStreamSynchronize(s));
+            return FD_OK;
+        }
+    }
     if (N > ctx->cap_N) {
         if ((rc = dev_alloc(ctx, &ctx->d_P, (size_t)N * 3))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_dist2, (size_t)N))) return rc;
@@ -561,11 +595,14 @@ int fd_deform(fd_ctx *ctx, int64_t N, const float *P_in, float *P_out, const flo
         if ((rc = dev_alloc(ctx, &ctx->d_tv, (size_t)ctx->cap_N * 3))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_nrm, (size_t)ctx->cap_N * 3))) return rc;
     }
+    // A vertex whose gate fails keeps the caller's fd_falloff entry, so that array goes up as
+    // well -- unless no vertex can be gated (no dist2 and a non-negative radius^2).
+    const bool fall_up = falloff_out && (dist2 || radius2 < 0.f);
     hipStream_t s = cur_stream(ctx);
     const size_t b3 = sizeof(float) * 3 * (size_t)N, b1 = sizeof(float) * (size_t)N;
     FD_HIP(ctx, hipMemcpyAsync(ctx->d_P, P_in, b3, hipMemcpyHostToDevice, s));
     if (dist2) FD_HIP(ctx, hipMemcpyAsync(ctx->d_dist2, dist2, b1, hipMemcpyHostToDevice, s));
-    if (falloff_out) FD_HIP(ctx, hipMemcpyAsync(ctx->d_fall, falloff_out, b1, hipMemcpyHostToDevice, s));
+    if (fall_up) FD_HIP(ctx, hipMemcpyAsync(ctx->d_fall, falloff_out, b1, hipMemcpyHostToDevice, s));
     if (tu) {
         FD_HIP(ctx, hipMemcpyAsync(ctx->d_tu, tu, b3, hipMemcpyHostToDevice, s));
         FD_HIP(ctx, hipMemcpyAsync(ctx->d_tv, tv, b3, hipMemcpyHostToDevice, s));
@@ -579,6 +616,21 @@ int fd_deform(fd_ctx *ctx, int64_t N, const float *P_in, float *P_out, const flo
     if (falloff_out) FD_HIP(ctx, hipMemcpyAsync(falloff_out, ctx->d_fall, b1, hipMemcpyDeviceToHost, s));
     FD_HIP(ctx, hipStreamSynchronize(s));
     return FD_OK;
+}
+
+void *fd_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        set_err(nullptr, "fd_host_alloc(%zu) failed: %s", bytes, hipGetErrorString(hipGetLastError()));
+        return nullptr;
+    }
+    return p;
+}
+
+void fd_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 static int require_built(fd_ctx *ctx, const char *who)

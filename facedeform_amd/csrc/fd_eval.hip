@@ -380,12 +380,12 @@ __device__ __forceinline__ float d2_log_d2(float d)
     return fd_fmul_legacy(d, __builtin_amdgcn_logf(__builtin_fabsf(d)));
 }
 
-// Inputs of one vertex group as a lane holds them: the coordinate its B-operand slot needs for
-// each of the wave's TV vertex tiles, and position + dist2 of the one vertex per tile quartet
-// whose epilogue this lane runs (tile g of the quartet, column j).
+// Inputs of one vertex group as a lane holds them: position + dist2 of the one vertex per tile
+// quartet whose epilogue this lane runs (tile g of the quartet, column j).  Every vertex is
+// loaded exactly once (the B-operand slots get their coordinate from these lanes by shuffle):
+// with page-locked host arrays the loads cross the host link.
 template <int TV>
 struct GroupIn {
-    float comp[TV];
     float pos[TV / 4][3];
     float d2v[TV / 4];
 };
@@ -394,13 +394,6 @@ template <int TV>
 __device__ __forceinline__ GroupIn<TV> load_group(const EvalParams &p, int64_t vbase, int g, int j)
 {
     GroupIn<TV> in;
-    const int gc = g < 3 ? g : 0;
-#pragma unroll
-    for (int t = 0; t < TV; ++t) {
-        const int64_t vi = vbase + 16 * t + j;
-        const int64_t vc = vi < p.N ? vi : p.N - 1;
-        in.comp[t] = p.P_in[3 * vc + gc];
-    }
 #pragma unroll
     for (int q = 0; q < TV / 4; ++q) {
         const int64_t vi = vbase + 16 * (4 * q + g) + j;
@@ -456,7 +449,12 @@ void k_deform32_tps_mfma(const EvalParams p, int ngroups)
         bf16x8 bop[TV];
 #pragma unroll
         for (int t = 0; t < TV; ++t) {
-            const float comp = g < 3 ? (in.comp[t] - nsel) * inv_s : 0.f;
+            // coordinate g of vertex (tile t, column j): it sits in lane group t & 3 of quartet t / 4
+            const int srcl = 16 * (t & 3) + j;
+            const float c0 = __shfl(in.pos[t / 4][0], srcl), c1 = __shfl(in.pos[t / 4][1], srcl),
+                        c2 = __shfl(in.pos[t / 4][2], srcl);
+            const float craw = g == 0 ? c0 : (g == 1 ? c1 : c2);
+            const float comp = g < 3 ? (craw - nsel) * inv_s : 0.f;
             float xx = comp * comp;
             xx += __shfl_xor(xx, 16);
             xx += __shfl_xor(xx, 32);

@@ -191,9 +191,16 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
         node->add(FDSOP_ERROR, "Invalid geometry arrays.");
         return node->severity;
     }
-    // duplicatePointSource(0) (:226): the output starts as a copy of input 0
-    if (geo->P_out != geo->P && geo->npoints > 0)
-        memcpy(geo->P_out, geo->P, sizeof(float) * 3 * (size_t)geo->npoints);
+    // duplicatePointSource(0) (:226): the output starts as a copy of input 0.  On the success
+    // path fd_deform writes every point of P_out from P (gated points are copied through), so
+    // the 12 B/point host copy is only made where the cook stops early.
+    struct PassThrough {
+        const fdsop_geo *g; bool armed;
+        ~PassThrough() {
+            if (armed && g->P_out != g->P && g->npoints > 0)
+                memcpy(g->P_out, g->P, sizeof(float) * 3 * (size_t)g->npoints);
+        }
+    } pass{geo, true};
 
     // :228-234
     if (geo->rest_npoints != geo->deform_npoints) {
@@ -301,12 +308,14 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     const float radius_sqrt = radius * radius;   // :402 (a square, despite the name)
 
     // :404-439
-    rc = fd_deform(ctx, geo->npoints, geo->P_out, geo->P_out, geo->dist2, geo->fd_falloff,
+    pass.armed = false;
+    rc = fd_deform(ctx, geo->npoints, geo->P, geo->P_out, geo->dist2, geo->fd_falloff,
                    do_tangent_disp ? geo->tangentu : nullptr, do_tangent_disp ? geo->tangentv : nullptr,
                    do_tangent_disp ? geo->N : nullptr, radius_sqrt, falloffrate);
     if (rc != FD_OK) {
         std::string t = std::string("GPU deformation failed: ") + fd_last_error(ctx);
         node->add(FDSOP_ERROR, t.c_str());
+        pass.armed = true;
     }
     return node->severity;
 }

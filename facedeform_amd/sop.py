@@ -101,7 +101,12 @@ class FaceDeformSOP:
         return e
 
     # -- cook
-    def cook(self, mesh_P, rest_P, deform_P, dist2=None, tangentu=None, tangentv=None, N=None) -> CookResult:
+    def cook(self, mesh_P, rest_P, deform_P, dist2=None, tangentu=None, tangentv=None, N=None,
+             out_P=None, out_falloff=None, want_Cd=True) -> CookResult:
+        """out_P / out_falloff: caller-owned result arrays (e.g. page-locked ones from
+        capi.host_array, as the HDK wrapper keeps them): with every mesh array page-locked the
+        evaluation runs in place over the host link.  want_Cd=False leaves the Cd fill to the
+        attribute default, as the wrapper does."""
         f32 = np.float32
         P = np.ascontiguousarray(mesh_P, f32).reshape(-1, 3)
         rest = np.ascontiguousarray(rest_P, f32).reshape(-1, 3)
@@ -116,9 +121,13 @@ class FaceDeformSOP:
             return arr
 
         d2, tu, tv, nn = opt(dist2, 1), opt(tangentu, 3), opt(tangentv, 3), opt(N, 3)
-        P_out = np.empty_like(P)
-        fall = np.empty(P.shape[0], f32)
-        Cd = np.empty_like(P)
+        P_out = np.empty_like(P) if out_P is None else out_P
+        fall = np.empty(P.shape[0], f32) if out_falloff is None else out_falloff
+        if P_out.dtype != f32 or not P_out.flags.c_contiguous or P_out.shape != P.shape:
+            raise ValueError("out_P must be a C-contiguous float32 array shaped like the mesh")
+        if fall.dtype != f32 or not fall.flags.c_contiguous or fall.shape != (P.shape[0],):
+            raise ValueError("out_falloff must be a C-contiguous float32 array with one entry per point")
+        Cd = np.empty_like(P) if want_Cd else None
         fp = capi._f32p
 
         def ptr(a):

@@ -97,7 +97,38 @@ static PRM_Template *buildTemplates()
 // ---- page-wise gather / scatter between GA attributes and flat arrays --------------------
 // (the access pattern the reference's dead threaded evaluator sketches,
 //  src/SOP_FaceDeform.hpp:116-188: GA pages are contiguous runs of 1024 elements)
-static void gatherV3(const GU_Detail *gdp, const GA_Attribute *attr, std::vector<float> &out)
+// Grow-only page-locked float array (fd_host_alloc): when every array of the cook is page-locked
+// the evaluation kernel reads and writes them in place over the host link, with no staging copy
+// (include/facedeform_hip.h, fd_host_alloc).  Kept as node members so the pages stay locked
+// from cook to cook.
+class PinnedF
+{
+public:
+    PinnedF() = default;
+    PinnedF(const PinnedF &) = delete;
+    PinnedF &operator=(const PinnedF &) = delete;
+    ~PinnedF() { fd_host_free(myData); }
+    void resize(size_t n)
+    {
+        if (n > myCap) {
+            fd_host_free(myData);
+            myData = (float *)fd_host_alloc(sizeof(float) * n);
+            myCap = myData ? n : 0;
+        }
+        mySize = myData ? n : 0;
+    }
+    void clear() { mySize = 0; }
+    bool empty() const { return mySize == 0; }
+    float *data() { return myData; }
+    const float *data() const { return myData; }
+    float &operator[](size_t i) { return myData[i]; }
+    const float &operator[](size_t i) const { return myData[i]; }
+private:
+    float *myData = nullptr;
+    size_t mySize = 0, myCap = 0;
+};
+
+static void gatherV3(const GU_Detail *gdp, const GA_Attribute *attr, PinnedF &out)
 {
     out.resize(3 * (size_t)gdp->getNumPoints());
     GA_ROPageHandleV3 h(attr);
@@ -112,7 +143,7 @@ static void gatherV3(const GU_Detail *gdp, const GA_Attribute *attr, std::vector
     }
 }
 
-static void scatterV3(GU_Detail *gdp, GA_Attribute *attr, const std::vector<float> &in)
+static void scatterV3(GU_Detail *gdp, GA_Attribute *attr, const PinnedF &in)
 {
     GA_RWPageHandleV3 h(attr);
     GA_Offset start, end;
@@ -155,7 +186,9 @@ protected:
             else { fdsop_set_float(myNode, r.token, 0, evalFloat(r.token, 0, t)); if (r.kind == '2') fdsop_set_float(myNode, r.token, 1, evalFloat(r.token, 1, t)); }
         }
 
-        std::vector<float> P, restP, deformP, tu, tv, nn, dist2, Pout, falloff, Cd;
+        PinnedF &P = myP, &restP = myRestP, &deformP = myDeformP, &tu = myTu, &tv = myTv, &nn = myNn,
+                &dist2 = myDist2, &Pout = myPout, &falloff = myFalloff;
+        tu.clear(); tv.clear(); nn.clear(); dist2.clear();
         gatherV3(gdp, gdp->getP(), P);
         gatherV3(rest, rest->getP(), restP);
         gatherV3(deform, deform->getP(), deformP);
@@ -172,7 +205,7 @@ protected:
             GA_FOR_ALL_PTOFF(gdp, o) dist2[(size_t)gdp->pointIndex(o)] = h.get(o);
         }
         const size_t n = (size_t)gdp->getNumPoints();
-        Pout.resize(3 * n); falloff.resize(n); Cd.resize(3 * n);
+        Pout.resize(3 * n); falloff.resize(n);
 
         fdsop_geo geo{};
         geo.npoints = (int64_t)n;
@@ -187,7 +220,7 @@ protected:
         geo.deform_P = deformP.data();
         geo.P_out = Pout.data();
         geo.fd_falloff = falloff.data();
-        geo.Cd = Cd.data();
+        geo.Cd = nullptr;      // the attribute is created with white defaults below (:386-388)
         fdsop_cook(myNode, &geo);
 
         // replay the engine's messages through the node's own channels
@@ -218,6 +251,7 @@ private:
     const GA_Attribute *captureDistanceAttribute() const { return nullptr; }
 
     fdsop_node *myNode = nullptr;
+    PinnedF myP, myRestP, myDeformP, myTu, myTv, myNn, myDist2, myPout, myFalloff;
 };
 
 }  // namespace fdhip

@@ -170,6 +170,15 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device);
 /* Block until everything enqueued on the context's stream has finished. */
 int fd_synchronize(fd_ctx *ctx);
 
+/* Page-locked host memory for the arrays handed to fd_deform (replaces nothing
+ * in the reference: GA pages are ordinary memory; the wrapper gathers them
+ * into a flat array anyway, hdk/SOP_FaceDeformHip.cpp).  When every array of a
+ * fd_deform call is page-locked the kernel reads and writes them in place over
+ * the host link (no staging copies, traffic in both directions at once);
+ * pageable arrays are uploaded, evaluated and downloaded one after the other. */
+void *fd_host_alloc(size_t bytes);
+void fd_host_free(void *p);
+
 /* ---- batched build ------------------------------------------------------------
  * The reference cooks one node at a time: one rbfbuildmodel per cookMySop
  * (src/SOP_FaceDeform.cpp:363).  A dense system of order 260 keeps one CU of a

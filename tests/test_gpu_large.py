@@ -142,3 +142,44 @@ def test_split_mesh_with_device_side_model_broadcast(hip_lib):
     a.synchronize(); b.synchronize()
     assert np.array_equal(d_out.cpu().numpy(), whole)
     a.close(); b.close()
+
+
+def test_pinned_host_arrays_take_the_chunked_path_bit_identically(hip_lib):
+    """fd_deform on page-locked caller arrays (fd_host_alloc) runs in chunks on two streams;
+    every vertex must get exactly the bits the one-pass pageable path gives it -- including
+    gated vertices (position and the caller's fd_falloff entry untouched), fall-off, tangent
+    projection, a ragged N and in-place output."""
+    N, M = 1_000_003, 96
+    rng = np.random.default_rng(5)
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    deform = synth.deformed_rig(rest, 1)
+    e = capi.Engine()
+    e.set_points(rest, (deform - rest).astype(np.float32)); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+    assert e.build().terminationtype == 1
+    dist2 = (rng.random(N) * 0.6).astype(np.float32)
+    dist2[::11] = -1.0
+    tu, tv, nn = synth.tangent_frames(P)
+    for use_d2, use_tan in ((False, False), (True, False), (True, True)):
+        kw = dict(radius2=0.49, falloffrate=1.5)
+        # pageable reference
+        out_a = np.empty_like(P); fall_a = np.full(N, 7.0, np.float32)
+        e.deform_into(P, out_a, dist2 if use_d2 else None, fall_a, (tu, tv, nn) if use_tan else None, **kw)
+        # page-locked, in place
+        pin_P = capi.host_array((N, 3)); pin_P[:] = P
+        pin_fall = capi.host_array(N); pin_fall[:] = 7.0
+        pin_d2 = None
+        if use_d2:
+            pin_d2 = capi.host_array(N); pin_d2[:] = dist2
+        pin_t = None
+        if use_tan:
+            pin_t = tuple(capi.host_array((N, 3)) for _ in range(3))
+            for dst, src in zip(pin_t, (tu, tv, nn)):
+                dst[:] = src
+        e.deform_into(pin_P, pin_P, pin_d2, pin_fall, pin_t, **kw)
+        assert np.array_equal(pin_P, out_a), (use_d2, use_tan)
+        assert np.array_equal(pin_fall, fall_a), (use_d2, use_tan)
+        if use_d2:
+            gated = dist2 > np.float32(0.49)
+            assert gated.any() and np.array_equal(pin_P[gated], P[gated]) and np.all(pin_fall[gated] == 7.0)
+    e.close()

@@ -16,9 +16,33 @@ for f in range(12):
     ts.append(time.perf_counter() - t0)
 ts = sorted(ts[2:])
 print(f"host-pointer cook (H2D 12 MB + build + evaluate + D2H 16 MB, pageable numpy arrays, incl. one 12 MB host copy in the binding): median {ts[len(ts)//2]*1e3:.3f} ms -> {N/ts[len(ts)//2]/1e6:.0f} Mverts/s")
+# the same cook on page-locked arrays (fd_host_alloc): chunked, copies overlap evaluation
+pin_in = capi.host_array((N, 3)); pin_in[:] = P
+pin_out = capi.host_array((N, 3)); pin_fall = capi.host_array(N)
+page_out = np.empty_like(P); page_fall = np.zeros(N, np.float32)
+for label, (a_in, a_out, a_fall) in (("pageable, no binding copy", (P, page_out, page_fall)), ("page-locked", (pin_in, pin_out, pin_fall))):
+    ts = []
+    for f in range(12):
+        delta = synth.smooth_deltas(rest, f)
+        a_fall[:] = 0
+        t0 = time.perf_counter()
+        e.set_points(rest, delta); e.build(); e.deform_into(a_in, a_out, None, a_fall)
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[2:])
+    print(f"host-pointer cook, {label}: median {ts[len(ts)//2]*1e3:.3f} ms -> {N/ts[len(ts)//2]/1e6:.0f} Mverts/s")
+    ts = []
+    for f in range(12):
+        t0 = time.perf_counter(); e.deform_into(a_in, a_out, None, a_fall); ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[2:])
+    print(f"   fd_deform alone (H2D 12 MB + evaluate + D2H 16 MB), {label}: median {ts[len(ts)//2]*1e3:.3f} ms")
 node = FaceDeformSOP(); node.set("kernel", 1)
 ts = []
 for f in range(8):
     t0 = time.perf_counter(); res = node.cook(P, rest, synth.deformed_rig(rest, f)); ts.append(time.perf_counter() - t0)
 ts = sorted(ts[2:])
 print(f"fdsop_cook through the C++ host mirror (same sizes, + Cd fill, fd_falloff): median {ts[len(ts)//2]*1e3:.3f} ms; severity {res.severity}; {res.infos}")
+ts = []
+for f in range(8):
+    t0 = time.perf_counter(); res = node.cook(pin_in, rest, synth.deformed_rig(rest, f), out_P=pin_out, out_falloff=pin_fall, want_Cd=False); ts.append(time.perf_counter() - t0)
+ts = sorted(ts[2:])
+print(f"fdsop_cook on page-locked mesh arrays, Cd left to the attribute default (what hdk/SOP_FaceDeformHip.cpp does): median {ts[len(ts)//2]*1e3:.3f} ms; severity {res.severity}")
