@@ -391,3 +391,96 @@ int fdo_deform(const double *table, int M, int kind, const double *radii, const 
     free(th); free(jobs); free(inv);
     return 0;
 }
+
+/* ---- next row N1: morph-space reprojection (reference src/dbse.cpp) ---------------------- */
+
+/* dbse.cpp:16-31: one column per blendshape, rows 3i..3i+2 = fp32 (shape - rest) widened */
+void fdo_morph_shapes_matrix(const float *rest_xyz, const float *const *shapes_xyz, int64_t N, int S, double *A)
+{
+    const int64_t rows = 3 * N;
+    for (int s = 0; s < S; ++s)
+        for (int64_t e = 0; e < rows; ++e) {
+            const float d = shapes_xyz[s][e] - rest_xyz[e];      /* UT_Vector3 subtraction, :25 */
+            A[(size_t)s * rows + e] = (double)d;
+        }
+}
+
+/* dbse.cpp:33 `new QRMatrix(myShapesMatrix)`: Eigen::HouseholderQR<MatrixXd>.  Unblocked form
+ * (Eigen/src/QR/HouseholderQR.h householder_qr_inplace_unblocked; the blocked variant Eigen picks
+ * for wide matrices applies the same reflectors): per column k, makeHouseholderInPlace on
+ * A[k:, k] then applyHouseholderOnTheLeft to A[k:, k+1:].  Identical to LAPACK dgeqr2. */
+void fdo_morph_qr(double *A, int64_t rows, int S, double *tau)
+{
+    for (int k = 0; k < S && k < rows; ++k) {
+        double *x = A + (size_t)k * rows;
+        const int64_t nt = rows - k - 1;
+        double tail2 = 0.0;
+        for (int64_t i = k + 1; i < rows; ++i) tail2 += x[i] * x[i];
+        const double c0 = x[k];
+        double beta, t;
+        if (nt == 0 || tail2 <= 2.2250738585072014e-308) {       /* numeric_limits<double>::min() */
+            t = 0.0; beta = c0;
+            for (int64_t i = k + 1; i < rows; ++i) x[i] = 0.0;
+        } else {
+            beta = sqrt(c0 * c0 + tail2);
+            if (c0 >= 0.0) beta = -beta;
+            for (int64_t i = k + 1; i < rows; ++i) x[i] = x[i] / (c0 - beta);   /* Eigen divides, dlarfg scales by the reciprocal */
+            t = (beta - c0) / beta;
+        }
+        x[k] = beta;
+        tau[k] = t;
+        /* applyHouseholderOnTheLeft: tmp = essential^T * bottom + row0; row0 -= tau tmp;
+         * bottom -= tau * essential * tmp */
+        for (int j = k + 1; j < S; ++j) {
+            double *a = A + (size_t)j * rows;
+            double tmp = 0.0;
+            for (int64_t i = k + 1; i < rows; ++i) tmp += x[i] * a[i];
+            tmp += a[k];
+            a[k] -= t * tmp;
+            for (int64_t i = k + 1; i < rows; ++i) a[i] -= t * x[i] * tmp;
+        }
+    }
+}
+
+/* dbse.cpp:39-60 */
+void fdo_morph_weights(const double *QR, int64_t N, int S, const float *P_xyz, const float *rest_xyz, double *w)
+{
+    const int64_t rows = 3 * N;
+    for (int s = 0; s < S; ++s) {
+        const double *q = QR + (size_t)s * rows;
+        double acc = 0.0;
+        for (int64_t e = 0; e < rows; ++e) {
+            const float d = P_xyz[e] - rest_xyz[e];              /* :49-51, fp32 then widened */
+            acc += (double)d * q[e];                             /* asDiagonal() * matrixQR(), colwise sum :55-56 */
+        }
+        w[s] = acc;
+    }
+}
+
+/* dbse.cpp:62-77 and SOP_FaceDeform.cpp:458-473 */
+void fdo_morph_displace(const double *shapes, int64_t N, int S, const double *w, const float *clamp_lo_hi,
+                        int add_delta, float falloffradius, const float *rest_xyz, float *P_xyz)
+{
+    const int64_t rows = 3 * N;
+    for (int64_t i = 0; i < N; ++i) {
+        float disp[3] = {0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            const float xd = (float)shapes[(size_t)s * rows + 3 * i];
+            const float yd = (float)shapes[(size_t)s * rows + 3 * i + 1];
+            const float zd = (float)shapes[(size_t)s * rows + 3 * i + 2];
+            const float ws = (float)(w[s] * 3);                  /* :70, the magic number */
+            float cw = ws;
+            if (clamp_lo_hi) cw = ws < clamp_lo_hi[0] ? clamp_lo_hi[0] : (ws > clamp_lo_hi[1] ? clamp_lo_hi[1] : ws);
+            disp[0] += xd * cw; disp[1] += yd * cw; disp[2] += zd * cw;
+        }
+        const float *rest = rest_xyz + 3 * i;
+        float *pos = P_xyz + 3 * i;
+        if (add_delta) {                                         /* SOP :467-470 */
+            disp[0] += (pos[0] - rest[0]) * falloffradius;
+            disp[1] += (pos[1] - rest[1]) * falloffradius;
+            disp[2] += (pos[2] - rest[2]) * falloffradius;
+        }
+        pos[0] = rest[0] + disp[0]; pos[1] = rest[1] + disp[1]; pos[2] = rest[2] + disp[2];   /* :471 */
+    }
+}
+

@@ -25,6 +25,11 @@
  *   fdo_deform             src/SOP_FaceDeform.cpp:396-439  (gate, evaluate, tangent,
  *                          fall-off, write-back -- in the reference's order)
  *   fdo_project_to_tangents src/SOP_FaceDeform.hpp:28-41
+ *   fdo_morph_*            src/dbse.cpp:9-87, src/SOP_FaceDeform.cpp:444-473 (next row N1:
+ *                          morph-space reprojection).  The Householder QR there is Eigen's
+ *                          (un-vendored, absent); its packed storage and reflector convention
+ *                          are those of LAPACK dgeqr2, which is what pins this restatement
+ *                          (SciPy scipy.linalg.qr(mode='raw'), tests/golden/make_golden.py).
  */
 #ifndef FD_ORACLE_H
 #define FD_ORACLE_H
@@ -85,6 +90,22 @@ int fdo_deform(const double *table, int M, int kind, const double *radii, const 
                int64_t N, const float *P_in, float *P_out, const float *dist2,
                float *falloff_out, const float *tu, const float *tv, const float *nrm,
                float radius2, float falloffrate, int nthreads);
+
+/* ---- next row N1: morph-space reprojection (DirectBSEdit) -------------------------
+ * dbse.cpp:9-37: shapes matrix A (3N x S, column-major, lda = 3N), A[3i+c][s] =
+ * double(float(shape_s[i][c] - rest[i][c])), then HouseholderQR in place: on return A holds
+ * Eigen's matrixQR() -- R in the upper triangle, the essential parts of the reflectors
+ * below the diagonal; tau[S] are the Householder coefficients.  S <= 3N. */
+void fdo_morph_shapes_matrix(const float *rest_xyz, const float *const *shapes_xyz, int64_t N, int S, double *A);
+void fdo_morph_qr(double *A, int64_t rows, int S, double *tau);
+/* dbse.cpp:39-60: delta = float(P - rest) per component, w_s = sum_i delta_i * QR[i][s]
+ * (the packed matrix itself, as the reference uses it). */
+void fdo_morph_weights(const double *QR, int64_t N, int S, const float *P_xyz, const float *rest_xyz, double *w);
+/* dbse.cpp:62-77 + SOP_FaceDeform.cpp:458-473, fp32 as there: disp = sum_s float(A0[.][s]) *
+ * clamp(float(3 w_s)); if (add_delta) disp += (P - rest) * falloffradius; P = rest + disp.
+ * shapes = the UNfactored matrix of fdo_morph_shapes_matrix; clamp_lo_hi NULL = no clamping. */
+void fdo_morph_displace(const double *shapes, int64_t N, int S, const double *w, const float *clamp_lo_hi,
+                        int add_delta, float falloffradius, const float *rest_xyz, float *P_xyz);
 
 #ifdef __cplusplus
 }

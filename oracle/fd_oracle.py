@@ -61,6 +61,15 @@ class Oracle:
         L.fdo_deform.argtypes = [_f64p, C.c_int, C.c_int, _f64p, _f64p, C.c_int64, _f32p, _f32p,
                                  _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_int]
         L.fdo_deform.restype = C.c_int
+        pp = C.POINTER(_f32p)
+        L.fdo_morph_shapes_matrix.argtypes = [_f32p, pp, C.c_int64, C.c_int, _f64p]
+        L.fdo_morph_shapes_matrix.restype = None
+        L.fdo_morph_qr.argtypes = [_f64p, C.c_int64, C.c_int, _f64p]
+        L.fdo_morph_qr.restype = None
+        L.fdo_morph_weights.argtypes = [_f64p, C.c_int64, C.c_int, _f32p, _f32p, _f64p]
+        L.fdo_morph_weights.restype = None
+        L.fdo_morph_displace.argtypes = [_f64p, C.c_int64, C.c_int, _f64p, _f32p, C.c_int, C.c_float, _f32p, _f32p]
+        L.fdo_morph_displace.restype = None
 
     # -- A2
     def control_table(self, rest, deform):
@@ -124,3 +133,42 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"fdo_deform failed: {rc}")
         return P_out, fall
+
+    # -- next row N1: morph-space reprojection (src/dbse.cpp)
+    def morph_shapes_matrix(self, rest, shapes):
+        """(3N, S) column-major float64 matrix of fp32 shape deltas (returned as an F-ordered array)."""
+        rest = np.ascontiguousarray(rest, np.float32).reshape(-1, 3)
+        shapes = [np.ascontiguousarray(s, np.float32).reshape(-1, 3) for s in shapes]
+        N, S = rest.shape[0], len(shapes)
+        A = np.empty((3 * N, S), np.float64, order="F")
+        arr = (_f32p * S)(*[_ptr(s, _f32p) for s in shapes])
+        self.lib.fdo_morph_shapes_matrix(_ptr(rest, _f32p), arr, N, S, A.ctypes.data_as(_f64p))
+        return A
+
+    def morph_qr(self, A):
+        """Householder QR in Eigen's packed form; returns (QR F-ordered, tau)."""
+        QR = np.array(A, np.float64, order="F", copy=True)
+        tau = np.zeros(QR.shape[1], np.float64)
+        self.lib.fdo_morph_qr(QR.ctypes.data_as(_f64p), QR.shape[0], QR.shape[1], _ptr(tau, _f64p))
+        return QR, tau
+
+    def morph_weights(self, QR, P, rest):
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+        rest = np.ascontiguousarray(rest, np.float32).reshape(-1, 3)
+        assert QR.flags.f_contiguous and QR.shape[0] == 3 * P.shape[0]
+        w = np.zeros(QR.shape[1], np.float64)
+        self.lib.fdo_morph_weights(QR.ctypes.data_as(_f64p), P.shape[0], QR.shape[1], _ptr(P, _f32p),
+                                   _ptr(rest, _f32p), _ptr(w, _f64p))
+        return w
+
+    def morph_displace(self, shapes_matrix, w, P, rest, clamp=None, add_delta=False, falloffradius=0.0):
+        P = np.array(P, np.float32, copy=True).reshape(-1, 3)
+        rest = np.ascontiguousarray(rest, np.float32).reshape(-1, 3)
+        w = np.ascontiguousarray(w, np.float64)
+        assert shapes_matrix.flags.f_contiguous
+        cl = None if clamp is None else np.asarray(clamp, np.float32)
+        self.lib.fdo_morph_displace(shapes_matrix.ctypes.data_as(_f64p), P.shape[0], shapes_matrix.shape[1],
+                                    _ptr(w, _f64p), None if cl is None else _ptr(cl, _f32p), int(bool(add_delta)),
+                                    float(falloffradius), _ptr(rest, _f32p), _ptr(P, _f32p))
+        return P
+
