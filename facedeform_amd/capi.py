@@ -49,6 +49,10 @@ EXPORTS = [
     "fd_set_points_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
+    "fd_morph_create", "fd_morph_destroy", "fd_morph_last_error", "fd_morph_init", "fd_morph_init_dev",
+    "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
+    "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
+    "fd_morph_get_qr",
     "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error",
     "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
@@ -98,6 +102,19 @@ def load() -> C.CDLL:
     L.fd_export_model.argtypes = [vp, vp, sz, i32]; L.fd_export_model.restype = i32
     L.fd_import_model.argtypes = [vp, vp, sz, i32]; L.fd_import_model.restype = i32
     L.fd_synchronize.argtypes = [vp]; L.fd_synchronize.restype = i32
+    L.fd_morph_create.argtypes = [C.POINTER(FdConfig)]; L.fd_morph_create.restype = vp
+    L.fd_morph_destroy.argtypes = [vp]; L.fd_morph_destroy.restype = None
+    L.fd_morph_last_error.argtypes = [vp]; L.fd_morph_last_error.restype = C.c_char_p
+    L.fd_morph_init.argtypes = [vp, i64, i32, vp, C.POINTER(vp)]; L.fd_morph_init.restype = i32
+    L.fd_morph_init_dev.argtypes = [vp, i64, i32, vp, C.POINTER(vp)]; L.fd_morph_init_dev.restype = i32
+    for name in ("fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count"):
+        getattr(L, name).argtypes = [vp]; getattr(L, name).restype = i32
+    L.fd_morph_last_init_ms.argtypes = [vp]; L.fd_morph_last_init_ms.restype = C.c_float
+    L.fd_morph_compute_weights_dev.argtypes = [vp, vp, vp]; L.fd_morph_compute_weights_dev.restype = i32
+    L.fd_morph_displace_dev.argtypes = [vp, vp, vp, i32, C.c_float, vp]; L.fd_morph_displace_dev.restype = i32
+    L.fd_morph_apply.argtypes = [vp, vp, vp, i32, C.c_float, _f64p]; L.fd_morph_apply.restype = i32
+    L.fd_morph_get_weights.argtypes = [vp, _f64p]; L.fd_morph_get_weights.restype = i32
+    L.fd_morph_get_qr.argtypes = [vp, _f64p, _f64p]; L.fd_morph_get_qr.restype = i32
     L.fd_host_alloc.argtypes = [sz]; L.fd_host_alloc.restype = vp
     L.fd_host_free.argtypes = [vp]; L.fd_host_free.restype = None
     L.fd_batch_create.argtypes = [C.POINTER(vp), i32]; L.fd_batch_create.restype = vp
@@ -362,3 +379,87 @@ class Batch:
         if check:
             self._check(rc)
         return list(reps)
+
+
+class Morph:
+    """fd_morph: DirectBSEdit on the device (shapes matrix + packed Householder QR, pseudo-weights,
+    displacement).  Host arrays are numpy; *_dev take device pointers (ints)."""
+
+    def __init__(self, device: int = -1):
+        self.L = load()
+        cfg = FdConfig(C.sizeof(FdConfig), device, EVAL_FP32, 0)
+        self.h = self.L.fd_morph_create(C.byref(cfg))
+        if not self.h:
+            raise FdError(FD_E_NO_DEVICE, self.L.fd_morph_last_error(None).decode())
+        self.N = self.S = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fd_morph_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != FD_OK:
+            raise FdError(rc, self.L.fd_morph_last_error(self.h).decode())
+
+    def init(self, rest, shapes):
+        rest = np.ascontiguousarray(rest, np.float32).reshape(-1, 3)
+        shapes = [np.ascontiguousarray(s, np.float32).reshape(-1, 3) for s in shapes]
+        for s in shapes:
+            if s.shape != rest.shape:
+                raise ValueError("every shape must have the rest pose's point count")
+        arr = (C.c_void_p * max(1, len(shapes)))(*[s.ctypes.data for s in shapes])
+        self._check(self.L.fd_morph_init(self.h, rest.shape[0], len(shapes), _np_ptr(rest), arr))
+        self.N, self.S = rest.shape[0], len(shapes)
+
+    def init_dev(self, N: int, d_rest: int, d_shapes):
+        arr = (C.c_void_p * max(1, len(d_shapes)))(*d_shapes)
+        self._check(self.L.fd_morph_init_dev(self.h, N, len(d_shapes), C.c_void_p(d_rest), arr))
+        self.N, self.S = N, len(d_shapes)
+
+    @property
+    def initialised(self):
+        return bool(self.L.fd_morph_is_initialised(self.h))
+
+    @property
+    def computed(self):
+        return bool(self.L.fd_morph_is_computed(self.h))
+
+    @property
+    def last_init_ms(self):
+        return float(self.L.fd_morph_last_init_ms(self.h))
+
+    def compute_weights_dev(self, d_P: int, stream_ptr: int | None = None):
+        self._check(self.L.fd_morph_compute_weights_dev(self.h, C.c_void_p(d_P), C.c_void_p(stream_ptr or 0)))
+
+    def displace_dev(self, d_P: int, clamp=None, add_delta=False, falloffradius=0.0, stream_ptr: int | None = None):
+        cl = None if clamp is None else np.asarray(clamp, np.float32)
+        self._check(self.L.fd_morph_displace_dev(self.h, C.c_void_p(d_P), _np_ptr(cl), int(bool(add_delta)),
+                                                 float(falloffradius), C.c_void_p(stream_ptr or 0)))
+
+    def apply(self, P, clamp=None, add_delta=False, falloffradius=0.0):
+        """Weights + displacement on a host array; returns (P_out, w)."""
+        out = np.array(P, np.float32, copy=True).reshape(-1, 3)
+        cl = None if clamp is None else np.asarray(clamp, np.float32)
+        w = np.zeros(max(1, self.S), np.float64)
+        self._check(self.L.fd_morph_apply(self.h, _np_ptr(out), _np_ptr(cl), int(bool(add_delta)), float(falloffradius),
+                                          w.ctypes.data_as(_f64p)))
+        return out, w[: self.S]
+
+    def weights(self):
+        w = np.zeros(max(1, self.S), np.float64)
+        self._check(self.L.fd_morph_get_weights(self.h, w.ctypes.data_as(_f64p)))
+        return w[: self.S]
+
+    def qr(self):
+        QR = np.empty((3 * self.N, self.S), np.float64, order="F")
+        tau = np.zeros(max(1, self.S), np.float64)
+        self._check(self.L.fd_morph_get_qr(self.h, QR.ctypes.data_as(_f64p), tau.ctypes.data_as(_f64p)))
+        return QR, tau[: self.S]
+

@@ -210,6 +210,41 @@ int fd_batch_build_async(fd_batch *batch, void *hip_stream);
  * the first non-zero per-context code. */
 int fd_batch_build_result(fd_batch *batch, fd_report *reports);
 
+/* ---- morph-space reprojection (next row N1) ---------------------------------
+ * Replaces DirectBSEdit (src/dbse.hpp:7-33, src/dbse.cpp:9-87) and the loop
+ * that applies it after the RBF pass (src/SOP_FaceDeform.cpp:444-473).  The
+ * 3N x S matrix of blendshape deltas lives on the device; the per-cook passes
+ * stream over it once each (HBM-bound).
+ *   fd_morph_init            DirectBSEdit::init (dbse.cpp:9-37): deltas
+ *                            float(shape - rest) widened to fp64, Householder QR
+ *                            in Eigen's packed form.  S <= 3N.  Synchronous.
+ *   fd_morph_compute_weights_dev  computeWeights (dbse.cpp:39-60):
+ *                            w_s = sum_i float(P_i - rest_i) * QRpacked[i][s]
+ *   fd_morph_displace_dev    displaceVector + the loop at SOP :458-473:
+ *                            P = rest + sum_s delta_s * clamp(float(3 w_s))
+ *                                [+ (P - rest) * falloffradius if add_delta]
+ *                            clamp_lo_hi: host pointer to {lo, hi} or NULL.
+ *   fd_morph_apply           both, on a host array in place; w_out (S) may be NULL.
+ * hip_stream NULL = the object's own stream.  is_initialised / is_computed
+ * mirror DirectBSEdit::isInitialized / isComputed, which the cook logic tests. */
+typedef struct fd_morph fd_morph;
+fd_morph *fd_morph_create(const fd_config *cfg);
+void fd_morph_destroy(fd_morph *m);
+const char *fd_morph_last_error(const fd_morph *m);
+int fd_morph_init(fd_morph *m, int64_t N, int S, const float *rest_xyz, const float *const *shapes_xyz);
+int fd_morph_init_dev(fd_morph *m, int64_t N, int S, const float *d_rest_xyz, const float *const *d_shapes_xyz);
+int fd_morph_is_initialised(const fd_morph *m);
+int fd_morph_is_computed(const fd_morph *m);
+int fd_morph_shape_count(const fd_morph *m);
+float fd_morph_last_init_ms(const fd_morph *m);
+int fd_morph_compute_weights_dev(fd_morph *m, const float *d_P_xyz, void *hip_stream);
+int fd_morph_displace_dev(fd_morph *m, float *d_P_xyz, const float *clamp_lo_hi, int add_delta,
+                          float falloffradius, void *hip_stream);
+int fd_morph_apply(fd_morph *m, float *P_xyz, const float *clamp_lo_hi, int add_delta, float falloffradius,
+                   double *w_out);
+int fd_morph_get_weights(fd_morph *m, double *w);
+int fd_morph_get_qr(fd_morph *m, double *qr, double *tau);   /* 3N x S column-major packed QR (tests) */
+
 /* ---- host-side cook: the HDK-free mirror of cookMySop ----------------------
  * fdsop_* mirrors the SOP's parm surface (src/SOP_FaceDeform.cpp:99-137) and
  * the cook sequence (:215-489) over plain arrays standing in for GU_Detail:
