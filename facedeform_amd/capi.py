@@ -40,7 +40,10 @@ class FdsopGeo(C.Structure):
     _fields_ = [("npoints", C.c_int64), ("P", _f32p), ("tangentu", _f32p), ("tangentv", _f32p),
                 ("N", _f32p), ("dist2", _f32p), ("rest_npoints", C.c_int64),
                 ("deform_npoints", C.c_int64), ("rest_P", _f32p), ("deform_P", _f32p),
-                ("P_out", _f32p), ("fd_falloff", _f32p), ("Cd", _f32p)]
+                ("P_out", _f32p), ("fd_falloff", _f32p), ("Cd", _f32p),
+                ("nshapes", C.c_int64), ("shapes_P", C.POINTER(C.c_void_p)), ("shapes_npoints", C.POINTER(C.c_int64)),
+                ("rest", _f32p), ("rest_changed", C.c_int), ("blends_changed", C.c_int),
+                ("weights", C.POINTER(C.c_double)), ("weights_count", C.POINTER(C.c_int64))]
 
 
 # every symbol include/facedeform_hip.h declares
@@ -50,7 +53,7 @@ EXPORTS = [
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
     "fd_morph_create", "fd_morph_destroy", "fd_morph_last_error", "fd_morph_init", "fd_morph_init_dev",
-    "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
+    "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
     "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
     "fd_morph_get_qr",
     "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error",
@@ -107,8 +110,9 @@ def load() -> C.CDLL:
     L.fd_morph_last_error.argtypes = [vp]; L.fd_morph_last_error.restype = C.c_char_p
     L.fd_morph_init.argtypes = [vp, i64, i32, vp, C.POINTER(vp)]; L.fd_morph_init.restype = i32
     L.fd_morph_init_dev.argtypes = [vp, i64, i32, vp, C.POINTER(vp)]; L.fd_morph_init_dev.restype = i32
-    for name in ("fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count"):
+    for name in ("fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count"):
         getattr(L, name).argtypes = [vp]; getattr(L, name).restype = i32
+    L.fd_morph_set_rest.argtypes = [vp, vp, i32]; L.fd_morph_set_rest.restype = i32
     L.fd_morph_last_init_ms.argtypes = [vp]; L.fd_morph_last_init_ms.restype = C.c_float
     L.fd_morph_compute_weights_dev.argtypes = [vp, vp, vp]; L.fd_morph_compute_weights_dev.restype = i32
     L.fd_morph_displace_dev.argtypes = [vp, vp, vp, i32, C.c_float, vp]; L.fd_morph_displace_dev.restype = i32
@@ -422,6 +426,10 @@ class Morph:
         arr = (C.c_void_p * max(1, len(d_shapes)))(*d_shapes)
         self._check(self.L.fd_morph_init_dev(self.h, N, len(d_shapes), C.c_void_p(d_rest), arr))
         self.N, self.S = N, len(d_shapes)
+
+    def set_rest(self, rest):
+        rest = None if rest is None else np.ascontiguousarray(rest, np.float32).reshape(-1, 3)
+        self._check(self.L.fd_morph_set_rest(self.h, _np_ptr(rest), 0))
 
     @property
     def initialised(self):

@@ -93,11 +93,14 @@ __global__ __launch_bounds__(kT) void k_qr_reflector(double *x, int k, const dou
 }
 
 // scale the tail into the essential part v (in place) and form the partial dots v . a_j of every
-// trailing column j: partial[wg * ld + (j - k - 1)]
+// trailing column j: partial[wg * ld + (j - k - 1)].  Waves reduce their own column sums and park
+// them in LDS; the workgroup synchronises once at the end.
 __global__ __launch_bounds__(kT) void k_qr_dots(double *A, int64_t rows, int S, int k, const double *hh,
                                                  double *partial, int ld)
 {
-    __shared__ double scratch[4];
+    extern __shared__ double s_part[];       // [4][S - k - 1]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nt = S - k - 1;
     const double denom = hh[2];
     double *x = A + (size_t)k * rows;
     const int64_t base = (int64_t)blockIdx.x * kRowsPerWg;
@@ -119,9 +122,12 @@ __global__ __launch_bounds__(kT) void k_qr_dots(double *A, int64_t rows, int S, 
             const int64_t i = base + r * kT + threadIdx.x;
             if (i > k && i < rows) acc = fma(v[r], a[i], acc);
         }
-        acc = wg_sum(acc, scratch);
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * ld + (j - k - 1)] = acc;
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) s_part[wave * nt + (j - k - 1)] = acc;
     }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nt; q += kT)
+        partial[(size_t)blockIdx.x * ld + q] = (s_part[q] + s_part[nt + q]) + (s_part[2 * nt + q] + s_part[3 * nt + q]);
 }
 
 // tmp_j = essential^T a_j + a_j[k]; the row-k update of applyHouseholderOnTheLeft happens here too
@@ -166,29 +172,44 @@ __global__ __launch_bounds__(kT) void k_qr_apply(double *A, int64_t rows, int S,
 }
 
 // ---- per cook --------------------------------------------------------------------------------
-// dbse.cpp:39-60: partial[wg * S + s] = sum over the workgroup's rows of float(P - rest) * QR[.][s]
+// dbse.cpp:39-60: partial[wg * S + s] = sum over the workgroup's rows of float(P - rest) * QR[.][s].
+// A lane keeps its kWR deltas in registers and walks the columns; a wave reduces each column by
+// itself and parks the result in LDS, so nothing but the last step synchronises the workgroup
+// (with a workgroup-wide reduction per column this pass ran at 2.9 TB/s).
+constexpr int kWR = 8;                       // rows per lane
+constexpr int kWRows = kWR * kT;             // rows per workgroup
 __global__ __launch_bounds__(kT) void k_morph_weights(const double *QR, int64_t rows, int S, const float *P,
                                                        const float *rest, double *partial)
 {
-    __shared__ double scratch[4];
-    const int64_t base = (int64_t)blockIdx.x * kRowsPerWg;
-    double d[kR];
+    extern __shared__ double s_part[];       // [4][S]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t base = (int64_t)blockIdx.x * kWRows;
+    double d[kWR];
 #pragma unroll
-    for (int r = 0; r < kR; ++r) {
+    for (int r = 0; r < kWR; ++r) {
         const int64_t i = base + r * kT + threadIdx.x;
         d[r] = i < rows ? (double)(P[i] - rest[i]) : 0.0;          // fp32 subtraction, then widened (:49-51)
     }
+    const bool full = base + kWRows <= rows;
     for (int s = 0; s < S; ++s) {
-        const double *q = QR + (size_t)s * rows;
+        const double *q = QR + (size_t)s * rows + base + threadIdx.x;
+        double v[kWR];
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < kWR; ++r) v[r] = __builtin_nontemporal_load(q + r * kT);
+        } else {
+#pragma unroll
+            for (int r = 0; r < kWR; ++r) v[r] = base + r * kT + threadIdx.x < rows ? q[r * kT] : 0.0;
+        }
         double acc = 0.0;
 #pragma unroll
-        for (int r = 0; r < kR; ++r) {
-            const int64_t i = base + r * kT + threadIdx.x;
-            if (i < rows) acc = fma(d[r], q[i], acc);
-        }
-        acc = wg_sum(acc, scratch);
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * S + s] = acc;
+        for (int r = 0; r < kWR; ++r) acc = fma(d[r], v[r], acc);
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) s_part[wave * S + s] = acc;
     }
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += kT)
+        partial[(size_t)blockIdx.x * S + s] = (s_part[s] + s_part[S + s]) + (s_part[2 * S + s] + s_part[3 * S + s]);
 }
 
 __global__ __launch_bounds__(kT) void k_morph_weights_reduce(const double *partial, int npartial, int S, double *w)
@@ -242,6 +263,10 @@ struct fd_morph {
     bool initialised = false, computed = false;
     hipStream_t stream = nullptr;
     float *d_rest = nullptr, *d_S32 = nullptr, *d_stage = nullptr, *d_P = nullptr;
+    // the `rest` point attribute the cook passes use (SOP_FaceDeform.cpp:178-184,445); NULL: the
+    // init rest pose (they differ only when input 0 carries its own rest attribute)
+    float *d_rest_attr = nullptr;
+    bool use_rest_attr = false;
     double *d_QR = nullptr, *d_tau = nullptr, *d_w = nullptr, *d_partial = nullptr, *d_hh = nullptr, *d_tmp = nullptr;
     size_t cap_entries = 0;       // 3N * S capacity of d_QR / d_S32
     int64_t cap_N = 0;
@@ -286,10 +311,11 @@ static int morph_reserve(fd_morph *m, int64_t N, int S)
 {
     int rc;
     const size_t rows = 3 * (size_t)N;
-    const size_t nwg = (rows + kRowsPerWg - 1) / kRowsPerWg;
+    const size_t nwg = (rows + kWRows - 1) / kWRows;        // the finer of the two row partitions
     if (N > m->cap_N) {
         if ((rc = mrealloc(m, &m->d_rest, rows)) || (rc = mrealloc(m, &m->d_stage, rows)) ||
             (rc = mrealloc(m, &m->d_P, rows))) return rc;
+        if (m->d_rest_attr) { (void)hipFree(m->d_rest_attr); m->d_rest_attr = nullptr; }
         m->cap_N = N;
     }
     if (rows * (size_t)S > m->cap_entries) {
@@ -320,13 +346,15 @@ static int morph_factor(fd_morph *m)
         hipLaunchKernelGGL(k_qr_reflector, dim3(1), dim3(kT), 0, st, x, k, m->d_partial, (int)nwg, m->d_hh, m->d_tau);
         if (k + 1 < S) {
             const int nt = S - k - 1;
-            hipLaunchKernelGGL(k_qr_dots, dim3(nwg), dim3(kT), 0, st, m->d_QR, rows, S, k, m->d_hh, m->d_partial, nt);
+            hipLaunchKernelGGL(k_qr_dots, dim3(nwg), dim3(kT), sizeof(double) * 4 * (size_t)nt, st, m->d_QR, rows, S, k,
+                               m->d_hh, m->d_partial, nt);
             hipLaunchKernelGGL(k_qr_dots_reduce, dim3(nt), dim3(kT), 0, st, m->d_QR, rows, k, m->d_hh, m->d_partial,
                                (int)nwg, nt, m->d_tmp);
             hipLaunchKernelGGL(k_qr_apply, dim3(nwg), dim3(kT), 0, st, m->d_QR, rows, S, k, m->d_hh, m->d_tmp);
         } else {
             // last column: only its own tail is scaled
-            hipLaunchKernelGGL(k_qr_dots, dim3(nwg), dim3(kT), 0, st, m->d_QR, rows, S, k, m->d_hh, m->d_partial, 1);
+            hipLaunchKernelGGL(k_qr_dots, dim3(nwg), dim3(kT), sizeof(double) * 4, st, m->d_QR, rows, S, k, m->d_hh,
+                               m->d_partial, 1);
         }
     }
     FDM_HIP(m, hipGetLastError());
@@ -376,7 +404,7 @@ void fd_morph_destroy(fd_morph *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    void *bufs[] = {m->d_rest, m->d_S32, m->d_stage, m->d_P, m->d_QR, m->d_tau, m->d_w, m->d_partial, m->d_hh, m->d_tmp};
+    void *bufs[] = {m->d_rest_attr, m->d_rest, m->d_S32, m->d_stage, m->d_P, m->d_QR, m->d_tau, m->d_w, m->d_partial, m->d_hh, m->d_tmp};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
@@ -396,6 +424,7 @@ static int morph_init_common(fd_morph *m, int64_t N, int S, const float *rest, c
     if (rc) return rc;
     m->N = N; m->S = S;
     m->initialised = false; m->computed = false;
+    m->use_rest_attr = false;
     const size_t rows = 3 * (size_t)N, bytes = rows * sizeof(float);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     hipStream_t st = m->stream;
@@ -429,6 +458,24 @@ int fd_morph_init_dev(fd_morph *m, int64_t N, int S, const float *d_rest_xyz, co
     return morph_init_common(m, N, S, d_rest_xyz, d_shapes_xyz, true);
 }
 
+int fd_morph_set_rest(fd_morph *m, const float *rest_xyz, int on_device)
+{
+    if (!m) return FD_E_INVALID;
+    if (!m->initialised) { merr(m, "fd_morph_set_rest: fd_morph_init has not succeeded"); return FD_E_NOT_BUILT; }
+    if (!rest_xyz) { m->use_rest_attr = false; return FD_OK; }
+    FDM_HIP(m, hipSetDevice(m->device));
+    const size_t rows = 3 * (size_t)m->N;
+    if (!m->d_rest_attr) {
+        int rc = mrealloc(m, &m->d_rest_attr, 3 * (size_t)m->cap_N);
+        if (rc) return rc;
+    }
+    FDM_HIP(m, hipMemcpyAsync(m->d_rest_attr, rest_xyz, rows * sizeof(float),
+                              on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->stream));
+    if (!on_device) FDM_HIP(m, hipStreamSynchronize(m->stream));
+    m->use_rest_attr = true;
+    return FD_OK;
+}
+
 int fd_morph_is_initialised(const fd_morph *m) { return m && m->initialised && m->N > 0; }   // dbse.hpp:16 isInitialized
 int fd_morph_is_computed(const fd_morph *m) { return m && m->computed; }                      // dbse.hpp:18 isComputed
 int fd_morph_shape_count(const fd_morph *m) { return m ? m->S : 0; }
@@ -441,9 +488,10 @@ int fd_morph_compute_weights_dev(fd_morph *m, const float *d_P_xyz, void *hip_st
     FDM_HIP(m, hipSetDevice(m->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : m->stream;
     const int64_t rows = 3 * m->N;
-    const unsigned nwg = (unsigned)((rows + kRowsPerWg - 1) / kRowsPerWg);
+    const unsigned nwg = (unsigned)((rows + kWRows - 1) / kWRows);
     if (m->S > 0) {
-        hipLaunchKernelGGL(k_morph_weights, dim3(nwg), dim3(kT), 0, st, m->d_QR, rows, m->S, d_P_xyz, m->d_rest, m->d_partial);
+        hipLaunchKernelGGL(k_morph_weights, dim3(nwg), dim3(kT), sizeof(double) * 4 * (size_t)m->S, st, m->d_QR, rows, m->S,
+                           d_P_xyz, m->use_rest_attr ? m->d_rest_attr : m->d_rest, m->d_partial);
         hipLaunchKernelGGL(k_morph_weights_reduce, dim3(m->S), dim3(kT), 0, st, m->d_partial, (int)nwg, m->S, m->d_w);
     }
     FDM_HIP(m, hipGetLastError());
@@ -461,7 +509,8 @@ int fd_morph_displace_dev(fd_morph *m, float *d_P_xyz, const float *clamp_lo_hi,
     const unsigned g = (unsigned)((m->N + kT - 1) / kT);
     hipLaunchKernelGGL(k_morph_displace, dim3(g), dim3(kT), sizeof(float) * (size_t)(m->S ? m->S : 1), st, m->d_S32, m->N,
                        m->S, m->d_w, clamp_lo_hi ? clamp_lo_hi[0] : 0.f, clamp_lo_hi ? clamp_lo_hi[1] : 0.f,
-                       clamp_lo_hi ? 1 : 0, add_delta ? 1 : 0, falloffradius, m->d_rest, d_P_xyz);
+                       clamp_lo_hi ? 1 : 0, add_delta ? 1 : 0, falloffradius, m->use_rest_attr ? m->d_rest_attr : m->d_rest,
+                       d_P_xyz);
     FDM_HIP(m, hipGetLastError());
     return FD_OK;
 }

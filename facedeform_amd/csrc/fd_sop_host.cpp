@@ -7,8 +7,10 @@
 // (hdk/SOP_FaceDeformHip.cpp) gathers GU_Detail attributes into an fdsop_geo
 // and calls fdsop_cook; the tests drive the same entry points through ctypes.
 //
-// Out of scope here, as in SURVEY.md section 2: ProximityCapture (its product,
-// the per-vertex dist2 array, is an input) and the DirectBSEdit morph pass.
+// The morph-space pass (setupBlends :175-213, the loop at :444-482, DirectBSEdit in
+// src/dbse.cpp) runs on the device through fd_morph_*.  Out of scope here, as in
+// ProximityCapture (its product, the per-vertex dist2 array,
+// is an input).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +74,8 @@ T sys_max(T a, T b) { return a > b ? a : b; }
 struct fdsop_node {
     fd_config cfg{};
     fd_ctx *engine = nullptr;
+    fd_morph *morph = nullptr;        // m_direct_blends (:SOP_FaceDeform.hpp), lives as long as the node
+    int morph_device = -2;
     double fval[kNumParms][2];
     std::string sval[kNumParms];
     std::string messages;
@@ -119,6 +123,7 @@ void fdsop_destroy(fdsop_node *node)
 {
     if (!node) return;
     if (node->engine) fd_destroy(node->engine);
+    if (node->morph) fd_morph_destroy(node->morph);
     delete node;
 }
 
@@ -238,8 +243,42 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     if (tangent_disp && !do_tangent_disp)
         node->add(FDSOP_WARNING, "Append PolyFrameSOP and enable tangent[u/v] and N attribute to allow tangent displacement.");
 
-    // :325-329 -- inputs 3.. (blendshapes) are not part of this boundary
-    if (morph_space) node->add(FDSOP_WARNING, "No blendshapes found. Ignoring morphspace deformation.");
+    // :323-329 -- morph space needs blendshapes on inputs 3..; setupBlends (:175-213)
+    const bool have_blends = geo->nshapes > 0 && geo->shapes_P && geo->shapes_npoints;
+    if (geo->weights_count) *geo->weights_count = 0;
+    // the `rest` attribute: input 0's own unless the rest pose changed or there is none, in
+    // which case it is a copy of the incoming P (:178-184)
+    const float *rest_attr = (geo->rest && !geo->rest_changed) ? geo->rest : geo->P;
+    bool morph_inited_this_cook = false;
+    if (morph_space && have_blends) {
+        if (!node->morph || node->morph_device != device) {
+            if (node->morph) { fd_morph_destroy(node->morph); node->morph = nullptr; }
+            fd_config mcfg = node->cfg;
+            mcfg.struct_size = (int)sizeof(fd_config);
+            mcfg.device = device;
+            node->morph = fd_morph_create(&mcfg);
+            node->morph_device = device;
+        }
+        if (node->morph && (geo->blends_changed || !fd_morph_is_initialised(node->morph))) {
+            std::vector<const float *> shapes;
+            bool mismatch = false;
+            for (int64_t sidx = 0; sidx < geo->nshapes; ++sidx) {
+                if (geo->shapes_npoints[sidx] != geo->npoints || !geo->shapes_P[sidx]) { mismatch = true; continue; }
+                shapes.push_back(geo->shapes_P[sidx]);
+            }
+            if (mismatch)   // :201-203
+                node->add(FDSOP_WARNING, "Some blendshapes don't match rest pose point count. Ignoring them.");
+            // DirectBSEdit::init measures the shapes against the mesh's CURRENT P (dbse.cpp:22), not
+            // against the rest attribute
+            if (geo->npoints <= 0 ||
+                fd_morph_init(node->morph, geo->npoints, (int)shapes.size(), geo->P, shapes.empty() ? nullptr : shapes.data()) != FD_OK)
+                node->add(FDSOP_WARNING, "Can't proceed with morph space deformation. Ingoring it.");   // :209-211
+            else
+                morph_inited_this_cook = true;
+        }
+    } else if (morph_space) {
+        node->add(FDSOP_WARNING, "No blendshapes found. Ignoring morphspace deformation.");
+    }
 
     // engine (re)creation when the device or the precision parm changed
     if (!node->engine || node->engine_precision != precision || node->engine_device != device) {
@@ -316,6 +355,39 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
         std::string t = std::string("GPU deformation failed: ") + fd_last_error(ctx);
         node->add(FDSOP_ERROR, t.c_str());
         pass.armed = true;
+        return node->severity;
+    }
+
+    // :444-482 -- morph-space reprojection of the deformed mesh
+    if (morph_space && have_blends && node->morph && fd_morph_is_initialised(node->morph)) {
+        // :448-450: the weights are computed only while isComputed() is false, i.e. on the first
+        // cook after DirectBSEdit::init; every later cook with unchanged blendshapes takes the
+        // warning branch below.  Kept as the reference has it.
+        bool weights_done = false;
+        const int S = fd_morph_shape_count(node->morph);
+        if (!fd_morph_is_computed(node->morph)) {
+            const int dofalloff = (int)node->fval[find_parm("dofalloff")][0];
+            const int doclampweight = (int)node->fval[find_parm("doclampweight")][0];
+            const float falloffradius = (float)node->fval[find_parm("falloffradius")][0];
+            const float weightrange[2] = {(float)node->fval[find_parm("weightrange")][0],
+                                          (float)node->fval[find_parm("weightrange")][1]};
+            std::vector<double> w((size_t)(S > 0 ? S : 1));
+            // the engine already holds this cook's P as its rest pose when it was initialised in
+            // this cook and input 0 has no rest attribute of its own; otherwise send the attribute
+            const bool same_rest = morph_inited_this_cook && rest_attr == geo->P;
+            int mrc = fd_morph_set_rest(node->morph, same_rest ? nullptr : rest_attr, 0);
+            // computeWeights (dbse.cpp:39-60) + the displacement loop (:458-473), P_out in place
+            if (mrc == FD_OK)
+                mrc = fd_morph_apply(node->morph, geo->P_out, doclampweight ? weightrange : nullptr,
+                                     dofalloff && falloffradius != 0.f, falloffradius, w.data());
+            weights_done = mrc == FD_OK;
+            if (weights_done) {   // :474-481, the detail array attribute `weights`
+                if (geo->weights) memcpy(geo->weights, w.data(), sizeof(double) * (size_t)S);
+                if (geo->weights_count) *geo->weights_count = S;
+            }
+        }
+        if (!weights_done)
+            node->add(FDSOP_WARNING, "Can't compute weights for morphspace deformation. Ingoring it.");   // :452
     }
     return node->severity;
 }

@@ -22,6 +22,7 @@ class CookResult:
     P: np.ndarray | None = None
     fd_falloff: np.ndarray | None = None
     Cd: np.ndarray | None = None
+    weights: np.ndarray | None = None              # the detail array `weights` of the morph pass
 
     @property
     def errors(self):
@@ -102,16 +103,17 @@ class FaceDeformSOP:
 
     # -- cook
     def cook(self, mesh_P, rest_P, deform_P, dist2=None, tangentu=None, tangentv=None, N=None,
-             out_P=None, out_falloff=None, want_Cd=True) -> CookResult:
+             out_P=None, out_falloff=None, want_Cd=True, shapes=None, rest=None, rest_changed=False,
+             blends_changed=False) -> CookResult:
         """out_P / out_falloff: caller-owned result arrays (e.g. page-locked ones from
         capi.host_array, as the HDK wrapper keeps them): with every mesh array page-locked the
         evaluation runs in place over the host link.  want_Cd=False leaves the Cd fill to the
         attribute default, as the wrapper does."""
         f32 = np.float32
         P = np.ascontiguousarray(mesh_P, f32).reshape(-1, 3)
-        rest = np.ascontiguousarray(rest_P, f32).reshape(-1, 3)
+        rig_rest = np.ascontiguousarray(rest_P, f32).reshape(-1, 3)
         deform = np.ascontiguousarray(deform_P, f32).reshape(-1, 3)
-        keep = [P, rest, deform]
+        keep = [P, rig_rest, deform]
 
         def opt(a, cols):
             if a is None:
@@ -133,9 +135,24 @@ class FaceDeformSOP:
         def ptr(a):
             return None if a is None else a.ctypes.data_as(fp)
 
-        geo = capi.FdsopGeo(P.shape[0], ptr(P), ptr(tu), ptr(tv), ptr(nn), ptr(d2), rest.shape[0],
-                            deform.shape[0], ptr(rest), ptr(deform), ptr(P_out), ptr(fall), ptr(Cd))
+        # inputs 3..: blendshapes of the morph-space pass; `rest` = input 0's rest attribute
+        shape_arrs = [np.ascontiguousarray(sh, f32).reshape(-1, 3) for sh in (shapes or [])]
+        keep.extend(shape_arrs)
+        ns = len(shape_arrs)
+        sh_ptrs = (C.c_void_p * max(1, ns))(*[a.ctypes.data for a in shape_arrs])
+        sh_counts = (C.c_int64 * max(1, ns))(*[a.shape[0] for a in shape_arrs])
+        rest_attr = opt(rest, 3)
+        weights = np.zeros(max(1, ns), np.float64)
+        wcount = C.c_int64(0)
+        geo = capi.FdsopGeo(P.shape[0], ptr(P), ptr(tu), ptr(tv), ptr(nn), ptr(d2), rig_rest.shape[0],
+                            deform.shape[0], ptr(rig_rest), ptr(deform), ptr(P_out), ptr(fall), ptr(Cd),
+                            ns, C.cast(sh_ptrs, C.POINTER(C.c_void_p)) if ns else None,
+                            C.cast(sh_counts, C.POINTER(C.c_int64)) if ns else None, ptr(rest_attr),
+                            int(bool(rest_changed)), int(bool(blends_changed)),
+                            weights.ctypes.data_as(C.POINTER(C.c_double)), C.pointer(wcount))
         sev = self.L.fdsop_cook(self.node, C.byref(geo))
         text = self.L.fdsop_messages(self.node).decode()
         msgs = [tuple(line.split("\t", 1)) for line in text.splitlines() if "\t" in line]
-        return CookResult(sev, msgs, P_out, fall, Cd)
+        res = CookResult(sev, msgs, P_out, fall, Cd)
+        res.weights = weights[: wcount.value].copy()
+        return res

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 1
+#define FD_ABI_VERSION 2
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -233,6 +233,11 @@ void fd_morph_destroy(fd_morph *m);
 const char *fd_morph_last_error(const fd_morph *m);
 int fd_morph_init(fd_morph *m, int64_t N, int S, const float *rest_xyz, const float *const *shapes_xyz);
 int fd_morph_init_dev(fd_morph *m, int64_t N, int S, const float *d_rest_xyz, const float *const *d_shapes_xyz);
+/* The `rest` point attribute the per-cook passes measure against
+ * (SOP_FaceDeform.cpp:178-184, 445-447).  Default (or NULL): the rest pose
+ * given to fd_morph_init -- what setupBlends stores when input 0 has no rest
+ * attribute of its own.  Reset by fd_morph_init. */
+int fd_morph_set_rest(fd_morph *m, const float *rest_xyz, int on_device);
 int fd_morph_is_initialised(const fd_morph *m);
 int fd_morph_is_computed(const fd_morph *m);
 int fd_morph_shape_count(const fd_morph *m);
@@ -271,6 +276,15 @@ typedef struct fdsop_geo {
     float *P_out;          /* npoints x 3 */
     float *fd_falloff;     /* npoints, or NULL */
     float *Cd;             /* npoints x 3, or NULL (always white, :386-388) */
+    /* inputs 3..: blendshapes of the morph-space pass (:175-213, 444-482); all optional */
+    int64_t nshapes;                 /* connected inputs beyond the deformed rig */
+    const float *const *shapes_P;    /* nshapes arrays, shapes_npoints[s] x 3 each */
+    const int64_t *shapes_npoints;   /* a count different from npoints drops the shape with a warning (:200-204) */
+    const float *rest;               /* input 0's `rest` point attribute (npoints x 3) or NULL (:178) */
+    int rest_changed;                /* what checkChangedSourceFlags(0) reports: the rest pose changed (:180-184) */
+    int blends_changed;              /* ... and for any of inputs 3.. (:186-194) */
+    double *weights;                 /* out: the detail array `weights` (:474-481), room for nshapes, or NULL */
+    int64_t *weights_count;          /* out: entries written; 0 when the morph pass did not run; or NULL */
 } fdsop_geo;
 
 fdsop_node *fdsop_create(const fd_config *cfg);

@@ -28,13 +28,13 @@ def test_header_symbols_all_exported(hip_lib):
 
 
 def test_abi_version(hip_lib):
-    assert hip_lib.fd_abi_version() == 1
+    assert hip_lib.fd_abi_version() == 2   # 2: fdsop_geo grew the morph-space inputs
 
 
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.FdConfig) == 32
     assert C.sizeof(capi.FdReport) == 32
-    assert C.sizeof(capi.FdsopGeo) == 13 * 8
+    assert C.sizeof(capi.FdsopGeo) == 20 * 8   # 13 mesh/rig fields + 7 morph-space fields (two ints share a slot)
 
 
 @pytest.mark.skipif(HAVE_GPU, reason="checks the no-device failure mode")

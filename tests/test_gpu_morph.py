@@ -138,3 +138,63 @@ def test_full_size_properties(hip_lib):
     assert np.array_equal(QR, QR2) and np.array_equal(tau, tau2)
     print(f"QR of {3 * N} x {S}: {m.last_init_ms:.1f} ms")
     m.close(); m2.close()
+
+
+def test_cook_with_morph_space_follows_the_reference_sequence(hip_lib, oracle):
+    """fdsop_cook with blendshapes on inputs 3..: setupBlends (:175-213), RBF pass, then the
+    morph-space loop (:444-482) -- against the oracle chaining the same steps; plus the
+    reference's messages and its isComputed() state machine (weights only on the first cook
+    after the blendshapes were (re)initialised)."""
+    from facedeform_amd.sop import FaceDeformSOP
+    from oracle import fd_oracle as fo
+    rng = np.random.default_rng(9)
+    N, M, S = 20_011, 48, 9
+    P = synth.head_mesh(N)
+    rig_rest = synth.control_points(M, "head")
+    rig_deform = synth.deformed_rig(rig_rest, 1)
+    shapes = [(P + (0.08 * rng.normal(size=(N, 3)) * (rng.random((N, 1)) < 0.5)).astype(np.float32)).astype(np.float32)
+              for _ in range(S)]
+    node = FaceDeformSOP()
+    node.set("kernel", 1)
+    node.set("morphspace", 1)
+    node.set("doclampweight", 1)
+    node.set("weightrange", -0.01, 0)
+    node.set("weightrange", 0.02, 1)
+    node.set("dofalloff", 1)
+    node.set("falloffradius", 0.25)
+    # no blendshapes connected: the reference's warning, plain RBF result
+    res0 = node.cook(P, rig_rest, rig_deform)
+    assert "No blendshapes found. Ignoring morphspace deformation." in res0.warnings
+    # first cook with blendshapes: init + weights + displacement
+    res = node.cook(P, rig_rest, rig_deform, shapes=shapes, blends_changed=True)
+    assert not [w for w in res.warnings if "morph" in w.lower() or "weights" in w.lower()], res.warnings
+    assert res.weights.shape == (S,)
+    # oracle: RBF deform, then DirectBSEdit on the deformed mesh with rest = incoming P
+    table = oracle.control_table(rig_rest, rig_deform)
+    rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [0.0], 0)
+    assert rc == 0 and tt == 1
+    P_def, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    A = oracle.morph_shapes_matrix(P, shapes)
+    QR, _ = oracle.morph_qr(A)
+    w_ref = oracle.morph_weights(QR, P_def, P)
+    # the weights see the fp32 RBF displacement (1e-5 relative); they are sums of O(1e-2) terms
+    assert np.abs(res.weights - w_ref).max() <= 2e-5 * max(1.0, np.abs(w_ref).max())
+    assert (np.abs(3 * w_ref) > 0.02).any(), "the clamp must be exercised"
+    ref = oracle.morph_displace(A, res.weights, res0.P, P, (-0.01, 0.02), True, 0.25)
+    assert np.array_equal(res.P, ref)                         # same weights, same fp32 order
+    ref2 = oracle.morph_displace(A, w_ref, P_def, P, (-0.01, 0.02), True, 0.25)
+    assert _disp_ratio(res.P, ref2, P, 2e-5) <= 1.0
+    # second cook, blendshapes unchanged: isComputed() is still true -> the warning branch (:448-453)
+    res2 = node.cook(P, rig_rest, rig_deform, shapes=shapes)
+    assert "Can't compute weights for morphspace deformation. Ingoring it." in res2.warnings
+    assert res2.weights.size == 0 and np.array_equal(res2.P, res0.P)
+    # a blendshape with another point count is dropped with the reference's warning (:200-204)
+    res3 = node.cook(P, rig_rest, rig_deform, shapes=shapes[:3] + [shapes[3][:100]], blends_changed=True)
+    assert "Some blendshapes don't match rest pose point count. Ignoring them." in res3.warnings
+    assert res3.weights.shape == (3,)
+    # input 0 carrying its own rest attribute: weights and the final position use it (:445-447, 471)
+    own_rest = (P + np.float32(0.001)).astype(np.float32)
+    res4 = node.cook(P, rig_rest, rig_deform, shapes=shapes, blends_changed=True, rest=own_rest)
+    w4 = oracle.morph_weights(QR, res0.P, own_rest)
+    assert np.abs(res4.weights - w4).max() <= 1e-9 * max(1.0, np.abs(w4).max())
+    assert np.array_equal(res4.P, oracle.morph_displace(A, res4.weights, res0.P, own_rest, (-0.01, 0.02), True, 0.25))
