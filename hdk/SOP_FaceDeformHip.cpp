@@ -13,10 +13,12 @@
 // part of the boundary yet.
 #include <UT/UT_DSOVersion.h>
 
+#include <GA/GA_AIFNumericArray.h>
 #include <GA/GA_Handle.h>
 #include <GA/GA_PageHandle.h>
 #include <GA/GA_SplittableRange.h>
 #include <GU/GU_Detail.h>
+#include <UT/UT_Array.h>
 #include <OP/OP_AutoLockInputs.h>
 #include <OP/OP_Operator.h>
 #include <OP/OP_OperatorTable.h>
@@ -24,6 +26,7 @@
 #include <SOP/SOP_Node.h>
 
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "facedeform_hip.h"
@@ -221,6 +224,41 @@ protected:
         geo.P_out = Pout.data();
         geo.fd_falloff = falloff.data();
         geo.Cd = nullptr;      // the attribute is created with white defaults below (:386-388)
+
+        // inputs 3..: blendshapes of the morph-space pass (reference setupBlends, :175-213)
+        std::vector<const float *> shapePtrs;
+        std::vector<int64_t> shapeCounts;
+        std::vector<double> weights;
+        int64_t weightsCount = 0;
+        int restChanged = 0, blendsChanged = 0;
+        if (evalInt("morphspace", 0, t) && nConnectedInputs() > 3) {
+            checkChangedSourceFlags(0, context, &restChanged);
+            const unsigned nshapes = nConnectedInputs() - 3;
+            if (myShapes.size() < nshapes) myShapes.resize(nshapes);
+            for (unsigned i = 3; i < nConnectedInputs(); ++i) {
+                int changed = 0;
+                checkChangedSourceFlags(i, context, &changed);
+                blendsChanged |= changed;
+                const GU_Detail *shape = inputGeo(i);
+                PinnedF &buf = *myShapes[i - 3].get(this);
+                // the arrays are only read when the engine (re)initialises; gather them then
+                if (changed || buf.empty()) gatherV3(shape, shape->getP(), buf);
+                shapePtrs.push_back(buf.data());
+                shapeCounts.push_back((int64_t)shape->getNumPoints());
+            }
+            if (const GA_Attribute *aRest = gdp->findFloatTuple(GA_ATTRIB_POINT, "rest", 3)) {
+                gatherV3(gdp, aRest, myRestAttr);
+                geo.rest = myRestAttr.data();
+            }
+            weights.resize(nshapes);
+            geo.nshapes = (int64_t)nshapes;
+            geo.shapes_P = shapePtrs.data();
+            geo.shapes_npoints = shapeCounts.data();
+            geo.rest_changed = restChanged;
+            geo.blends_changed = blendsChanged;
+            geo.weights = weights.data();
+            geo.weights_count = &weightsCount;
+        }
         fdsop_cook(myNode, &geo);
 
         // replay the engine's messages through the node's own channels
@@ -241,6 +279,16 @@ protected:
         GA_Offset o;
         GA_FOR_ALL_PTOFF(gdp, o) hf.set(o, falloff[(size_t)gdp->pointIndex(o)]);
         (void)hc;
+        if (weightsCount > 0) {
+            // :474-481, the detail array attribute `weights`
+            GA_Attribute *wAttrib = gdp->addFloatArray(GA_ATTRIB_DETAIL, "weights", 1);
+            const GA_AIFNumericArray *wAif = wAttrib->getAIFNumericArray();
+            UT_FprealArray arr;
+            arr.setSize(weightsCount);
+            for (int64_t i = 0; i < weightsCount; ++i) arr(i) = weights[(size_t)i];
+            wAif->set(wAttrib, 0, arr);
+            wAttrib->bumpDataId();
+        }
         gdp->getP()->bumpDataId();
         return error();
     }
@@ -251,7 +299,13 @@ private:
     const GA_Attribute *captureDistanceAttribute() const { return nullptr; }
 
     fdsop_node *myNode = nullptr;
-    PinnedF myP, myRestP, myDeformP, myTu, myTv, myNn, myDist2, myPout, myFalloff;
+    PinnedF myP, myRestP, myDeformP, myTu, myTv, myNn, myDist2, myPout, myFalloff, myRestAttr;
+    // one gather buffer per blendshape input (PinnedF is not movable: held by pointer)
+    struct ShapeSlot {
+        std::unique_ptr<PinnedF> p;
+        PinnedF *get(SOP_FaceDeformHip *) { if (!p) p.reset(new PinnedF()); return p.get(); }
+    };
+    std::vector<ShapeSlot> myShapes;
 };
 
 }  // namespace fdhip
