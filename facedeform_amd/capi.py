@@ -52,6 +52,7 @@ EXPORTS = [
     "fd_set_points_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
+    "fd_capture_dist2", "fd_capture_dist2_dev",
     "fd_morph_create", "fd_morph_destroy", "fd_morph_last_error", "fd_morph_init", "fd_morph_init_dev",
     "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
     "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
@@ -105,6 +106,8 @@ def load() -> C.CDLL:
     L.fd_export_model.argtypes = [vp, vp, sz, i32]; L.fd_export_model.restype = i32
     L.fd_import_model.argtypes = [vp, vp, sz, i32]; L.fd_import_model.restype = i32
     L.fd_synchronize.argtypes = [vp]; L.fd_synchronize.restype = i32
+    L.fd_capture_dist2.argtypes = [vp, i64, vp, vp, i32, vp, C.c_float, i32, vp]; L.fd_capture_dist2.restype = i32
+    L.fd_capture_dist2_dev.argtypes = [vp, i64, vp, vp, i32, vp, C.c_float, i32, vp]; L.fd_capture_dist2_dev.restype = i32
     L.fd_morph_create.argtypes = [C.POINTER(FdConfig)]; L.fd_morph_create.restype = vp
     L.fd_morph_destroy.argtypes = [vp]; L.fd_morph_destroy.restype = None
     L.fd_morph_last_error.argtypes = [vp]; L.fd_morph_last_error.restype = C.c_char_p
@@ -257,6 +260,21 @@ class Engine:
         self._check(self.L.fd_deform(self.ctx, N, _np_ptr(P_in), _np_ptr(P_out), _np_ptr(dist2), _np_ptr(falloff),
                                      _np_ptr(tu), _np_ptr(tv), _np_ptr(nr), float(radius2),
                                      float(falloffrate)))
+
+    def capture_dist2(self, P, triangles, radius2, dofalloff=True, mask=None):
+        """ProximityCapture's per-point squared distance to the rig surface (host arrays)."""
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+        tri = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        out = np.empty(P.shape[0], np.float32)
+        self._check(self.L.fd_capture_dist2(self.ctx, P.shape[0], _np_ptr(P), _np_ptr(m), tri.shape[0], _np_ptr(tri),
+                                            float(radius2), int(bool(dofalloff)), _np_ptr(out)))
+        return out
+
+    def capture_dist2_dev(self, N: int, d_P: int, d_mask: int, T: int, d_tri: int, radius2, dofalloff, d_dist2: int):
+        vp = C.c_void_p
+        self._check(self.L.fd_capture_dist2_dev(self.ctx, N, vp(d_P), vp(d_mask or None), T, vp(d_tri or None),
+                                                float(radius2), int(bool(dofalloff)), vp(d_dist2)))
 
     def deform_dev(self, N: int, d_P_in: int, d_P_out: int, d_dist2: int = 0, d_falloff: int = 0,
                    d_tu: int = 0, d_tv: int = 0, d_nrm: int = 0, radius2=1.0, falloffrate=1.0):

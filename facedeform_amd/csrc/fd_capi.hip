@@ -618,6 +618,56 @@ int fd_deform(fd_ctx *ctx, int64_t N, const float *P_in, float *P_out, const flo
     return FD_OK;
 }
 
+// ---- dist2 producer (next row N2; kernel in fd_capture.hip) -----------------------------------
+int fd_capture_dist2_dev(fd_ctx *ctx, int64_t N, const float *d_P, const unsigned char *d_mask, int T,
+                         const float *d_tri_xyz, float radius2, int dofalloff, float *d_dist2)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (N < 0 || T < 0 || (N > 0 && (!d_P || !d_dist2)) || (T > 0 && !d_tri_xyz)) {
+        set_err(ctx, "fd_capture_dist2: bad sizes or NULL arrays");
+        return FD_E_INVALID;
+    }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    FD_HIP(ctx, launch_capture_dist2(d_P, N, d_mask, d_tri_xyz, T, radius2, dofalloff, d_dist2, cur_stream(ctx)));
+    return FD_OK;
+}
+
+int fd_capture_dist2(fd_ctx *ctx, int64_t N, const float *P, const unsigned char *mask, int T, const float *tri_xyz,
+                     float radius2, int dofalloff, float *dist2)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (N < 0 || T < 0 || (N > 0 && (!P || !dist2)) || (T > 0 && !tri_xyz)) {
+        set_err(ctx, "fd_capture_dist2: bad sizes or NULL arrays");
+        return FD_E_INVALID;
+    }
+    if (N == 0) return FD_OK;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    hipStream_t s = cur_stream(ctx);
+    float *d_P = nullptr, *d_tri = nullptr, *d_out = nullptr;
+    unsigned char *d_mask = nullptr;
+    auto cleanup = [&]() {
+        if (d_P) (void)hipFree(d_P);
+        if (d_tri) (void)hipFree(d_tri);
+        if (d_out) (void)hipFree(d_out);
+        if (d_mask) (void)hipFree(d_mask);
+    };
+    hipError_t e = hipMalloc((void **)&d_P, sizeof(float) * 3 * (size_t)N);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(float) * (size_t)N);
+    if (e == hipSuccess && T > 0) e = hipMalloc((void **)&d_tri, sizeof(float) * 9 * (size_t)T);
+    if (e == hipSuccess && mask) e = hipMalloc((void **)&d_mask, (size_t)N);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_P, P, sizeof(float) * 3 * (size_t)N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && T > 0) e = hipMemcpyAsync(d_tri, tri_xyz, sizeof(float) * 9 * (size_t)T, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && mask) e = hipMemcpyAsync(d_mask, mask, (size_t)N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_capture_dist2(d_P, N, d_mask, d_tri, T, radius2, dofalloff, d_out, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dist2, d_out, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) { set_err(ctx, "fd_capture_dist2 failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    return FD_OK;
+}
+
 void *fd_host_alloc(size_t bytes)
 {
     void *p = nullptr;

@@ -210,6 +210,22 @@ int fd_batch_build_async(fd_batch *batch, void *hip_stream);
  * the first non-zero per-context code. */
 int fd_batch_build_result(fd_batch *batch, fd_report *reports);
 
+/* ---- dist2 producer (next row N2) ---------------------------------------------
+ * The per-point body of ProximityCapture::capture (src/capture.cpp:58-97) on the
+ * device: for every mesh point of an island (mask[i] != 0; mask NULL = all points)
+ * the squared distance to the closest point of the rest rig's surface -- what
+ * GU_RayIntersect::minimumPoint returns there -- when it is below radius2, else
+ * -1 (:76-88); 0 when dofalloff is off (:71-75) and for points outside every
+ * island (the detached attribute's default, :31).  The rig surface is T
+ * triangles, 9 floats each (a, b, c).  The result is fd_deform's dist2 input;
+ * with the _dev form it never leaves the device.  Island finding (nearest mesh
+ * point of every rig point + edge rings, :101-141) needs the mesh topology and
+ * stays with the caller. */
+int fd_capture_dist2_dev(fd_ctx *ctx, int64_t N, const float *d_P, const unsigned char *d_mask, int T,
+                         const float *d_tri_xyz, float radius2, int dofalloff, float *d_dist2);
+int fd_capture_dist2(fd_ctx *ctx, int64_t N, const float *P, const unsigned char *mask, int T,
+                     const float *tri_xyz, float radius2, int dofalloff, float *dist2);
+
 /* ---- morph-space reprojection (next row N1) ---------------------------------
  * Replaces DirectBSEdit (src/dbse.hpp:7-33, src/dbse.cpp:9-87) and the loop
  * that applies it after the RBF pass (src/SOP_FaceDeform.cpp:444-473).  The

@@ -484,3 +484,67 @@ void fdo_morph_displace(const double *shapes, int64_t N, int S, const double *w,
     }
 }
 
+/* ---- next row N2: dist2 producer (reference src/capture.cpp:46-99) ------------------------ */
+static double tri_dist2(const double p[3], const float *t)
+{
+    double a[3], b[3], c[3], ab[3], ac[3], ap[3], bp[3], cp[3], q[3];
+    for (int k = 0; k < 3; ++k) { a[k] = t[k]; b[k] = t[3 + k]; c[k] = t[6 + k]; }
+    for (int k = 0; k < 3; ++k) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ap[k] = p[k] - a[k]; }
+#define DOT(u, v) ((u)[0] * (v)[0] + (u)[1] * (v)[1] + (u)[2] * (v)[2])
+    const double d1 = DOT(ab, ap), d2 = DOT(ac, ap);
+    if (d1 <= 0.0 && d2 <= 0.0) { for (int k = 0; k < 3; ++k) q[k] = a[k]; goto done; }           /* vertex A */
+    for (int k = 0; k < 3; ++k) bp[k] = p[k] - b[k];
+    const double d3 = DOT(ab, bp), d4 = DOT(ac, bp);
+    if (d3 >= 0.0 && d4 <= d3) { for (int k = 0; k < 3; ++k) q[k] = b[k]; goto done; }            /* vertex B */
+    const double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {                                                     /* edge AB */
+        const double v = d1 / (d1 - d3);
+        for (int k = 0; k < 3; ++k) q[k] = a[k] + v * ab[k];
+        goto done;
+    }
+    for (int k = 0; k < 3; ++k) cp[k] = p[k] - c[k];
+    const double d5 = DOT(ab, cp), d6 = DOT(ac, cp);
+    if (d6 >= 0.0 && d5 <= d6) { for (int k = 0; k < 3; ++k) q[k] = c[k]; goto done; }            /* vertex C */
+    const double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {                                                     /* edge AC */
+        const double w = d2 / (d2 - d6);
+        for (int k = 0; k < 3; ++k) q[k] = a[k] + w * ac[k];
+        goto done;
+    }
+    const double va = d3 * d6 - d5 * d4;
+    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {                                       /* edge BC */
+        const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int k = 0; k < 3; ++k) q[k] = b[k] + w * (c[k] - b[k]);
+        goto done;
+    }
+    {
+        const double den = va + vb + vc;
+        if (den == 0.0) { for (int k = 0; k < 3; ++k) q[k] = a[k]; goto done; }                    /* degenerate */
+        const double v = vb / den, w = vc / den;                                                   /* face */
+        for (int k = 0; k < 3; ++k) q[k] = a[k] + ab[k] * v + ac[k] * w;
+    }
+done:
+    {
+        const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+        return dx * dx + dy * dy + dz * dz;
+    }
+#undef DOT
+}
+
+void fdo_capture_dist2(const float *P_xyz, int64_t N, const unsigned char *mask, const float *tri_xyz, int T,
+                       float radius2, int dofalloff, float *dist2)
+{
+    for (int64_t i = 0; i < N; ++i) {
+        if (mask && !mask[i]) { dist2[i] = 0.f; continue; }        /* attribute default, capture.cpp:31 */
+        if (!dofalloff) { dist2[i] = 0.f; continue; }              /* :71-75 */
+        const double p[3] = {P_xyz[3 * i], P_xyz[3 * i + 1], P_xyz[3 * i + 2]};
+        double best = INFINITY;
+        for (int t = 0; t < T; ++t) {
+            const double d = tri_dist2(p, tri_xyz + 9 * (size_t)t);
+            if (d < best) best = d;
+        }
+        const float bf = (float)best;
+        dist2[i] = (T > 0 && bf < radius2) ? bf : -1.f;            /* :76-88 */
+    }
+}
+

@@ -107,6 +107,17 @@ void fdo_morph_weights(const double *QR, int64_t N, int S, const float *P_xyz, c
 void fdo_morph_displace(const double *shapes, int64_t N, int S, const double *w, const float *clamp_lo_hi,
                         int add_delta, float falloffradius, const float *rest_xyz, float *P_xyz);
 
+/* ---- next row N2: the dist2 producer (ProximityCapture::capture, src/capture.cpp:46-99) ----
+ * For every mesh point of an island (mask[i] != 0; mask NULL = every point): with dofalloff off
+ * the attribute gets 0 (:71-75); otherwise the squared distance to the closest point of the rest
+ * rig's surface if that is below radius2, else -1 (:76-88: GU_RayIntersect::minimumPoint with
+ * GU_MinInfo(radius2) either finds a closer point or leaves distance_sqrt at -1).  Points outside
+ * every island keep the detached attribute's default 0 (:31).  The rig surface is given as T
+ * triangles, 9 floats each; the HDK's own primitive evaluation is not reproduced.  Closest point
+ * on a triangle by Voronoi regions (Ericson, Real-Time Collision Detection 5.1.5), in fp64. */
+void fdo_capture_dist2(const float *P_xyz, int64_t N, const unsigned char *mask, const float *tri_xyz, int T,
+                       float radius2, int dofalloff, float *dist2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,8 @@ class Oracle:
         L.fdo_morph_weights.restype = None
         L.fdo_morph_displace.argtypes = [_f64p, C.c_int64, C.c_int, _f64p, _f32p, C.c_int, C.c_float, _f32p, _f32p]
         L.fdo_morph_displace.restype = None
+        L.fdo_capture_dist2.argtypes = [_f32p, C.c_int64, C.c_void_p, _f32p, C.c_int, C.c_float, C.c_int, _f32p]
+        L.fdo_capture_dist2.restype = None
 
     # -- A2
     def control_table(self, rest, deform):
@@ -171,4 +173,14 @@ class Oracle:
                                     _ptr(w, _f64p), None if cl is None else _ptr(cl, _f32p), int(bool(add_delta)),
                                     float(falloffradius), _ptr(rest, _f32p), _ptr(P, _f32p))
         return P
+
+    # -- next row N2: dist2 producer (src/capture.cpp:46-99)
+    def capture_dist2(self, P, triangles, radius2, dofalloff=True, mask=None):
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+        tri = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        out = np.empty(P.shape[0], np.float32)
+        self.lib.fdo_capture_dist2(_ptr(P, _f32p), P.shape[0], None if m is None else m.ctypes.data, _ptr(tri, _f32p),
+                                   tri.shape[0], float(radius2), int(bool(dofalloff)), _ptr(out, _f32p))
+        return out
 

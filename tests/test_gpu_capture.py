@@ -1,0 +1,107 @@
+"""GPU: the dist2 producer (fd_capture_dist2*, next row N2) against the independently formulated
+golden vectors and the oracle (reference src/capture.cpp:46-99), and chained into fd_deform.
+
+Bar: the kernel works in fp32 on differences from the triangle's first vertex; |d2 - ref| <=
+2e-6 * (ref + L^2) with L the rig's extent -- a few fp32 ulps of the lengths involved.  The
+-1 / 0 decisions are exact except within that margin of the radius."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from conftest import parity_ratio
+from facedeform_amd import capi, synth
+from oracle import fd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def cap():
+    return np.load(os.path.join(HERE, "golden", "capture_golden.npz"))
+
+
+def _rig_triangles(rest):
+    """A triangle fan over nearest neighbours: every control point with two of its neighbours."""
+    tris = []
+    for i in range(rest.shape[0]):
+        d = np.linalg.norm(rest - rest[i], axis=1)
+        j, k = np.argsort(d)[1:3]
+        tris.append(np.concatenate([rest[i], rest[j], rest[k]]))
+    return np.array(tris, np.float32)
+
+
+def test_golden(hip_lib, cap):
+    e = capi.Engine()
+    P, tris, ref, mask = cap["P"], cap["tris"], cap["d2"], cap["mask"]
+    out = e.capture_dist2(P, tris, 1e30, True)
+    L2 = float(np.abs(tris).max()) ** 2
+    assert np.all(np.abs(out - ref) <= 2e-6 * (ref + L2)), np.abs(out - ref).max()
+    r2 = np.float32(0.09)
+    out = e.capture_dist2(P, tris, r2, True, mask)
+    inside = mask.astype(bool)
+    margin = 2e-6 * (ref + L2)
+    near = inside & (ref < r2 - margin)
+    far = inside & (ref > r2 + margin)
+    assert np.all(out[~inside] == 0.0) and np.all(out[far] == -1.0)
+    assert np.all(np.abs(out[near] - ref[near]) <= margin[near])
+    assert np.all(e.capture_dist2(P, tris, r2, False, mask) == 0.0)
+    assert np.all(e.capture_dist2(P[:7], tris[:0], r2, True) == -1.0)
+    e.close()
+
+
+def test_full_size_against_oracle_sample_and_into_deform(hip_lib, oracle):
+    """N = 1M, T = 256 triangles (more than one would stage at M = 256 is covered by T = 2100
+    below): device-resident, the result feeds fd_deform_dev without leaving the device."""
+    N, M = 1_000_000, 256
+    dev = torch.device("cuda", 0)
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    deform = synth.deformed_rig(rest, 1)
+    tris = _rig_triangles(rest)
+    rng = np.random.default_rng(4)
+    mask = (rng.random(N) < 0.8).astype(np.uint8)
+    r2 = np.float32(0.05)
+    d_P = torch.from_numpy(P).to(dev); d_tri = torch.from_numpy(tris).to(dev); d_mask = torch.from_numpy(mask).to(dev)
+    d_d2 = torch.empty(N, device=dev, dtype=torch.float32)
+    d_out = torch.empty_like(d_P); d_fall = torch.zeros(N, device=dev)
+    e = capi.Engine()
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    e.set_stream(stream.cuda_stream)
+    e.set_points(rest, (deform - rest).astype(np.float32)); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+    e.build()
+    e.capture_dist2_dev(N, d_P.data_ptr(), d_mask.data_ptr(), tris.shape[0], d_tri.data_ptr(), r2, True, d_d2.data_ptr())
+    e.deform_dev(N, d_P.data_ptr(), d_out.data_ptr(), d_dist2=d_d2.data_ptr(), d_falloff=d_fall.data_ptr(),
+                 radius2=r2, falloffrate=1.5)
+    stream.synchronize()
+    idx = np.linspace(0, N - 1, 5000).astype(np.int64)
+    ref = oracle.capture_dist2(P[idx], tris, r2, True, mask[idx])
+    got = d_d2.cpu().numpy()[idx]
+    exact = oracle.capture_dist2(P[idx], tris, 1e30, True)            # unthresholded distances
+    margin = 2e-6 * (exact + 1.0)
+    decided = np.abs(exact - r2) > margin                              # away from the threshold
+    assert np.all(got[decided & (ref == -1)] == -1.0) and np.all(got[mask[idx] == 0] == 0.0)
+    sel = decided & (ref >= 0) & (mask[idx] == 1)
+    assert sel.sum() > 100 and np.all(np.abs(got[sel] - ref[sel]) <= margin[sel])
+    # and the deformation that consumed it, against the oracle fed with the device's dist2
+    table = oracle.control_table(rest, deform)
+    rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+    ref_P, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P[idx], dist2=got, radius2=r2, falloffrate=1.5)
+    assert parity_ratio(d_out.cpu().numpy()[idx], ref_P, P[idx], 1e-5) <= 1.0
+    e.set_stream(None); e.close()
+
+
+def test_many_triangles_and_ragged_n(hip_lib, oracle):
+    rng = np.random.default_rng(8)
+    N, T = 10_007, 2100                                     # three LDS chunks, ragged both ways
+    P = (rng.normal(size=(N, 3)) * 0.7).astype(np.float32)
+    v = rng.normal(size=(T, 3)).astype(np.float32)
+    tris = np.concatenate([v, v + 0.1 * rng.normal(size=(T, 3)).astype(np.float32),
+                           v + 0.1 * rng.normal(size=(T, 3)).astype(np.float32)], axis=1).astype(np.float32)
+    e = capi.Engine()
+    out = e.capture_dist2(P, tris, 1e30, True)
+    ref = oracle.capture_dist2(P, tris, 1e30, True)
+    assert np.all(np.abs(out - ref) <= 2e-6 * (ref + 16.0))
+    e.close()
