@@ -269,10 +269,12 @@ __device__ unsigned long long g_panel_stamps[16];
 // measured slower: it has to mask and move all NB columns every step).
 template <int NB, int TMAX>
 __global__ __launch_bounds__(TMAX) void k_lu_panel(const BatchSlot *tab, int lda, int npad, int n_real,
-                                                   int k0)
+                                                   int k0, int step)
 {
     double *A = tab[blockIdx.z].A;
-    int *ipiv = tab[blockIdx.z].ipiv, *moves = tab[blockIdx.z].moves;
+    // one move list per elimination step: with look-ahead the next panel writes its list while
+    // the rest of this step's trailing update still reads the current one
+    int *ipiv = tab[blockIdx.z].ipiv, *moves = tab[blockIdx.z].moves + (size_t)step * kMovesStride;
     DevModel *model = tab[blockIdx.z].model;
     constexpr int R = 32 / NB;          // rows per lane: R * NB = 32 doubles in registers
     // live part of the pivot row of the current column, one slot per wave's candidate
@@ -357,9 +359,14 @@ __global__ __launch_bounds__(TMAX) void k_lu_panel(const BatchSlot *tab, int lda
         __syncthreads();
         FD_STAMP(3)
 
-        const unsigned glow = (unsigned)(s_key[j % 3] & 0xffffffffull);
-        const int gpos = 0xffff - (int)(glow >> 8);
-        const int gw = (int)(glow & 0xffu);
+        const unsigned long long gkey = s_key[j % 3];
+        // no key at all: every candidate of this column was NaN (a matrix poisoned upstream, e.g.
+        // coincident centres under the QNN radius rule).  Keep the diagonal row where it is -- the
+        // zero key would decode to logical position 65535 and the write-back would leave the matrix
+        const bool none = gkey == 0ull;
+        const unsigned glow = (unsigned)(gkey & 0xffffffffull);
+        const int gpos = none ? j : 0xffff - (int)(glow >> 8);
+        const int gw = none ? 0 : (int)(glow & 0xffu);
         // the interchange: the pivot row takes logical position j, the row that was there takes gpos
 #pragma clang loop unroll(full)
         for (int t = 0; t < R; ++t) {
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(TMAX) void k_lu_panel(const BatchSlot *tab, int lda
         asm volatile("" ::: "memory");
         const double piv = prow[j];
         const double gbest = fabs(piv);
-        const bool ok = gbest > tiny;   // false for NaN as well
+        const bool ok = !none && gbest > tiny;   // false for NaN as well
         if (k0 + j < n_real) {
             if (!ok) singular = true;
             pmin = gbest < pmin ? gbest : pmin;
@@ -429,10 +436,10 @@ __global__ __launch_bounds__(TMAX) void k_lu_panel(const BatchSlot *tab, int lda
 
 // ---- LU trailing update ---------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda, int npad, int k0)
+__global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda, int npad, int k0, int step, int cb0)
 {
     double *A = tab[blockIdx.z].A;
-    const int *moves = tab[blockIdx.z].moves;
+    const int *moves = tab[blockIdx.z].moves + (size_t)step * kMovesStride;
     constexpr int S = NB / 4;           // k-steps of the f64 16x16x4 MFMA
     __shared__ double sL[NB][NB + 1];   // L11 (unit lower), +1 pad: column reads conflict-free
     __builtin_amdgcn_s_setprio(3);
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int c0 = k0 + NB + blockIdx.x * kColBlock;
+    const int c0 = k0 + NB + (cb0 + (int)blockIdx.x) * kColBlock;
     const int c = lane & 15;            // column inside the block
     const int g = lane >> 4;            // row group (MFMA k index)
 
@@ -873,8 +880,28 @@ __global__ __launch_bounds__(64) void k_pack_tiles(const BatchSlot *tab, int Mpa
     (void)Mpad;
 }
 
+// NB of the panel that starts at column k0 (the register budget of one workgroup decides)
+int panel_width(int npad, int k0)
+{
+    const int nrem = npad - k0;
+    return nrem <= 1024 ? 32 : (nrem <= 2048 ? 16 : (nrem <= 4096 ? 8 : 4));
+}
+
+struct LuStreams {
+    hipStream_t main, aux;      // aux == nullptr: no look-ahead, everything on main
+    hipEvent_t ev_panel[2], ev_rest[2];
+    bool rest_pending = false;  // a part-B update has been enqueued on aux and not yet waited for
+    int last_rest = 0;
+};
+
+// One elimination step.  Without look-ahead (the default, see make_lookahead in fd_capi.hip):
+// panel, then the whole trailing update, on one stream.  With it the update is split: part A = the column blocks the NEXT panel will read,
+// on the main stream right after the panel; part B = everything to the right of them, on the
+// aux stream.  The next panel therefore overlaps part B, and the critical path per step is
+// max(panel, part B) + part A instead of panel + full update.  Part A of step k+1 lies inside
+// part B of step k, hence the wait on ev_rest before it.
 template <int NB>
-void lu_step(const BuildBuffers &b, int k0, hipStream_t stream)
+void lu_step(const BuildBuffers &b, int k0, int step, LuStreams &st)
 {
     constexpr int R = 32 / NB;
     const int nrem = b.npad - k0;
@@ -882,15 +909,39 @@ void lu_step(const BuildBuffers &b, int k0, hipStream_t stream)
     int threads = round_up((nrem + R - 1) / R, 64);
     if (threads < 64) threads = 64;
     if (threads <= 512)
-        hipLaunchKernelGGL((k_lu_panel<NB, 512>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda,
-                           b.npad, b.n, k0);
+        hipLaunchKernelGGL((k_lu_panel<NB, 512>), dim3(1, 1, nb), dim3(threads), 0, st.main, b.d_slots, b.lda,
+                           b.npad, b.n, k0, step);
     else
-        hipLaunchKernelGGL((k_lu_panel<NB, 1024>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda,
-                           b.npad, b.n, k0);
+        hipLaunchKernelGGL((k_lu_panel<NB, 1024>), dim3(1, 1, nb), dim3(threads), 0, st.main, b.d_slots, b.lda,
+                           b.npad, b.n, k0, step);
     // the last block may run into the 16 zero columns allocated past ncols
     const int ncb = (b.ncols - (k0 + NB) + kColBlock - 1) / kColBlock;
-    if (ncb > 0)
-        hipLaunchKernelGGL((k_lu_trail<NB>), dim3(ncb, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0);
+    if (ncb <= 0) return;
+    if (!st.aux) {
+        hipLaunchKernelGGL((k_lu_trail<NB>), dim3(ncb, 1, nb), dim3(256), 0, st.main, b.d_slots, b.lda, b.npad, k0,
+                           step, 0);
+        return;
+    }
+    const int next_k0 = k0 + NB;
+    int na = next_k0 < b.npad ? (panel_width(b.npad, next_k0) + kColBlock - 1) / kColBlock : 0;
+    if (na > ncb) na = ncb;
+    const int par = step & 1;
+    if (ncb > na) {
+        (void)hipEventRecord(st.ev_panel[par], st.main);
+        (void)hipStreamWaitEvent(st.aux, st.ev_panel[par], 0);
+    }
+    if (na > 0) {
+        if (st.rest_pending) { (void)hipStreamWaitEvent(st.main, st.ev_rest[st.last_rest], 0); st.rest_pending = false; }
+        hipLaunchKernelGGL((k_lu_trail<NB>), dim3(na, 1, nb), dim3(256), 0, st.main, b.d_slots, b.lda, b.npad, k0,
+                           step, 0);
+    }
+    if (ncb > na) {
+        hipLaunchKernelGGL((k_lu_trail<NB>), dim3(ncb - na, 1, nb), dim3(256), 0, st.aux, b.d_slots, b.lda, b.npad, k0,
+                           step, na);
+        (void)hipEventRecord(st.ev_rest[par], st.aux);
+        st.rest_pending = true;
+        st.last_rest = par;
+    }
 }
 
 }  // namespace
@@ -932,14 +983,22 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
     }
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
 
-    int k0 = 0;
+    LuStreams st{};
+    st.main = stream;
+    st.aux = b.aux_stream;
+    for (int q = 0; q < 2; ++q) { st.ev_panel[q] = b.aux_events[q]; st.ev_rest[q] = b.aux_events[2 + q]; }
+    int k0 = 0, step = 0;
     while (k0 < b.npad) {
-        const int nrem = b.npad - k0;
-        if (nrem <= 1024) { lu_step<32>(b, k0, stream); k0 += 32; }
-        else if (nrem <= 2048) { lu_step<16>(b, k0, stream); k0 += 16; }
-        else if (nrem <= 4096) { lu_step<8>(b, k0, stream); k0 += 8; }
-        else { lu_step<4>(b, k0, stream); k0 += 4; }
+        const int w = panel_width(b.npad, k0);
+        if (w == 32) lu_step<32>(b, k0, step, st);
+        else if (w == 16) lu_step<16>(b, k0, step, st);
+        else if (w == 8) lu_step<8>(b, k0, step, st);
+        else lu_step<4>(b, k0, step, st);
+        k0 += w;
+        ++step;
     }
+    // rejoin: whatever part-B update is still running on the aux stream
+    if (st.rest_pending) (void)hipStreamWaitEvent(st.main, st.ev_rest[st.last_rest], 0);
     {
         if (b.npad <= 512) {
             const size_t ybytes = sizeof(double) * 3 * (size_t)b.npad;

@@ -57,6 +57,10 @@ struct fd_ctx {
     float *d_tu = nullptr, *d_tv = nullptr, *d_nrm = nullptr;
 
     hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
+    // LU look-ahead (fd_build.hip lu_step): a second stream and four events, only with
+    // FD_LOOKAHEAD set (see make_lookahead)
+    hipStream_t lu_stream = nullptr;
+    hipEvent_t lu_events[4] = {nullptr, nullptr, nullptr, nullptr};
 
     // The build is ~25 dependent launches whose arguments depend only on the configuration
     // and on buffer addresses: captured once into a hipGraph, replayed on every later build.
@@ -79,6 +83,8 @@ struct fd_batch {
     PointSrc src{};
     bool have_src = false;
     hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
+    hipStream_t lu_stream = nullptr;
+    hipEvent_t lu_events[4] = {nullptr, nullptr, nullptr, nullptr};
     hipGraphExec_t exec = nullptr;
     bool use_graph = true;
     struct Key { int M, kind, term, nparams; double params[4]; } key{};
@@ -173,10 +179,31 @@ static int ensure_solver_capacity(fd_ctx *ctx, int npad)
         if ((rc = dev_alloc(ctx, &ctx->d_A, (size_t)npad * cols))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_X, (size_t)npad * 3))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_ipiv, (size_t)npad))) return rc;
-        if (!ctx->d_moves && (rc = dev_alloc(ctx, &ctx->d_moves, (size_t)512))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_moves, (size_t)kMovesStride * (size_t)lu_step_capacity(npad)))) return rc;
         ctx->cap_npad = npad;
     }
     return FD_OK;
+}
+
+// Second stream + events of the LU look-ahead (fd_build.hip lu_step); false leaves the build on
+// one stream.  OFF unless FD_LOOKAHEAD is set: measured on MI355X / ROCm 7.2 it loses -- C2 build
+// 0.444 vs 0.401 ms, C3 7.65 vs 6.63 ms -- because every cross-queue event wait costs more than
+// the overlap of a ~25 us panel with a ~30 us update buys.
+static bool make_lookahead(hipStream_t *stream, hipEvent_t events[4])
+{
+    static const bool on = getenv("FD_LOOKAHEAD") != nullptr;
+    if (!on) return false;
+    if (*stream) return true;
+    if (hipStreamCreateWithFlags(stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); *stream = nullptr; return false; }
+    for (int q = 0; q < 4; ++q)
+        if (hipEventCreateWithFlags(&events[q], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int r = 0; r < q; ++r) { (void)hipEventDestroy(events[r]); events[r] = nullptr; }
+            (void)hipStreamDestroy(*stream);
+            *stream = nullptr;
+            return false;
+        }
+    return true;
 }
 
 static int sync_slot(fd_ctx *ctx)
@@ -288,6 +315,8 @@ void fd_destroy(fd_ctx *ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->lu_events) if (e) (void)hipEventDestroy(e);
+    if (ctx->lu_stream) (void)hipStreamDestroy(ctx->lu_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -399,6 +428,8 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.Mpad = round_up(ctx->M, kRecPad);
     b.d_slots = ctx->d_slot;
     b.nbatch = 1;
+    b.aux_stream = nullptr;
+    for (hipEvent_t &e : b.aux_events) e = nullptr;
 }
 
 int fd_build_async(fd_ctx *ctx)
@@ -413,6 +444,10 @@ int fd_build_async(fd_ctx *ctx)
     if ((rc = sync_slot(ctx))) return rc;
     BuildBuffers b;
     fill_build_buffers(ctx, b);
+    if (make_lookahead(&ctx->lu_stream, ctx->lu_events)) {
+        b.aux_stream = ctx->lu_stream;
+        for (int q = 0; q < 4; ++q) b.aux_events[q] = ctx->lu_events[q];
+    }
     if (grew) {
         // the 16 overrun columns past the RHS block must read as zero forever
         const size_t cols = (size_t)ctx->cap_npad + kRhsCols + 16;
@@ -841,6 +876,8 @@ void fd_batch_destroy(fd_batch *b)
         if (c && c->tev0 == b->ev0) { c->tev0 = c->ev0; c->tev_mid = c->ev_mid; c->tev1 = c->ev1; }
     }
     if (b->exec) (void)hipGraphExecDestroy(b->exec);
+    for (hipEvent_t e : b->lu_events) if (e) (void)hipEventDestroy(e);
+    if (b->lu_stream) (void)hipStreamDestroy(b->lu_stream);
     if (b->d_slots) (void)hipFree(b->d_slots);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
@@ -912,6 +949,10 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     fill_build_buffers(c0, bb);
     bb.d_slots = b->d_slots;
     bb.nbatch = b->n;
+    if (make_lookahead(&b->lu_stream, b->lu_events)) {
+        bb.aux_stream = b->lu_stream;
+        for (int q = 0; q < 4; ++q) bb.aux_events[q] = b->lu_events[q];
+    }
 
     fd_batch::Key key{};
     key.M = c0->M; key.kind = c0->kind; key.term = c0->term; key.nparams = c0->nparams;

@@ -74,6 +74,8 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 constexpr int kPanelThreads = 1024;   // one workgroup factors a panel
 constexpr int kMaxOrder = 5632;       // back-substitution keeps Y (3 x order fp64) in LDS
 constexpr int kRhsCols = 16;          // 3 right-hand sides padded to one MFMA tile
+constexpr int kMovesStride = 132;     // ints per elimination step's move list: count + 2 * (2 * 32) pairs
+static inline int lu_step_capacity(int npad) { return npad / 4 + 2; }   // steps a system of this order can take
 
 constexpr int kMaxBatch = 32;         // models one launch chain may build together
 
@@ -109,6 +111,10 @@ struct BuildBuffers {
     int Mpad;
     const BatchSlot *d_slots;         // device table, nbatch entries
     int nbatch;
+    // LU look-ahead: second stream + {panel done, rest done} x 2 events; aux_stream == nullptr
+    // runs every step on the one stream
+    hipStream_t aux_stream;
+    hipEvent_t aux_events[4];
 };
 
 hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);

@@ -100,3 +100,31 @@ def test_morph_without_shapes_and_capture_without_points(hip_lib):
     e = capi.Engine()
     assert e.capture_dist2(np.zeros((0, 3), np.float32), np.zeros((1, 9), np.float32), 1.0).shape == (0,)
     e.close()
+
+
+def test_poisoned_systems_fail_cleanly(hip_lib):
+    """Matrices full of NaN must end in terminationtype -4 / -5, not in a wild write: coincident
+    centres under the QNN rule give radius 0 and exp(-0/0) = NaN everywhere in two columns; a NaN
+    or Inf control point poisons a whole row.  (The panel's pivot search sees no candidate in an
+    all-NaN column; it used to decode the empty key into logical row 65535.)  The context must
+    stay usable afterwards."""
+    rest = synth.control_points(40, "sphere")
+    deform = synth.deformed_rig(rest)
+    delta = (deform - rest).astype(np.float32)
+    e = capi.Engine()
+    e.set_kernel(capi.KERNEL_GAUSSIAN_QNN, [1.0, 5.0]); e.set_term(0)
+    bad = rest.copy(); bad[7] = bad[3]; bad[21] = bad[3]
+    e.set_points(bad, delta)
+    assert e.build(check=False).terminationtype == -5
+    for poison in (np.nan, np.inf):
+        bad = rest.copy(); bad[11, 1] = poison
+        for kind, params in ((capi.KERNEL_GAUSSIAN_QNN, [1.0, 5.0]), (capi.KERNEL_THIN_PLATE, [])):
+            e.set_kernel(kind, params)
+            e.set_points(bad, delta)
+            assert e.build(check=False).terminationtype in (-4, -5), (poison, kind)
+    e.set_kernel(capi.KERNEL_THIN_PLATE)
+    e.set_points(rest, delta)
+    assert e.build().terminationtype == 1
+    out, _ = e.deform(rest)
+    assert np.abs((out - rest) - delta).max() <= 1e-5 * np.abs(delta).max() + 1e-7
+    e.close()
