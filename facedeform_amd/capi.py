@@ -43,13 +43,14 @@ class FdsopGeo(C.Structure):
                 ("P_out", _f32p), ("fd_falloff", _f32p), ("Cd", _f32p),
                 ("nshapes", C.c_int64), ("shapes_P", C.POINTER(C.c_void_p)), ("shapes_npoints", C.POINTER(C.c_int64)),
                 ("rest", _f32p), ("rest_changed", C.c_int), ("blends_changed", C.c_int),
-                ("weights", C.POINTER(C.c_double)), ("weights_count", C.POINTER(C.c_int64))]
+                ("weights", C.POINTER(C.c_double)), ("weights_count", C.POINTER(C.c_int64)),
+                ("rig_rest_unchanged", C.c_int)]
 
 
 # every symbol include/facedeform_hip.h declares
 EXPORTS = [
     "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_points",
-    "fd_set_points_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
+    "fd_set_points_dev", "fd_set_deltas", "fd_set_deltas_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
     "fd_capture_dist2", "fd_capture_dist2_dev",
@@ -90,6 +91,8 @@ def load() -> C.CDLL:
     L.fd_set_stream.argtypes = [vp, vp]; L.fd_set_stream.restype = i32
     L.fd_set_points.argtypes = [vp, vp, vp, i32]; L.fd_set_points.restype = i32
     L.fd_set_points_dev.argtypes = [vp, vp, vp, i32]; L.fd_set_points_dev.restype = i32
+    L.fd_set_deltas.argtypes = [vp, vp, i32]; L.fd_set_deltas.restype = i32
+    L.fd_set_deltas_dev.argtypes = [vp, vp, i32]; L.fd_set_deltas_dev.restype = i32
     L.fd_set_kernel.argtypes = [vp, i32, _f64p, i32]; L.fd_set_kernel.restype = i32
     L.fd_set_term.argtypes = [vp, i32]; L.fd_set_term.restype = i32
     L.fd_build.argtypes = [vp, C.POINTER(FdReport)]; L.fd_build.restype = i32
@@ -207,6 +210,14 @@ class Engine:
     def set_points_dev(self, d_rest: int, d_delta: int, M: int):
         self.M = M
         self._check(self.L.fd_set_points_dev(self.ctx, C.c_void_p(d_rest), C.c_void_p(d_delta), M))
+
+    def set_deltas(self, delta):
+        """New deltas for the rest points of the last build (reuses its factorisation)."""
+        delta = np.ascontiguousarray(delta, np.float32).reshape(-1, 3)
+        self._check(self.L.fd_set_deltas(self.ctx, _np_ptr(delta), delta.shape[0]))
+
+    def set_deltas_dev(self, d_delta: int, M: int):
+        self._check(self.L.fd_set_deltas_dev(self.ctx, C.c_void_p(d_delta), M))
 
     def set_kernel(self, kind: int, params=()):
         p = np.ascontiguousarray(np.asarray(params, np.float64).reshape(-1))

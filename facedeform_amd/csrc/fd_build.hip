@@ -90,6 +90,25 @@ __global__ void k_prepare(const BatchSlot *tab, const PointSrc src, int use_src,
     }
 }
 
+// New right-hand sides for an existing factorisation (fd_set_deltas): only the RHS columns are
+// rewritten; centres, matrix and the singular / duplicate flags of the factorisation stay.
+__global__ void k_prepare_rhs(const BatchSlot *tab, const PointSrc src, int use_src, int M, int npad, int lda)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    const float *delta = use_src ? src.delta[blockIdx.z] : s.delta;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) s.model->terminationtype = 0;
+    if (i < npad) {
+        for (int c = 0; c < kRhsCols; ++c) {
+            double v = 0.0;
+            if (i < M && c < 3) v = (double)delta[3 * i + c];
+            s.A[(size_t)(npad + c) * lda + i] = v;
+        }
+    }
+    if (use_src && i < M)
+        for (int c = 0; c < 3; ++c) s.delta[3 * i + c] = delta[3 * i + c];
+}
+
 // QNN radii: R_i = q * distance to the nearest other centre
 __global__ void k_qnn_nearest(const BatchSlot *tab, int M, double q)
 {
@@ -946,6 +965,28 @@ void lu_step(const BuildBuffers &b, int k0, int step, LuStreams &st)
 
 }  // namespace
 
+static void launch_backsub(const BuildBuffers &b, hipStream_t stream)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    {
+        if (b.npad <= 512) {
+            const size_t ybytes = sizeof(double) * 3 * (size_t)b.npad;
+            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), ybytes, stream, b.d_slots, b.lda,
+                               b.npad, 0, b.npad);
+        } else {
+            constexpr int W = 256;      // rows per diagonal range (a multiple of 32, like npad)
+            for (int hi = b.npad; hi > 0; hi -= W) {
+                const int lo = hi > W ? hi - W : 0;
+                hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)(hi - lo),
+                                   stream, b.d_slots, b.lda, b.npad, lo, hi);
+                if (lo > 0)
+                    hipLaunchKernelGGL(k_backsub_update, dim3((lo + 255) / 256, 1, nb), dim3(256), 0, stream,
+                                       b.d_slots, b.lda, b.npad, lo, hi - lo);
+            }
+        }
+    }
+}
+
 // centres, right-hand sides, status reset.  src == nullptr: read the contexts' own copies of
 // the control points; otherwise straight from the caller's arrays (one pointer pair per model).
 hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
@@ -999,23 +1040,7 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
     }
     // rejoin: whatever part-B update is still running on the aux stream
     if (st.rest_pending) (void)hipStreamWaitEvent(st.main, st.ev_rest[st.last_rest], 0);
-    {
-        if (b.npad <= 512) {
-            const size_t ybytes = sizeof(double) * 3 * (size_t)b.npad;
-            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), ybytes, stream, b.d_slots, b.lda,
-                               b.npad, 0, b.npad);
-        } else {
-            constexpr int W = 256;      // rows per diagonal range (a multiple of 32, like npad)
-            for (int hi = b.npad; hi > 0; hi -= W) {
-                const int lo = hi > W ? hi - W : 0;
-                hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)(hi - lo),
-                                   stream, b.d_slots, b.lda, b.npad, lo, hi);
-                if (lo > 0)
-                    hipLaunchKernelGGL(k_backsub_update, dim3((lo + 255) / 256, 1, nb), dim3(256), 0, stream,
-                                       b.d_slots, b.lda, b.npad, lo, hi - lo);
-            }
-        }
-    }
+    launch_backsub(b, stream);
     hipError_t e = launch_pack(b, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
@@ -1036,6 +1061,41 @@ hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream)
     hipLaunchKernelGGL(k_pack, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.npad, b.M, b.Mpad, b.T, b.kind, 1);
     if (b.kind == FD_KERNEL_THIN_PLATE)
         hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16, 1, nb), dim3(64), 0, stream, b.d_slots, b.Mpad);
+    return hipGetLastError();
+}
+
+// fd_set_deltas: the factorisation in A (L below the diagonal as the panels left it, U above,
+// one move list per step) is reused; the 16-column RHS block alone goes through every step's
+// row interchanges, triangular solve and update -- the same k_lu_trail, one workgroup per step --
+// then back-substitution and packing as usual.  Same kernels, same operand values, same order
+// as in a full build: the weights are bit-identical to rebuilding from scratch.
+// Requires every panel width to be a multiple of the 16-column block (order <= 2048), so that
+// the RHS block is exactly one of the trailing update's column blocks.
+hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
+{
+    static const PointSrc none{};
+    const unsigned nb = (unsigned)b.nbatch;
+    if (b.npad > 2048) return hipErrorInvalidValue;
+    {
+        const int threads = 256;
+        const int blocks = (b.npad + threads - 1) / threads;
+        hipLaunchKernelGGL(k_prepare_rhs, dim3(blocks, 1, nb), dim3(threads), 0, stream, b.d_slots, src ? *src : none,
+                           src ? 1 : 0, b.M, b.npad, b.lda);
+    }
+    int k0 = 0, step = 0;
+    while (k0 < b.npad) {
+        const int w = panel_width(b.npad, k0);
+        const int cb = (b.npad - (k0 + w)) / kColBlock;      // the RHS block among this step's column blocks
+        if (w == 32)
+            hipLaunchKernelGGL((k_lu_trail<32>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb);
+        else
+            hipLaunchKernelGGL((k_lu_trail<16>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb);
+        k0 += w;
+        ++step;
+    }
+    launch_backsub(b, stream);
+    hipError_t e = launch_pack(b, stream);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

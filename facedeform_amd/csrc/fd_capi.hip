@@ -26,6 +26,11 @@ struct fd_ctx {
     bool built = false;           // status read back and == 1
     bool have_report = false;
     fd_report report{};
+    // fd_set_deltas: a full build with the current rest points / kernel / term has been enqueued
+    // (its factorisation sits in d_A), and the next build only has new right-hand sides
+    bool have_factor = false;
+    bool deltas_only = false;
+    hipGraphExec_t resolve_exec = nullptr;
 
     // device buffers (grow-only)
     int cap_M = 0;                // capacity in centres
@@ -70,7 +75,7 @@ struct fd_ctx {
         int M, kind, term, nparams;
         double params[4];
         const void *A, *rest, *rec32;
-    } graph_key{};
+    } graph_key{}, resolve_key{};
     char err[512] = {0};
 };
 
@@ -312,6 +317,7 @@ void fd_destroy(fd_ctx *ctx)
     if (ctx->h_model) (void)hipHostFree(ctx->h_model);
     if (ctx->h_header) (void)hipHostFree(ctx->h_header);
     if (ctx->build_exec) (void)hipGraphExecDestroy(ctx->build_exec);
+    if (ctx->resolve_exec) (void)hipGraphExecDestroy(ctx->resolve_exec);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -356,8 +362,40 @@ static int set_points_common(fd_ctx *ctx, const float *rest, const float *delta,
     ctx->points_set = true;
     ctx->built = false;
     ctx->build_pending = false;
+    ctx->have_factor = false;
+    ctx->deltas_only = false;
     return FD_OK;
 }
+
+// New deltas for the rest points already factorised (the animated-rig case: the rest rig stands
+// still, the deformed rig moves).  The next fd_build* only carries the new right-hand sides
+// through the stored factorisation.
+static int set_deltas_common(fd_ctx *ctx, const float *delta, int M, bool on_device)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (!delta || M <= 0) { set_err(ctx, "fd_set_deltas: need M > 0 and the array"); return FD_E_INVALID; }
+    if (!ctx->have_factor || M != ctx->M) {
+        set_err(ctx, "fd_set_deltas: no factorisation for %d control points (call fd_set_points + fd_build first; "
+                     "fd_set_kernel / fd_set_term / fd_import_model discard it)", M);
+        return FD_E_NOT_BUILT;
+    }
+    if (round_up(order_of(ctx), 32) > 2048) {
+        set_err(ctx, "fd_set_deltas: supported up to order 2048 (M = %d here); use fd_set_points", M);
+        return FD_E_INVALID;
+    }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    FD_HIP(ctx, hipMemcpyAsync(ctx->d_delta, delta, sizeof(float) * 3 * (size_t)M, k, cur_stream(ctx)));
+    if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+    ctx->deltas_only = true;
+    ctx->built = false;
+    ctx->build_pending = false;
+    return FD_OK;
+}
+
+int fd_set_deltas(fd_ctx *ctx, const float *delta_xyz, int M) { return set_deltas_common(ctx, delta_xyz, M, false); }
+int fd_set_deltas_dev(fd_ctx *ctx, const float *d_delta_xyz, int M) { return set_deltas_common(ctx, d_delta_xyz, M, true); }
 
 int fd_set_points(fd_ctx *ctx, const float *rest_xyz, const float *delta_xyz, int M)
 {
@@ -387,11 +425,15 @@ int fd_set_kernel(fd_ctx *ctx, int kind, const double *params, int nparams)
         if (nparams < 2) p[1] = 5.0;
         if (!(p[0] > 0.0) || !(p[1] > 0.0)) { set_err(ctx, "fd_set_kernel: q and z must be > 0"); return FD_E_INVALID; }
     }
+    if (kind == ctx->kind && nparams == ctx->nparams && memcmp(ctx->params, p, sizeof(p)) == 0)
+        return FD_OK;                 // nothing changes: the model and its factorisation stay valid
     ctx->kind = kind;
     ctx->nparams = nparams;
     memcpy(ctx->params, p, sizeof(p));
     ctx->built = false;
     ctx->build_pending = false;
+    ctx->have_factor = false;
+    ctx->deltas_only = false;
     return FD_OK;
 }
 
@@ -399,9 +441,12 @@ int fd_set_term(fd_ctx *ctx, int term)
 {
     if (!ctx) return FD_E_INVALID;
     if (term < FD_TERM_LINEAR || term > FD_TERM_ZERO) { set_err(ctx, "fd_set_term: bad term %d", term); return FD_E_INVALID; }
+    if (term == ctx->term) return FD_OK;
     ctx->term = term;
     ctx->built = false;
     ctx->build_pending = false;
+    ctx->have_factor = false;
+    ctx->deltas_only = false;
     return FD_OK;
 }
 
@@ -444,6 +489,39 @@ int fd_build_async(fd_ctx *ctx)
     if ((rc = sync_slot(ctx))) return rc;
     BuildBuffers b;
     fill_build_buffers(ctx, b);
+    if (ctx->deltas_only && ctx->have_factor) {
+        // fd_set_deltas: right-hand sides only, through the factorisation of the last full build
+        hipStream_t st = cur_stream(ctx);
+        fd_ctx::GraphKey rkey{};
+        rkey.M = ctx->M; rkey.kind = ctx->kind; rkey.term = ctx->term; rkey.nparams = ctx->nparams;
+        memcpy(rkey.params, ctx->params, sizeof(rkey.params));
+        rkey.A = ctx->d_A; rkey.rest = ctx->d_rest; rkey.rec32 = ctx->d_rec32;
+        if (ctx->use_graph && (!ctx->resolve_exec || memcmp(&rkey, &ctx->resolve_key, sizeof(rkey)) != 0)) {
+            if (ctx->resolve_exec) { (void)hipGraphExecDestroy(ctx->resolve_exec); ctx->resolve_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                hipError_t e1 = launch_resolve(b, st, nullptr);
+                e = hipStreamEndCapture(st, &graph);
+                if (e == hipSuccess && e1 != hipSuccess) e = e1;
+            }
+            if (e == hipSuccess && graph) e = hipGraphInstantiate(&ctx->resolve_exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { (void)hipGetLastError(); ctx->resolve_exec = nullptr; }
+            else ctx->resolve_key = rkey;
+        }
+        FD_HIP(ctx, hipEventRecord(ctx->ev0, st));
+        FD_HIP(ctx, hipEventRecord(ctx->ev_mid, st));
+        if (ctx->use_graph && ctx->resolve_exec) FD_HIP(ctx, hipGraphLaunch(ctx->resolve_exec, st));
+        else FD_HIP(ctx, launch_resolve(b, st, nullptr));
+        FD_HIP(ctx, hipEventRecord(ctx->ev1, st));
+        ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
+        ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
+        ctx->build_pending = true;
+        ctx->built = false;
+        ctx->have_report = false;
+        return FD_OK;
+    }
     if (make_lookahead(&ctx->lu_stream, ctx->lu_events)) {
         b.aux_stream = ctx->lu_stream;
         for (int q = 0; q < 4; ++q) b.aux_events[q] = ctx->lu_events[q];
@@ -488,6 +566,8 @@ int fd_build_async(fd_ctx *ctx)
     FD_HIP(ctx, hipEventRecord(ctx->ev1, cur_stream(ctx)));
     ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
+    ctx->have_factor = true;
+    ctx->deltas_only = false;
     ctx->build_pending = true;
     ctx->built = false;
     ctx->have_report = false;
@@ -812,6 +892,8 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     FD_HIP(ctx, launch_pack_from_weights(b, cur_stream(ctx)));
     ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
     if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+    ctx->have_factor = false;
+    ctx->deltas_only = false;
     ctx->points_set = false;   // no rest/delta on this context: it can deform, not rebuild
     ctx->build_pending = false;
     ctx->built = true;
@@ -902,6 +984,8 @@ int fd_batch_set_points_dev(fd_batch *b, const float *const *d_rest_xyz, const f
         c->points_set = true;
         c->built = false;
         c->build_pending = false;
+        c->have_factor = false;
+        c->deltas_only = false;
         b->src.rest[i] = d_rest_xyz[i];
         b->src.delta[i] = d_delta_xyz[i];
     }
@@ -994,6 +1078,8 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         fd_ctx *c = b->ctxs[i];
         c->wait_event = b->ev1; c->wait_stream = stream; c->wait_batch = b;
         c->tev0 = b->ev0; c->tev_mid = b->ev_mid; c->tev1 = b->ev1;
+        c->have_factor = true;       // a batched build leaves the same factorisation a single one does
+        c->deltas_only = false;
         c->build_pending = true;
         c->built = false;
         c->have_report = false;

@@ -119,6 +119,7 @@ struct BuildBuffers {
 
 hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
+hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream);
 hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream);
 

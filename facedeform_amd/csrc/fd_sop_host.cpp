@@ -298,12 +298,9 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     }
     fd_ctx *ctx = node->engine;
 
-    // :331-340 -- rbfcreate + rbfsetpoints
-    if (M <= 0 || fd_set_points(ctx, geo->rest_P, delta.data(), M) != FD_OK) {
-        node->add(FDSOP_ERROR, "Can't build RBF model.");
-        return node->severity;
-    }
-    // :342-349 -- model select; `kernel` (addition) overrides the Gaussian family
+    // :342-349 -- model select; `kernel` (addition) overrides the Gaussian family.  (Set before
+    // the points here: an unchanged kernel / term leaves the engine's factorisation in place, and
+    // fd_set_deltas below depends on that; every failure ends in the same message as at :337-340.)
     int rc = FD_OK;
     if (kernel_ext == 1 || kernel_ext == 2 || kernel_ext == 3) {
         const int kind = kernel_ext == 1 ? FD_KERNEL_THIN_PLATE : (kernel_ext == 2 ? FD_KERNEL_BIHARMONIC : FD_KERNEL_CUBIC);
@@ -319,6 +316,16 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     // :351-361 -- any other ordinal leaves ALGLIB's default (linear) in place
     const int term = (term_index == 1) ? FD_TERM_CONST : (term_index == 2 ? FD_TERM_ZERO : FD_TERM_LINEAR);
     if (rc == FD_OK) rc = fd_set_term(ctx, term);
+    // :331-340 -- rbfcreate + rbfsetpoints.  The reference rebuilds its model on every cook (B12);
+    // when the caller vouches that the rest rig has not changed since the last cook
+    // (checkChangedSourceFlags(1) in the wrapper) only the deltas are new and the engine reuses
+    // its factorisation -- bit-identical weights, half the cook.  Anything that invalidates it
+    // (first cook, another M, kernel or term) falls back to the full path.
+    if (rc == FD_OK) {
+        rc = FD_E_NOT_BUILT;
+        if (M > 0 && geo->rig_rest_unchanged) rc = fd_set_deltas(ctx, delta.data(), M);
+        if (rc != FD_OK) rc = M > 0 ? fd_set_points(ctx, geo->rest_P, delta.data(), M) : FD_E_INVALID;
+    }
     if (rc != FD_OK) {
         node->add(FDSOP_ERROR, "Can't build RBF model.");
         return node->severity;

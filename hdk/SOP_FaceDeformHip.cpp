@@ -259,6 +259,12 @@ protected:
             geo.weights = weights.data();
             geo.weights_count = &weightsCount;
         }
+        {
+            // the rest rig of the previous cook again?  Then only the deltas are new (fd_set_deltas)
+            int rigChanged = 1;
+            checkChangedSourceFlags(1, context, &rigChanged);
+            geo.rig_rest_unchanged = !rigChanged;
+        }
         fdsop_cook(myNode, &geo);
 
         // replay the engine's messages through the node's own channels

@@ -110,6 +110,16 @@ int fd_set_points(fd_ctx *ctx, const float *rest_xyz, const float *delta_xyz, in
 int fd_set_points_dev(fd_ctx *ctx, const float *d_rest_xyz, const float *d_delta_xyz, int M);
 
 /* Replaces rbfsetalgoqnn / rbfsetalgomultilayer (src/SOP_FaceDeform.cpp:342-349). */
+/* New deltas for rest points that have already been factorised: the animated-rig case, where
+ * the rest rig (input 1) stands still and only the deformed rig (input 2) moves.  The reference
+ * rebuilds its model on every cook (src/SOP_FaceDeform.cpp:331-363); the system matrix depends on
+ * the rest points, kernel and term only, so after fd_set_deltas the next fd_build* carries just
+ * the new right-hand sides through the stored factorisation (same kernels and operand order as
+ * a full build: the weights are bit-identical to fd_set_points + fd_build with the same data).
+ * FD_E_NOT_BUILT when there is no factorisation to reuse (no build yet, or fd_set_points /
+ * fd_set_kernel / fd_set_term / fd_import_model since); M must match; order <= 2048. */
+int fd_set_deltas(fd_ctx *ctx, const float *delta_xyz, int M);
+int fd_set_deltas_dev(fd_ctx *ctx, const float *d_delta_xyz, int M);
 int fd_set_kernel(fd_ctx *ctx, int kind, const double *params, int nparams);
 
 /* Replaces rbfsetlinterm / rbfsetconstterm / rbfsetzeroterm (:351-361). */
@@ -301,6 +311,10 @@ typedef struct fdsop_geo {
     int blends_changed;              /* ... and for any of inputs 3.. (:186-194) */
     double *weights;                 /* out: the detail array `weights` (:474-481), room for nshapes, or NULL */
     int64_t *weights_count;          /* out: entries written; 0 when the morph pass did not run; or NULL */
+    /* The rest rig (input 1) is the one of the previous cook -- what checkChangedSourceFlags(1)
+     * tells the wrapper.  Then only the deltas are new and the engine reuses its factorisation
+     * (fd_set_deltas); 0 = rebuild, as the reference does every cook (B12). */
+    int rig_rest_unchanged;
 } fdsop_geo;
 
 fdsop_node *fdsop_create(const fd_config *cfg);

@@ -34,7 +34,7 @@ def test_abi_version(hip_lib):
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.FdConfig) == 32
     assert C.sizeof(capi.FdReport) == 32
-    assert C.sizeof(capi.FdsopGeo) == 20 * 8   # 13 mesh/rig fields + 7 morph-space fields (two ints share a slot)
+    assert C.sizeof(capi.FdsopGeo) == 21 * 8   # 13 mesh/rig fields + 7 morph-space fields (two ints share a slot) + the rig flag
 
 
 @pytest.mark.skipif(HAVE_GPU, reason="checks the no-device failure mode")

@@ -46,3 +46,9 @@ for f in range(8):
     t0 = time.perf_counter(); res = node.cook(pin_in, rest, synth.deformed_rig(rest, f), out_P=pin_out, out_falloff=pin_fall, want_Cd=False); ts.append(time.perf_counter() - t0)
 ts = sorted(ts[2:])
 print(f"fdsop_cook on page-locked mesh arrays, Cd left to the attribute default (what hdk/SOP_FaceDeformHip.cpp does): median {ts[len(ts)//2]*1e3:.3f} ms; severity {res.severity}")
+ts = []
+for f in range(10):
+    t0 = time.perf_counter(); res = node.cook(pin_in, rest, synth.deformed_rig(rest, f), out_P=pin_out, out_falloff=pin_fall, want_Cd=False, rig_rest_unchanged=True); ts.append(time.perf_counter() - t0)
+ts = sorted(ts[2:])
+print(f"... and the rest rig unchanged from cook to cook (fd_set_deltas: factorisation reused): median {ts[len(ts)//2]*1e3:.3f} ms; severity {res.severity}")
+
