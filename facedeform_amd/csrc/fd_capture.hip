@@ -122,11 +122,14 @@ hipError_t launch_capture_dist2(const float *d_P, int64_t N, const unsigned char
     if (N <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((N + kCapBlock - 1) / kCapBlock);
     const int nt = T < kTriChunk ? (T > 0 ? T : 1) : kTriChunk;
-    static bool attr_set = false;     // 64 KiB of dynamic LDS has to be requested once
-    if (!attr_set) {
+    // 64 KiB of dynamic LDS has to be requested once per device
+    static unsigned long long attr_devices = 0ull;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 64 || !(attr_devices & (1ull << dev))) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_capture_dist2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(float) * kTriRec * kTriChunk));
-        attr_set = true;
+        if (dev < 64) attr_devices |= 1ull << dev;
     }
     hipLaunchKernelGGL(k_capture_dist2, dim3(grid), dim3(kCapBlock), sizeof(float) * kTriRec * (size_t)nt, stream, d_P, N, d_mask,
                        d_tri, T, radius2, dofalloff, d_dist2);
