@@ -44,7 +44,7 @@ class FdsopGeo(C.Structure):
                 ("nshapes", C.c_int64), ("shapes_P", C.POINTER(C.c_void_p)), ("shapes_npoints", C.POINTER(C.c_int64)),
                 ("rest", _f32p), ("rest_changed", C.c_int), ("blends_changed", C.c_int),
                 ("weights", C.POINTER(C.c_double)), ("weights_count", C.POINTER(C.c_int64)),
-                ("rig_rest_unchanged", C.c_int)]
+                ("rig_rest_unchanged", C.c_int), ("mesh_unchanged", C.c_int)]
 
 
 # every symbol include/facedeform_hip.h declares
@@ -53,6 +53,7 @@ EXPORTS = [
     "fd_set_points_dev", "fd_set_deltas", "fd_set_deltas_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
+    "fd_mesh_set", "fd_mesh_size", "fd_deform_mesh",
     "fd_capture_dist2", "fd_capture_dist2_dev",
     "fd_morph_create", "fd_morph_destroy", "fd_morph_last_error", "fd_morph_init", "fd_morph_init_dev",
     "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
@@ -109,6 +110,9 @@ def load() -> C.CDLL:
     L.fd_export_model.argtypes = [vp, vp, sz, i32]; L.fd_export_model.restype = i32
     L.fd_import_model.argtypes = [vp, vp, sz, i32]; L.fd_import_model.restype = i32
     L.fd_synchronize.argtypes = [vp]; L.fd_synchronize.restype = i32
+    L.fd_mesh_set.argtypes = [vp, i64, vp, vp, vp, vp, vp]; L.fd_mesh_set.restype = i32
+    L.fd_mesh_size.argtypes = [vp]; L.fd_mesh_size.restype = i64
+    L.fd_deform_mesh.argtypes = [vp, vp, vp, C.c_float, C.c_float]; L.fd_deform_mesh.restype = i32
     L.fd_capture_dist2.argtypes = [vp, i64, vp, vp, i32, vp, C.c_float, i32, vp]; L.fd_capture_dist2.restype = i32
     L.fd_capture_dist2_dev.argtypes = [vp, i64, vp, vp, i32, vp, C.c_float, i32, vp]; L.fd_capture_dist2_dev.restype = i32
     L.fd_morph_create.argtypes = [C.POINTER(FdConfig)]; L.fd_morph_create.restype = vp
@@ -271,6 +275,22 @@ class Engine:
         self._check(self.L.fd_deform(self.ctx, N, _np_ptr(P_in), _np_ptr(P_out), _np_ptr(dist2), _np_ptr(falloff),
                                      _np_ptr(tu), _np_ptr(tv), _np_ptr(nr), float(radius2),
                                      float(falloffrate)))
+
+    def mesh_set(self, P, dist2=None, tangents=None):
+        """Upload the cook-invariant mesh arrays once (fd_mesh_set)."""
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+        d2 = None if dist2 is None else np.ascontiguousarray(dist2, np.float32)
+        tu = tv = nr = None
+        if tangents is not None:
+            tu, tv, nr = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in tangents)
+        self._check(self.L.fd_mesh_set(self.ctx, P.shape[0], _np_ptr(P), _np_ptr(d2), _np_ptr(tu), _np_ptr(tv), _np_ptr(nr)))
+
+    def deform_mesh(self, P_out, falloff=None, radius2=1.0, falloffrate=1.0):
+        """Evaluate the cached mesh into caller-owned arrays (page-locked ones are written in place)."""
+        for a in (P_out, falloff):
+            if a is not None and (a.dtype != np.float32 or not a.flags.c_contiguous):
+                raise ValueError("arrays must be C-contiguous float32")
+        self._check(self.L.fd_deform_mesh(self.ctx, _np_ptr(P_out), _np_ptr(falloff), float(radius2), float(falloffrate)))
 
     def capture_dist2(self, P, triangles, radius2, dofalloff=True, mask=None):
         """ProximityCapture's per-point squared distance to the rig surface (host arrays)."""

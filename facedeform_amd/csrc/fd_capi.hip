@@ -60,6 +60,12 @@ struct fd_ctx {
     int64_t cap_N = 0;
     float *d_P = nullptr, *d_dist2 = nullptr, *d_fall = nullptr;
     float *d_tu = nullptr, *d_tv = nullptr, *d_nrm = nullptr;
+    // fd_mesh_set: the mesh arrays that stay the same from cook to cook live in their own
+    // device buffers (the staging above is evaluated in place, so it cannot serve as a cache)
+    int64_t mesh_N = 0, mesh_cap = 0;
+    bool mesh_has_dist2 = false, mesh_has_frames = false;
+    float *m_P = nullptr, *m_dist2 = nullptr, *m_tu = nullptr, *m_tv = nullptr, *m_nrm = nullptr;
+    float *m_out = nullptr, *m_fall = nullptr;      // result staging for pageable outputs
 
     hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
     // LU look-ahead (fd_build.hip lu_step): a second stream and four events, only with
@@ -312,7 +318,8 @@ void fd_destroy(fd_ctx *ctx)
     if (ctx->stream_ || ctx->own_stream) (void)hipStreamSynchronize(cur_stream(ctx));
     void *bufs[] = {ctx->d_rest, ctx->d_delta, ctx->d_centres, ctx->d_radii, ctx->d_W, ctx->d_A,
                     ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_model, ctx->d_slot,
-                    ctx->d_P, ctx->d_dist2, ctx->d_fall, ctx->d_tu, ctx->d_tv, ctx->d_nrm};
+                    ctx->d_P, ctx->d_dist2, ctx->d_fall, ctx->d_tu, ctx->d_tv, ctx->d_nrm,
+                    ctx->m_P, ctx->m_dist2, ctx->m_tu, ctx->m_tv, ctx->m_nrm, ctx->m_out, ctx->m_fall};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (ctx->h_model) (void)hipHostFree(ctx->h_model);
     if (ctx->h_header) (void)hipHostFree(ctx->h_header);
@@ -796,6 +803,93 @@ void *fd_host_alloc(size_t bytes)
 void fd_host_free(void *p)
 {
     if (p) (void)hipHostFree(p);
+}
+
+// ---- device-resident mesh (next row N3, engine side) ----------------------------------------
+int fd_mesh_set(fd_ctx *ctx, int64_t N, const float *P, const float *dist2, const float *tu, const float *tv,
+                const float *nrm)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (N <= 0 || !P) { set_err(ctx, "fd_mesh_set: need N > 0 and P"); return FD_E_INVALID; }
+    const int ntan = (tu != nullptr) + (tv != nullptr) + (nrm != nullptr);
+    if (ntan != 0 && ntan != 3) { set_err(ctx, "fd_mesh_set: tu, tv, nrm must be all set or all NULL"); return FD_E_INVALID; }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    ctx->mesh_N = 0;
+    if (N > ctx->mesh_cap) {
+        if ((rc = dev_alloc(ctx, &ctx->m_P, (size_t)N * 3))) return rc;
+        if (ctx->m_dist2) { (void)hipFree(ctx->m_dist2); ctx->m_dist2 = nullptr; }
+        if (ctx->m_tu) { (void)hipFree(ctx->m_tu); ctx->m_tu = nullptr; }
+        if (ctx->m_tv) { (void)hipFree(ctx->m_tv); ctx->m_tv = nullptr; }
+        if (ctx->m_nrm) { (void)hipFree(ctx->m_nrm); ctx->m_nrm = nullptr; }
+        if (ctx->m_out) { (void)hipFree(ctx->m_out); ctx->m_out = nullptr; }
+        if (ctx->m_fall) { (void)hipFree(ctx->m_fall); ctx->m_fall = nullptr; }
+        ctx->mesh_cap = N;
+    }
+    if (dist2 && !ctx->m_dist2 && (rc = dev_alloc(ctx, &ctx->m_dist2, (size_t)ctx->mesh_cap))) return rc;
+    if (tu && !ctx->m_tu) {
+        if ((rc = dev_alloc(ctx, &ctx->m_tu, (size_t)ctx->mesh_cap * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->m_tv, (size_t)ctx->mesh_cap * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->m_nrm, (size_t)ctx->mesh_cap * 3))) return rc;
+    }
+    hipStream_t s = cur_stream(ctx);
+    const size_t b3 = sizeof(float) * 3 * (size_t)N, b1 = sizeof(float) * (size_t)N;
+    FD_HIP(ctx, hipMemcpyAsync(ctx->m_P, P, b3, hipMemcpyHostToDevice, s));
+    if (dist2) FD_HIP(ctx, hipMemcpyAsync(ctx->m_dist2, dist2, b1, hipMemcpyHostToDevice, s));
+    if (tu) {
+        FD_HIP(ctx, hipMemcpyAsync(ctx->m_tu, tu, b3, hipMemcpyHostToDevice, s));
+        FD_HIP(ctx, hipMemcpyAsync(ctx->m_tv, tv, b3, hipMemcpyHostToDevice, s));
+        FD_HIP(ctx, hipMemcpyAsync(ctx->m_nrm, nrm, b3, hipMemcpyHostToDevice, s));
+    }
+    FD_HIP(ctx, hipStreamSynchronize(s));      // the caller's arrays may change after this returns
+    ctx->mesh_N = N;
+    ctx->mesh_has_dist2 = dist2 != nullptr;
+    ctx->mesh_has_frames = tu != nullptr;
+    return FD_OK;
+}
+
+int64_t fd_mesh_size(const fd_ctx *ctx) { return ctx ? ctx->mesh_N : 0; }
+
+int fd_deform_mesh(fd_ctx *ctx, float *P_out, float *falloff_out, float radius2, float falloffrate)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (ctx->mesh_N <= 0) { set_err(ctx, "fd_deform_mesh: fd_mesh_set has not been called"); return FD_E_INVALID; }
+    if (!P_out) { set_err(ctx, "fd_deform_mesh: P_out is NULL"); return FD_E_INVALID; }
+    if (!ctx->built && !ctx->build_pending) { set_err(ctx, "fd_deform_mesh: no successfully built model"); return FD_E_NOT_BUILT; }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const int64_t N = ctx->mesh_N;
+    hipStream_t s = cur_stream(ctx);
+    const float *d2 = ctx->mesh_has_dist2 ? ctx->m_dist2 : nullptr;
+    const float *tu = ctx->mesh_has_frames ? ctx->m_tu : nullptr, *tv = ctx->mesh_has_frames ? ctx->m_tv : nullptr,
+                *nr = ctx->mesh_has_frames ? ctx->m_nrm : nullptr;
+    // page-locked outputs: the kernel reads the mesh from HBM and writes the results straight
+    // into the caller's arrays -- the only traffic on the host link is the result itself
+    static const bool no_zero_copy = getenv("FD_NO_ZEROCOPY") != nullptr;
+    if (!no_zero_copy && host_is_pinned(P_out) && (!falloff_out || host_is_pinned(falloff_out))) {
+        void *zo = nullptr, *zf = nullptr;
+        bool ok = hipHostGetDevicePointer(&zo, P_out, 0) == hipSuccess;
+        if (ok && falloff_out) ok = hipHostGetDevicePointer(&zf, falloff_out, 0) == hipSuccess;
+        if (ok) {
+            rc = fd_deform_dev_stream(ctx, s, N, ctx->m_P, (float *)zo, d2, (float *)zf, tu, tv, nr, radius2, falloffrate);
+            if (rc) return rc;
+            FD_HIP(ctx, hipStreamSynchronize(s));
+            return FD_OK;
+        }
+        (void)hipGetLastError();
+    }
+    if (!ctx->m_out && (rc = dev_alloc(ctx, &ctx->m_out, (size_t)ctx->mesh_cap * 3))) return rc;
+    if (falloff_out && !ctx->m_fall && (rc = dev_alloc(ctx, &ctx->m_fall, (size_t)ctx->mesh_cap))) return rc;
+    const size_t b3 = sizeof(float) * 3 * (size_t)N, b1 = sizeof(float) * (size_t)N;
+    // a gated vertex keeps the caller's fd_falloff entry (see fd_deform)
+    if (falloff_out && (d2 || radius2 < 0.f)) FD_HIP(ctx, hipMemcpyAsync(ctx->m_fall, falloff_out, b1, hipMemcpyHostToDevice, s));
+    rc = fd_deform_dev_stream(ctx, s, N, ctx->m_P, ctx->m_out, d2, falloff_out ? ctx->m_fall : nullptr, tu, tv, nr, radius2,
+                              falloffrate);
+    if (rc) return rc;
+    FD_HIP(ctx, hipMemcpyAsync(P_out, ctx->m_out, b3, hipMemcpyDeviceToHost, s));
+    if (falloff_out) FD_HIP(ctx, hipMemcpyAsync(falloff_out, ctx->m_fall, b1, hipMemcpyDeviceToHost, s));
+    FD_HIP(ctx, hipStreamSynchronize(s));
+    return FD_OK;
 }
 
 static int require_built(fd_ctx *ctx, const char *who)

@@ -74,6 +74,8 @@ T sys_max(T a, T b) { return a > b ? a : b; }
 struct fdsop_node {
     fd_config cfg{};
     fd_ctx *engine = nullptr;
+    // what the engine's device-resident mesh (fd_mesh_set) was uploaded with
+    bool mesh_had_dist2 = false, mesh_had_frames = false;
     fd_morph *morph = nullptr;        // m_direct_blends (:SOP_FaceDeform.hpp), lives as long as the node
     int morph_device = -2;
     double fval[kNumParms][2];
@@ -353,11 +355,23 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     if (geo->fd_falloff && geo->npoints > 0) memset(geo->fd_falloff, 0, sizeof(float) * (size_t)geo->npoints);
     const float radius_sqrt = radius * radius;   // :402 (a square, despite the name)
 
-    // :404-439
+    // :404-439.  The mesh arrays go to the device through fd_mesh_set; when the caller vouches
+    // that input 0 is the one of the previous cook (same data IDs) the upload is skipped and the
+    // cook moves only its results over the host link.
     pass.armed = false;
-    rc = fd_deform(ctx, geo->npoints, geo->P, geo->P_out, geo->dist2, geo->fd_falloff,
-                   do_tangent_disp ? geo->tangentu : nullptr, do_tangent_disp ? geo->tangentv : nullptr,
-                   do_tangent_disp ? geo->N : nullptr, radius_sqrt, falloffrate);
+    rc = FD_OK;
+    if (geo->npoints > 0) {
+        const bool want_d2 = geo->dist2 != nullptr;
+        const bool reuse = geo->mesh_unchanged && fd_mesh_size(ctx) == geo->npoints &&
+                           node->mesh_had_dist2 == want_d2 && node->mesh_had_frames == do_tangent_disp;
+        if (!reuse) {
+            rc = fd_mesh_set(ctx, geo->npoints, geo->P, geo->dist2, do_tangent_disp ? geo->tangentu : nullptr,
+                             do_tangent_disp ? geo->tangentv : nullptr, do_tangent_disp ? geo->N : nullptr);
+            node->mesh_had_dist2 = want_d2;
+            node->mesh_had_frames = do_tangent_disp;
+        }
+        if (rc == FD_OK) rc = fd_deform_mesh(ctx, geo->P_out, geo->fd_falloff, radius_sqrt, falloffrate);
+    }
     if (rc != FD_OK) {
         std::string t = std::string("GPU deformation failed: ") + fd_last_error(ctx);
         node->add(FDSOP_ERROR, t.c_str());

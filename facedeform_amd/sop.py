@@ -104,7 +104,7 @@ class FaceDeformSOP:
     # -- cook
     def cook(self, mesh_P, rest_P, deform_P, dist2=None, tangentu=None, tangentv=None, N=None,
              out_P=None, out_falloff=None, want_Cd=True, shapes=None, rest=None, rest_changed=False,
-             blends_changed=False, rig_rest_unchanged=False) -> CookResult:
+             blends_changed=False, rig_rest_unchanged=False, mesh_unchanged=False) -> CookResult:
         """out_P / out_falloff: caller-owned result arrays (e.g. page-locked ones from
         capi.host_array, as the HDK wrapper keeps them): with every mesh array page-locked the
         evaluation runs in place over the host link.  want_Cd=False leaves the Cd fill to the
@@ -150,7 +150,7 @@ class FaceDeformSOP:
                             C.cast(sh_counts, C.POINTER(C.c_int64)) if ns else None, ptr(rest_attr),
                             int(bool(rest_changed)), int(bool(blends_changed)),
                             weights.ctypes.data_as(C.POINTER(C.c_double)), C.pointer(wcount),
-                            int(bool(rig_rest_unchanged)))
+                            int(bool(rig_rest_unchanged)), int(bool(mesh_unchanged)))
         sev = self.L.fdsop_cook(self.node, C.byref(geo))
         text = self.L.fdsop_messages(self.node).decode()
         msgs = [tuple(line.split("\t", 1)) for line in text.splitlines() if "\t" in line]

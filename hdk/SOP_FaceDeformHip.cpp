@@ -264,6 +264,11 @@ protected:
             int rigChanged = 1;
             checkChangedSourceFlags(1, context, &rigChanged);
             geo.rig_rest_unchanged = !rigChanged;
+            // input 0 again, untouched (its attributes keep their data IDs when nothing upstream
+            // recooked)?  Then the engine's device-resident mesh is still good.
+            int meshChanged = 1;
+            checkChangedSourceFlags(0, context, &meshChanged);
+            geo.mesh_unchanged = !meshChanged;
         }
         fdsop_cook(myNode, &geo);
 

@@ -163,6 +163,20 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
                          const float *d_dist2, float *d_falloff_out, const float *d_tu,
                          const float *d_tv, const float *d_nrm, float radius2, float falloffrate);
 
+/* ---- device-resident mesh (next row N3, engine side) --------------------------
+ * In an animated shot the mesh on input 0 -- P, the capture's dist2, the tangent
+ * frames -- is the same from cook to cook (Houdini tells by the attributes' data
+ * IDs) while the rig moves.  fd_mesh_set uploads those arrays once (host
+ * pointers; dist2 and the three frame arrays optional; synchronous);
+ * fd_deform_mesh evaluates the current model on them and delivers P_out (and
+ * falloff_out, may be NULL) into host arrays: written in place over the host link
+ * when they are page-locked, through a device staging copy otherwise.  Same
+ * results as fd_deform on the same arrays. */
+int fd_mesh_set(fd_ctx *ctx, int64_t N, const float *P, const float *dist2, const float *tu, const float *tv,
+                const float *nrm);
+int64_t fd_mesh_size(const fd_ctx *ctx);
+int fd_deform_mesh(fd_ctx *ctx, float *P_out, float *falloff_out, float radius2, float falloffrate);
+
 /* ---- model access -----------------------------------------------------------
  * W is (M+4) x 3 fp64 row-major: M RBF weights, the constant row, the x,y,z
  * linear rows (zero when the term lacks them).  radii (may be NULL) gets M
@@ -315,6 +329,10 @@ typedef struct fdsop_geo {
      * tells the wrapper.  Then only the deltas are new and the engine reuses its factorisation
      * (fd_set_deltas); 0 = rebuild, as the reference does every cook (B12). */
     int rig_rest_unchanged;
+    /* The arrays of input 0 (P, dist2, tangent frames) are the ones of the previous cook -- their
+     * data IDs did not change.  Then the engine's device-resident copy (fd_mesh_set) is used and
+     * nothing of the mesh is uploaded; 0 = upload. */
+    int mesh_unchanged;
 } fdsop_geo;
 
 fdsop_node *fdsop_create(const fd_config *cfg);

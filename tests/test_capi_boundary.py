@@ -34,6 +34,8 @@ def test_abi_version(hip_lib):
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.FdConfig) == 32
     assert C.sizeof(capi.FdReport) == 32
+    assert C.sizeof(capi.FdsopGeo) == 21 * 8   # (the two trailing int flags share the last slot)
+    assert capi.FdsopGeo.mesh_unchanged.offset == 20 * 8 + 4
     assert C.sizeof(capi.FdsopGeo) == 21 * 8   # 13 mesh/rig fields + 7 morph-space fields (two ints share a slot) + the rig flag
 
 

@@ -142,3 +142,29 @@ def test_cook_with_unchanged_rest_rig(hip_lib):
     rest2 = synth.control_points(50, "head")
     res3 = node.cook(P, rest2, synth.deformed_rig(rest2, 1), rig_rest_unchanged=True)
     assert np.array_equal(res3.P, fresh.cook(P, rest2, synth.deformed_rig(rest2, 1)).P)
+
+
+def test_cook_with_unchanged_mesh(hip_lib):
+    """mesh_unchanged: the second cook evaluates the device-resident mesh; same bits as a fresh
+    node.  Toggling the tangent parm or the dist2 input changes what the cache must hold and
+    re-uploads silently."""
+    from facedeform_amd.sop import FaceDeformSOP
+    P = synth.head_mesh(30_000)
+    rest = synth.control_points(64, "head")
+    tu, tv, nn = synth.tangent_frames(P)
+    d2 = (0.5 * np.abs(P[:, 1])).astype(np.float32)
+    node, fresh = FaceDeformSOP(), FaceDeformSOP()
+    for n in (node, fresh):
+        n.set("kernel", 1); n.set("radius", 0.6)
+    node.cook(P, rest, synth.deformed_rig(rest, 0), dist2=d2)
+    res = node.cook(P, rest, synth.deformed_rig(rest, 1), dist2=d2, mesh_unchanged=True, rig_rest_unchanged=True)
+    ref = fresh.cook(P, rest, synth.deformed_rig(rest, 1), dist2=d2)
+    assert np.array_equal(res.P, ref.P) and np.array_equal(res.fd_falloff, ref.fd_falloff)
+    for n in (node, fresh):
+        n.set("tangent", 1)
+    res = node.cook(P, rest, synth.deformed_rig(rest, 2), dist2=d2, tangentu=tu, tangentv=tv, N=nn, mesh_unchanged=True)
+    ref = fresh.cook(P, rest, synth.deformed_rig(rest, 2), dist2=d2, tangentu=tu, tangentv=tv, N=nn)
+    assert np.array_equal(res.P, ref.P)
+    res = node.cook(P, rest, synth.deformed_rig(rest, 2), tangentu=tu, tangentv=tv, N=nn, mesh_unchanged=True)   # dist2 gone
+    ref = fresh.cook(P, rest, synth.deformed_rig(rest, 2), tangentu=tu, tangentv=tv, N=nn)
+    assert np.array_equal(res.P, ref.P) and res.warnings == ref.warnings

@@ -183,3 +183,41 @@ def test_pinned_host_arrays_take_the_chunked_path_bit_identically(hip_lib):
             gated = dist2 > np.float32(0.49)
             assert gated.any() and np.array_equal(pin_P[gated], P[gated]) and np.all(pin_fall[gated] == 7.0)
     e.close()
+
+
+def test_device_resident_mesh_gives_the_same_bits(hip_lib):
+    """fd_mesh_set + fd_deform_mesh (next row N3, engine side): the mesh arrays are uploaded once;
+    every later cook must produce exactly what fd_deform produces from host arrays -- into
+    pageable and into page-locked outputs, with gating, fall-off and tangent frames, across
+    model changes (fd_set_deltas) and a smaller mesh set afterwards."""
+    N, M = 300_007, 128
+    rng = np.random.default_rng(12)
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    e = capi.Engine()
+    e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+    e.set_points(rest, synth.smooth_deltas(rest, 0).astype(np.float32)); e.build()
+    dist2 = (rng.random(N) * 0.6).astype(np.float32); dist2[::13] = -1.0
+    tu, tv, nn = synth.tangent_frames(P)
+    with pytest.raises(capi.FdError):
+        e.deform_mesh(np.empty_like(P))                       # nothing cached yet
+    for d2, tan in ((None, None), (dist2, None), (dist2, (tu, tv, nn))):
+        e.mesh_set(P, d2, tan)
+        for frame in (0, 1):
+            if frame:
+                e.set_deltas(synth.smooth_deltas(rest, frame).astype(np.float32)); e.build()
+            ref = np.empty_like(P); ref_fall = np.full(N, 3.0, np.float32)
+            e.deform_into(P, ref, d2, ref_fall, tan, radius2=0.3, falloffrate=1.25)
+            out = np.empty_like(P); fall = np.full(N, 3.0, np.float32)
+            e.deform_mesh(out, fall, radius2=0.3, falloffrate=1.25)
+            assert np.array_equal(out, ref) and np.array_equal(fall, ref_fall)
+            pin_out = capi.host_array((N, 3)); pin_fall = capi.host_array(N); pin_fall[:] = 3.0
+            e.deform_mesh(pin_out, pin_fall, radius2=0.3, falloffrate=1.25)
+            assert np.array_equal(pin_out, ref) and np.array_equal(pin_fall, ref_fall)
+    small = P[:1000].copy()
+    e.mesh_set(small)
+    out = np.empty_like(small)
+    e.deform_mesh(out)
+    ref = np.empty_like(small); e.deform_into(small, ref)
+    assert np.array_equal(out, ref)
+    e.close()

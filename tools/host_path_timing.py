@@ -51,4 +51,21 @@ for f in range(10):
     t0 = time.perf_counter(); res = node.cook(pin_in, rest, synth.deformed_rig(rest, f), out_P=pin_out, out_falloff=pin_fall, want_Cd=False, rig_rest_unchanged=True); ts.append(time.perf_counter() - t0)
 ts = sorted(ts[2:])
 print(f"... and the rest rig unchanged from cook to cook (fd_set_deltas: factorisation reused): median {ts[len(ts)//2]*1e3:.3f} ms; severity {res.severity}")
+# static mesh + animated rig, engine level: mesh on the device (fd_mesh_set), deltas only (fd_set_deltas)
+e.set_points(rest, synth.smooth_deltas(rest, 0)); e.build()
+e.mesh_set(P)
+for label, (a_out, a_fall) in (("pageable outputs", (page_out, page_fall)), ("page-locked outputs", (pin_out, pin_fall))):
+    ts = []
+    for f in range(12):
+        delta = synth.smooth_deltas(rest, f)
+        t0 = time.perf_counter()
+        e.set_deltas(delta); e.build(); e.deform_mesh(a_out, a_fall)
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[2:])
+    print(f"static mesh on the device + fd_set_deltas + fd_deform_mesh, {label}: median {ts[len(ts)//2]*1e3:.3f} ms -> {N/ts[len(ts)//2]/1e6:.0f} Mverts/s")
+ts = []
+for f in range(10):
+    t0 = time.perf_counter(); res = node.cook(pin_in, rest, synth.deformed_rig(rest, f), out_P=pin_out, out_falloff=pin_fall, want_Cd=False, rig_rest_unchanged=True, mesh_unchanged=True); ts.append(time.perf_counter() - t0)
+ts = sorted(ts[2:])
+print(f"fdsop_cook, page-locked arrays, rest rig AND mesh unchanged from cook to cook (the animated-shot case): median {ts[len(ts)//2]*1e3:.3f} ms; severity {res.severity}")
 
