@@ -15,8 +15,10 @@ int main()
     for (int j = 0; j < npad; ++j)
         for (int i = 0; i < npad; ++i)
             A[(size_t)j * lda + i] = (i < n && j < n) ? (double)rand() / RAND_MAX - 0.5 : (i == j ? 1.0 : 0.0);
-    double *dA; int *dipiv, *dmoves; DevModel *dm;
-    hipMalloc(&dA, A.size() * 8); hipMalloc(&dipiv, npad * 4); hipMalloc(&dmoves, 512 * 4); hipMalloc(&dm, sizeof(DevModel));
+    double *dA; int *dipiv, *dmoves; DevModel *dm; BatchSlot *dslot;
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dipiv, npad * 4); hipMalloc(&dmoves, kMovesStride * lu_step_capacity(npad) * 4);
+    hipMalloc(&dm, sizeof(DevModel)); hipMalloc(&dslot, sizeof(BatchSlot));
+    { BatchSlot hs{}; hs.A = dA; hs.ipiv = dipiv; hs.moves = dmoves; hs.model = dm; hipMemcpy(dslot, &hs, sizeof(hs), hipMemcpyHostToDevice); }
     DevModel hm{}; { const double amax = 0.5; unsigned long long bits; __builtin_memcpy(&bits, &amax, 8); hm.amax_bits = bits; } hm.pivmin_bits = 0x7FF0000000000000ull;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int threads : {320, 256, 128, 64}) {
@@ -26,7 +28,7 @@ int main()
             hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
             hipMemcpy(dm, &hm, sizeof(hm), hipMemcpyHostToDevice);
             hipEventRecord(e0);
-            hipLaunchKernelGGL((k_lu_panel<32, 512>), dim3(1), dim3(threads), 0, 0, dA, lda, npad, n, k0 < 0 ? 0 : k0, dipiv, dmoves, dm);
+            hipLaunchKernelGGL((k_lu_panel<32, 512>), dim3(1), dim3(threads), 0, 0, dslot, lda, npad, n, k0 < 0 ? 0 : k0, 0);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
         }
