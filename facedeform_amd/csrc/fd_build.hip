@@ -897,6 +897,22 @@ __global__ __launch_bounds__(64) void k_pack_tiles(const BatchSlot *tab, int Mpa
     }
     if (lane < 16) t.pad[lane] = 0.f;
     (void)Mpad;
+
+    // fp16 form: pieces hi = RN16(v), lo = RN16(v - hi).  Lane group g < 3: {c_hi, c_hi, c_lo, c_lo}
+    // against the vertex's {x_hi, x_lo, x_hi, x_lo}; group 3: {|c|^2_hi, |c|^2_lo, 1, 1} against
+    // {1, 1, |x|^2_hi, |x|^2_lo}.
+    MfmaTileH *tiles16 = tab[blockIdx.z].tiles16;
+    if (tiles16) {
+        MfmaTileH &th = tiles16[tile];
+        const float v = g < 3 ? (g == 0 ? r.cx : (g == 1 ? r.cy : r.cz)) : fmaf(r.cz, r.cz, fmaf(r.cy, r.cy, r.cx * r.cx));
+        const _Float16 vh = (_Float16)v;
+        const _Float16 vl = (_Float16)(v - (float)vh);
+        const unsigned uh = (unsigned)__builtin_bit_cast(unsigned short, vh), ul = (unsigned)__builtin_bit_cast(unsigned short, vl);
+        if (g < 3) { th.a[lane][0] = uh | (uh << 16); th.a[lane][1] = ul | (ul << 16); }
+        else { th.a[lane][0] = uh | (ul << 16); th.a[lane][1] = 0x3c003c00u; }
+        if (i < 12) th.w[g][i] = t.w[g][i];
+        if (lane < 16) th.pad[lane] = 0.f;
+    }
 }
 
 // NB of the panel that starts at column k0 (the register budget of one workgroup decides)

@@ -42,6 +42,7 @@ struct fd_ctx {
     Rec32 *d_rec32 = nullptr;
     Rec64 *d_rec64 = nullptr;
     MfmaTile *d_tiles = nullptr;
+    MfmaTileH *d_tiles16 = nullptr;
     DevModel *d_model = nullptr;
     DevModel *h_model = nullptr;  // pinned mirror
     // where the build kernels find the buffers above: a one-entry device table (a single build
@@ -177,6 +178,7 @@ static int ensure_model_capacity(fd_ctx *ctx, int M)
         if ((rc = dev_alloc(ctx, &ctx->d_rec32, (size_t)Mpad))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_rec64, (size_t)Mpad))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_tiles, (size_t)Mpad / 16))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_tiles16, (size_t)Mpad / 16))) return rc;
         ctx->cap_M = M;
     }
     return FD_OK;
@@ -224,7 +226,7 @@ static int sync_slot(fd_ctx *ctx)
     t.centres = ctx->d_centres; t.radii = ctx->d_radii;
     t.A = ctx->d_A; t.X = ctx->d_X; t.W = ctx->d_W;
     t.ipiv = ctx->d_ipiv; t.moves = ctx->d_moves;
-    t.rec32 = ctx->d_rec32; t.rec64 = ctx->d_rec64; t.tiles = ctx->d_tiles;
+    t.rec32 = ctx->d_rec32; t.rec64 = ctx->d_rec64; t.tiles = ctx->d_tiles; t.tiles16 = ctx->d_tiles16;
     t.model = ctx->d_model;
     if (ctx->alloc_gen != 0 && memcmp(&t, &ctx->h_slot, sizeof(t)) == 0) return FD_OK;
     // a buffer moved: hipFree in dev_alloc has drained the device, nothing reads the old table
@@ -317,7 +319,7 @@ void fd_destroy(fd_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream_ || ctx->own_stream) (void)hipStreamSynchronize(cur_stream(ctx));
     void *bufs[] = {ctx->d_rest, ctx->d_delta, ctx->d_centres, ctx->d_radii, ctx->d_W, ctx->d_A,
-                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_model, ctx->d_slot,
+                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_tiles16, ctx->d_model, ctx->d_slot,
                     ctx->d_P, ctx->d_dist2, ctx->d_fall, ctx->d_tu, ctx->d_tv, ctx->d_nrm,
                     ctx->m_P, ctx->m_dist2, ctx->m_tu, ctx->m_tv, ctx->m_nrm, ctx->m_out, ctx->m_fall};
     for (void *p : bufs) if (p) (void)hipFree(p);
@@ -654,7 +656,7 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
     a.tu = d_tu; a.tv = d_tv; a.nrm = d_nrm;
     a.radius2 = radius2; a.falloffrate = falloffrate;
     a.M = ctx->M; a.Mpad = round_up(ctx->M, kRecPad); a.kind = ctx->kind;
-    a.rec32 = ctx->d_rec32; a.rec64 = ctx->d_rec64; a.tiles = ctx->d_tiles;
+    a.rec32 = ctx->d_rec32; a.rec64 = ctx->d_rec64; a.tiles = ctx->d_tiles; a.tiles16 = ctx->d_tiles16;
     a.model = ctx->d_model;
     a.precision = ctx->eval_precision;
     a.variant = ctx->eval_variant;

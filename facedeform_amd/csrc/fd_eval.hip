@@ -24,6 +24,8 @@
 // bit-identical) and the fp32 epilogue rounds like the reference's unfused CPU code.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "fd_internal.h"
 
 namespace fd {
@@ -50,6 +52,7 @@ struct EvalParams {
     const Rec32 *rec32;
     const Rec64 *rec64;
     const MfmaTile *tiles;
+    const MfmaTileH *tiles16;
     const DevModel *model;
 };
 
@@ -404,13 +407,21 @@ __device__ __forceinline__ GroupIn<TV> load_group(const EvalParams &p, int64_t v
     return in;
 }
 
-template <int TV>
+// HALF = false: bf16 x 3 pieces, K = 32 (MfmaTile).  HALF = true: fp16 x 2 pieces, K = 16
+// (MfmaTileH): half the matrix-pipe time and operand bytes, about twice the d2 rounding error.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int TV, bool HALF>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_deform32_tps_mfma(const EvalParams p, int ngroups)
 {
     static_assert(TV % 4 == 0, "a lane group finishes one tile of every quartet");
+    using Tile = typename std::conditional<HALF, MfmaTileH, MfmaTile>::type;
+    using Operand = typename std::conditional<HALF, f16x4, bf16x8>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const MfmaTile *lds_tiles = reinterpret_cast<const MfmaTile *>(smem);
+    const Tile *lds_tiles = reinterpret_cast<const Tile *>(smem);
+    const Tile *gl_tiles;
+    if constexpr (HALF) gl_tiles = p.tiles16; else gl_tiles = p.tiles;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
@@ -423,9 +434,9 @@ void k_deform32_tps_mfma(const EvalParams p, int ngroups)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto stage = [&](int ct0, int nct) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.tiles + ct0);
+        const uint4 *src = reinterpret_cast<const uint4 *>(gl_tiles + ct0);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        const int n16 = nct * (int)(sizeof(MfmaTile) / 16);
+        const int n16 = nct * (int)(sizeof(Tile) / 16);
         __syncthreads();
         for (int q = tid; q < n16; q += kBlock) dst[q] = src[q];
         __syncthreads();
@@ -446,7 +457,7 @@ void k_deform32_tps_mfma(const EvalParams p, int ngroups)
         }
 
         // B operand (vertex side) of every vertex tile of this wave
-        bf16x8 bop[TV];
+        Operand bop[TV];
 #pragma unroll
         for (int t = 0; t < TV; ++t) {
             // coordinate g of vertex (tile t, column j): it sits in lane group t & 3 of quartet t / 4
@@ -459,16 +470,26 @@ void k_deform32_tps_mfma(const EvalParams p, int ngroups)
             xx += __shfl_xor(xx, 16);
             xx += __shfl_xor(xx, 32);
             const float v2 = g < 3 ? -2.f * comp : xx;
-            const unsigned u = __float_as_uint(v2);
-            const float r1 = v2 - __uint_as_float(u & 0xffff0000u);
-            const unsigned u1 = __float_as_uint(r1);
-            const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-            const short h = (short)(u >> 16), m = (short)(u1 >> 16), l = (short)(__float_as_uint(r2) >> 16);
-            const short one = (short)0x3f80;
-            bf16x8 b;
-            if (g < 3) b = (bf16x8){h, m, h, m, l, h, 0, 0};
-            else b = (bf16x8){one, one, one, h, m, l, 0, 0};
-            bop[t] = b;
+            if constexpr (HALF) {
+                const _Float16 h = (_Float16)v2;
+                const _Float16 l = (_Float16)(v2 - (float)h);
+                const _Float16 one = (_Float16)1.0f;
+                f16x4 b;
+                if (g < 3) b = (f16x4){h, l, h, l};          // against {c_hi, c_hi, c_lo, c_lo}
+                else b = (f16x4){one, one, h, l};            // against {|c|^2_hi, |c|^2_lo, 1, 1}
+                bop[t] = b;
+            } else {
+                const unsigned u = __float_as_uint(v2);
+                const float r1 = v2 - __uint_as_float(u & 0xffff0000u);
+                const unsigned u1 = __float_as_uint(r1);
+                const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                const short h = (short)(u >> 16), m = (short)(u1 >> 16), l = (short)(__float_as_uint(r2) >> 16);
+                const short one = (short)0x3f80;
+                bf16x8 b;
+                if (g < 3) b = (bf16x8){h, m, h, m, l, h, 0, 0};
+                else b = (bf16x8){one, one, one, h, m, l, 0, 0};
+                bop[t] = b;
+            }
         }
         bool lane_live = false;
 #pragma unroll
@@ -488,8 +509,8 @@ void k_deform32_tps_mfma(const EvalParams p, int ngroups)
             if (!resident) stage(ct0, nct);
             if (wave_work) {
                 for (int ct = 0; ct < nct; ++ct) {
-                    const MfmaTile &tile = lds_tiles[ct];
-                    const bf16x8 aop = *reinterpret_cast<const bf16x8 *>(&tile.a[lane][0]);
+                    const Tile &tile = lds_tiles[ct];
+                    const Operand aop = *reinterpret_cast<const Operand *>(&tile.a[lane][0]);
                     const float4 w0 = *reinterpret_cast<const float4 *>(&tile.w[g][0]);
                     const float4 w1 = *reinterpret_cast<const float4 *>(&tile.w[g][4]);
                     const float4 w2 = *reinterpret_cast<const float4 *>(&tile.w[g][8]);
@@ -497,7 +518,10 @@ void k_deform32_tps_mfma(const EvalParams p, int ngroups)
                     const f32x2 wB[3] = {(f32x2){w1.z, w1.w}, (f32x2){w2.x, w2.y}, (f32x2){w2.z, w2.w}};   // rows 2,3
                     f32x4 d[TV];
 #pragma unroll
-                    for (int t = 0; t < TV; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop[t], zero4, 0, 0, 0);
+                    for (int t = 0; t < TV; ++t) {
+                        if constexpr (HALF) d[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(aop, bop[t], zero4, 0, 0, 0);
+                        else d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop[t], zero4, 0, 0, 0);
+                    }
 #pragma unroll
                     for (int t = 0; t < TV; ++t) {
                         const f32x2 tA = {d2_log_d2(d[t][0]), d2_log_d2(d[t][1])};
@@ -640,8 +664,12 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
     int variant = a.variant > 0 ? a.variant : kDefaultVariant;
     // thin-plate with at least four centre tiles: d2 on the matrix pipe (variant 200) is the
     // faster kernel (C2 68 vs 80 us, C3 429 vs 540 us); below that its per-group set-up shows
-    if (a.variant <= 0 && KIND == FD_KERNEL_THIN_PLATE && a.tiles != nullptr && a.Mpad >= 64) variant = 200;
-    if (variant == 200) {
+    if (a.variant <= 0 && KIND == FD_KERNEL_THIN_PLATE && a.tiles != nullptr && a.Mpad >= 64) {
+        static const bool bf16_tiles = getenv("FD_MFMA_BF16") != nullptr;
+        variant = (a.tiles16 != nullptr && !bf16_tiles) ? 202 : 200;
+    }
+    if (variant == 202 && a.tiles16 == nullptr) variant = 200;
+    if (variant == 200 || variant == 202) {
         if constexpr (KIND == FD_KERNEL_THIN_PLATE) {
             constexpr int TV = 4;
             const int64_t per = (int64_t)kBlock / 64 * 16 * TV;     // vertices per workgroup
@@ -656,8 +684,13 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
             const int64_t rounds = (ngroups + max_grid - 1) / max_grid;
             const unsigned grid = (unsigned)((ngroups + rounds - 1) / rounds);
             const int ntiles = a.Mpad / 16;
-            const size_t lds = sizeof(MfmaTile) * (size_t)(ntiles < kTileChunk ? ntiles : kTileChunk);
-            hipLaunchKernelGGL((k_deform32_tps_mfma<TV>), dim3(grid), dim3(kBlock), lds, stream, p, (int)ngroups);
+            const size_t nres = (size_t)(ntiles < kTileChunk ? ntiles : kTileChunk);
+            if (variant == 202)
+                hipLaunchKernelGGL((k_deform32_tps_mfma<TV, true>), dim3(grid), dim3(kBlock), sizeof(MfmaTileH) * nres, stream,
+                                   p, (int)ngroups);
+            else
+                hipLaunchKernelGGL((k_deform32_tps_mfma<TV, false>), dim3(grid), dim3(kBlock), sizeof(MfmaTile) * nres, stream,
+                                   p, (int)ngroups);
             return hipGetLastError();
         } else {
             variant = kDefaultVariant;   // the matrix-pipe path exists for thin-plate only
@@ -708,7 +741,7 @@ hipError_t launch_deform(const DeformArgs &a, hipStream_t stream)
     p.tu = a.tu; p.tv = a.tv; p.nrm = a.nrm;
     p.radius2 = a.radius2; p.falloffrate = a.falloffrate;
     p.Mpad = a.Mpad;
-    p.rec32 = a.rec32; p.rec64 = a.rec64; p.tiles = a.tiles;
+    p.rec32 = a.rec32; p.rec64 = a.rec64; p.tiles = a.tiles; p.tiles16 = a.tiles16;
     p.model = a.model;
     switch (a.kind) {
     case FD_KERNEL_GAUSSIAN:

@@ -36,6 +36,17 @@ struct MfmaTile {
 };
 static_assert(sizeof(MfmaTile) == 1280, "tile image must stay 1280 bytes");
 
+// The same tile for v_mfma_f32_16x16x16_f16: every fp32 value as TWO fp16 pieces (hi + lo, 22
+// bits; fp16 subnormals are honoured by the matrix pipe, tools/mfma_f16_subnormal_test.hip), all
+// four cross products per coordinate in K = 16.  Half the operand bytes and half the MFMA time
+// of the bf16 tile, at ~2x its d2 rounding error.  768 B.
+struct MfmaTileH {
+    unsigned int a[64][2];   // lane l: 4 fp16 = k-slots 4*(l>>4) .. +3 of centre (l&15)
+    float w[4][12];          // as MfmaTile::w
+    float pad[16];
+};
+static_assert(sizeof(MfmaTileH) == 768, "fp16 tile image must stay 768 bytes");
+
 // Device-resident build status + affine part; read by the deform kernel so that
 // an asynchronous build needs no host round trip before the deform launch.
 struct DevModel {
@@ -93,6 +104,7 @@ struct BatchSlot {
     Rec32 *rec32;
     Rec64 *rec64;
     MfmaTile *tiles;                  // Mpad / 16 tiles (thin-plate only)
+    MfmaTileH *tiles16;               // the fp16 form of the same tiles
     DevModel *model;
 };
 
@@ -133,6 +145,7 @@ struct DeformArgs {
     int M, Mpad, kind;
     const Rec32 *rec32; const Rec64 *rec64;
     const MfmaTile *tiles;
+    const MfmaTileH *tiles16;
     const DevModel *model;
     int precision, variant;
 };

@@ -73,7 +73,7 @@ def test_golden_points_deform_all_kernels(hip_lib, oracle, golden, precision, to
         e.close()
 
 
-@pytest.mark.parametrize("variant", [0, 2, 12, 101, 103, 112, 200])
+@pytest.mark.parametrize("variant", [0, 2, 12, 101, 103, 112, 200, 202])
 def test_c1_sphere_matches_oracle(hip_lib, oracle, variant):
     """BASELINE config 1: 10k-vertex sphere, 32 control points, thin-plate, linear term."""
     P = synth.sphere_mesh(10_000)
@@ -321,9 +321,10 @@ def test_length_unit_and_origin_do_not_cost_accuracy(hip_lib, oracle, scale, off
         e.close()
 
 
+@pytest.mark.parametrize("variant", [200, 202])
 @pytest.mark.parametrize("M,N", [(32, 10_007), (48, 4_099), (256, 20_000), (800, 3_001)])
-def test_matrix_pipe_variant_matches_oracle(hip_lib, oracle, M, N):
-    """Variant 200: d2 on the bf16 MFMA (thin-plate).  Ragged N, M that is not a multiple of
+def test_matrix_pipe_variant_matches_oracle(hip_lib, oracle, M, N, variant):
+    """Variants 200 / 202: d2 on the matrix pipe (thin-plate), bf16 x 3 pieces / fp16 x 2 pieces.  Ragged N, M that is not a multiple of
     16, more centre tiles than one LDS chunk holds (M = 800 -> 50 tiles), vertices sitting
     exactly on centres (d2 == 0, where rounding may go negative), gate, fall-off, tangents."""
     rng = np.random.default_rng(M)
@@ -337,7 +338,7 @@ def test_matrix_pipe_variant_matches_oracle(hip_lib, oracle, M, N):
     dist2[::9] = -1.0
     table, W, radii = _oracle_model(oracle, fo.KERNEL_THIN_PLATE, [], 0, rest, deform)
     for kw in (dict(), dict(dist2=dist2, radius2=r2, falloffrate=1.5), dict(dist2=dist2, tangents=(tu, tv, nn), radius2=r2)):
-        e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, deform, variant=200)
+        e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, deform, variant=variant)
         e.build()
         out, fall = e.deform(P, **kw)
         ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, **kw)

@@ -75,7 +75,7 @@ def main():
         if "SQ_INSTS_MFMA" in d and sq:
             busy = mean(next(iter(sq.values()))["SQ_BUSY_CYCLES"]) / 32.0
             out.append(f"derived: MFMA pipe busy {mean(d['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024 / busy * 100:.1f}% "
-                       f"({mean(d['SQ_VALU_MFMA_BUSY_CYCLES']) / max(1.0, mean(d['SQ_INSTS_MFMA'])):.0f} cycles per 16x16x32 bf16 MFMA)")
+                       f"({mean(d['SQ_VALU_MFMA_BUSY_CYCLES']) / max(1.0, mean(d['SQ_INSTS_MFMA'])):.0f} cycles per matrix instruction)")
     bd = counters("pmc_build", "k_lu_trail")
     for k, d in bd.items():
         out.append(f"C3 build, {k} per launch: " + ", ".join(f"{c}={mean(v):.0f}" for c, v in sorted(d.items())))
