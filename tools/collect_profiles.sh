@@ -12,7 +12,7 @@ OUT=gpurun_out/profiles_r01
 rm -rf $OUT
 mkdir -p $OUT
 VAR=${FD_PROFILE_VARIANT:-202}
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench_c2 -- python bench.py --steps 192 --warmup 96 --no-cpu-baseline > $OUT/bench_c2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench_c2 -- python bench.py --no-cpu-baseline > $OUT/bench_c2.log 2>&1
 echo "bench exit $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench1 -o bench_c2_single -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --inflight 1 --lanes 1 > $OUT/bench_c2_single.log 2>&1
 echo "bench single exit $?"
