@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=3,
                     help="groups of frames in flight per GPU (one stream + one fd_batch each)")
     ap.add_argument("--event-every", type=int, default=4,
-                    help="bracket every k-th evaluation with HIP events (each pair costs ~5 us of stream time)")
+                    help="evaluations per HIP event pair (a pair costs ~4-5 us of stream time, spread over the run)")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
                     help="evaluations on one stream for all lanes (default) or on each lane's build stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -282,7 +282,7 @@ def main():
     torch.cuda.synchronize()
 
     delta_stride = n_ctrl * 3 * 4
-    ev_idx_set = set()
+    ev_runs, ev_run_ends = {}, {}      # first step of a timed run -> its length; last step -> first step
 
     def group(g, first, count, ev=None):
         """Cook steps first .. first+count-1 (count <= B frames) on lane g % n_lanes."""
@@ -304,14 +304,14 @@ def main():
             ev[first][1].record(stream)
         es = eval_stream if args.eval_stream == "shared" else stream
         for k in range(count):
-            timed = ev is not None and (first + k) in ev_idx_set
-            if timed:
+            # an event pair brackets a run of consecutive evaluations (ev_runs: first step -> length)
+            if ev is not None and (first + k) in ev_runs:
                 ev[first + k][2].record(es)
             # fd_deform_dev_stream makes es wait for the batch that builds this model
             ln["engines"][k].deform_dev_stream(es.cuda_stream, n_verts, d_P.data_ptr(),
                                                ln["out"][k].data_ptr(), d_falloff=ln["fall"][k].data_ptr())
-            if timed:
-                ev[first + k][3].record(es)
+            if ev is not None and (first + k) in ev_run_ends:
+                ev[ev_run_ends[first + k]][3].record(es)
         ln["evals_done"].record(es)
 
     def run_steps(nsteps, ev=None, g0=0):
@@ -344,12 +344,21 @@ def main():
     check_builds()
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    # evaluations that get an event pair: every k-th step, never the first of a group (its pair
-    # would also contain the wait for the group's build)
-    ev_idx = [i for i in range(args.steps) if i % B != 0 and i % max(1, args.event_every) == 1 % max(1, args.event_every)]
-    if not ev_idx:
-        ev_idx = list(range(args.steps))
-    ev_idx_set.update(ev_idx)
+    # One HIP event pair per run of `event_every` consecutive evaluations of a group (the pair's
+    # own cost, ~4 us of launch hand-over, is spread over the run), never starting on the first
+    # evaluation of a group: that one also waits for the group's build.
+    run_len = max(1, args.event_every)
+    i = 0
+    while i < args.steps:
+        g_end = min((i // B + 1) * B, args.steps)
+        start = i + 1 if (i % B == 0 and g_end - i > 1) else i
+        while start < g_end:
+            n = min(run_len, g_end - start)
+            ev_runs[start] = n
+            ev_run_ends[start + n - 1] = start
+            start += n
+        i = g_end
+    ev_idx = sorted(ev_runs)
     sync_all()
     t0 = time.perf_counter()
     run_steps(args.steps, events, g0=0)
@@ -382,14 +391,13 @@ def main():
     group_firsts = list(range(0, args.steps, B))
     build_group_ms = float(np.mean([events[i][0].elapsed_time(events[i][1]) for i in group_firsts]))
     build_ms = build_group_ms / min(B, args.steps)
-    eval_ms = float(np.mean([events[i][2].elapsed_time(events[i][3]) for i in ev_idx]))
+    eval_ms = float(np.sum([events[i][2].elapsed_time(events[i][3]) for i in ev_idx]) / sum(ev_runs[i] for i in ev_idx))
 
     if rank == 0 and os.environ.get("FD_BENCH_GAPS") and args.eval_stream == "shared":
         # idle time on the evaluation stream between consecutive evaluations (diagnostic)
-        pairs = [(a, b) for a, b in zip(ev_idx[:-1], ev_idx[1:]) if a // B == b // B]
-        gaps = np.array([(events[a][3].elapsed_time(events[b][2]) * 1e3 - (b - a - 1) * eval_ms * 1e3) / (b - a)
-                         for a, b in pairs])
-        print(f"[gaps us] idle per evaluation within a group: mean {gaps.mean():.1f} median {np.median(gaps):.1f} "
+        pairs = [(a, b) for a, b in zip(ev_idx[:-1], ev_idx[1:]) if a // B == b // B and a + ev_runs[a] == b]
+        gaps = np.array([events[a][3].elapsed_time(events[b][2]) * 1e3 for a, b in pairs])
+        print(f"[gaps us] idle between consecutive timed runs within a group: mean {gaps.mean():.1f} median {np.median(gaps):.1f} "
               f"max {gaps.max():.1f}", file=sys.stderr, flush=True)
     if rank == 0 and os.environ.get("FD_BENCH_GAPS"):
         base = events[0][0]
