@@ -1,7 +1,7 @@
 """Time every evaluation-kernel variant on one GPU (HIP events on the launch stream) and
 report the parity error of each against the oracle on a vertex sample."""
 import os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from facedeform_amd import capi, synth
 from oracle import fd_oracle as fo

@@ -1,8 +1,8 @@
 """Parity ratio (error / tolerance, tolerance = north_star's 1e-5) of the thin-plate evaluation
 variants on the hard cases: large length unit and far-away origin, small length unit, many centres."""
 import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from conftest import parity_ratio
 from facedeform_amd import capi, synth

@@ -41,7 +41,7 @@ def main():
     mf = counters("pmc_mfma", kern)
     kname = next(iter(fetch), next(iter(sq), "?"))
     out.append(f"rocprofv3 --pmc <counters> --kernel-trace (one counter group per run), evaluation kernel {kname} at C2 "
-               f"(N=1e6, M=256), isolated launches (tools/eval_variants.py)")
+               f"(N=1e6, M=256), isolated launches (tests/tools/eval_variants.py)")
     traffic = {}
     if fetch and write:
         fk = mean(next(iter(fetch.values()))["FETCH_SIZE"])
