@@ -63,6 +63,8 @@ def parse_args():
                     help="groups of frames in flight per GPU (one stream + one fd_batch each)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="evaluations per HIP event pair (a pair costs ~4-5 us of stream time, spread over the run)")
+    ap.add_argument("--eval-launch", choices=["batched", "single"], default="batched",
+                    help="evaluate the frames of a group with one launch (fd_batch_deform_dev) or one launch per frame")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
                     help="evaluations on one stream for all lanes (default) or on each lane's build stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -276,13 +278,14 @@ def main():
             eng.set_term(capi.TERM_LINEAR)
             engines.append(eng)
         lanes.append({"engines": engines, "stream": stream, "batches": {B: capi.Batch(engines)},
-                      "evals_done": torch.cuda.Event(),
+                      "evals_done": torch.cuda.Event(), "built": torch.cuda.Event(),
                       "out": [torch.empty_like(d_P) for _ in range(B)],
                       "fall": [torch.zeros(n_verts, device=dev, dtype=torch.float32) for _ in range(B)]})
     torch.cuda.synchronize()
 
     delta_stride = n_ctrl * 3 * 4
     ev_runs, ev_run_ends = {}, {}      # first step of a timed run -> its length; last step -> first step
+    batched_eval = args.eval_launch == "batched" and B > 1
 
     def group(g, first, count, ev=None):
         """Cook steps first .. first+count-1 (count <= B frames) on lane g % n_lanes."""
@@ -303,6 +306,19 @@ def main():
         if ev:
             ev[first][1].record(stream)
         es = eval_stream if args.eval_stream == "shared" else stream
+        if batched_eval:
+            # ONE launch evaluates the group's frames (grid y = frame).  The evaluation stream is
+            # made to wait for the build here, so that the event pair holds the launch alone.
+            ln["built"].record(stream)
+            es.wait_event(ln["built"])
+            if ev:
+                ev[first][2].record(es)
+            batch.deform_dev(n_verts, [d_P.data_ptr()] * count, [o.data_ptr() for o in ln["out"][:count]],
+                             d_falloff=[f.data_ptr() for f in ln["fall"][:count]], stream_ptr=es.cuda_stream)
+            if ev:
+                ev[first][3].record(es)
+            ln["evals_done"].record(es)
+            return
         for k in range(count):
             # an event pair brackets a run of consecutive evaluations (ev_runs: first step -> length)
             if ev is not None and (first + k) in ev_runs:
@@ -391,9 +407,20 @@ def main():
     group_firsts = list(range(0, args.steps, B))
     build_group_ms = float(np.mean([events[i][0].elapsed_time(events[i][1]) for i in group_firsts]))
     build_ms = build_group_ms / min(B, args.steps)
-    eval_ms = float(np.sum([events[i][2].elapsed_time(events[i][3]) for i in ev_idx]) / sum(ev_runs[i] for i in ev_idx))
+    if batched_eval:
+        # one event pair per evaluation launch; a launch covers the frames of its group
+        g_counts = [min(B, args.steps - i) for i in group_firsts]
+        g_ms = [events[i][2].elapsed_time(events[i][3]) for i in group_firsts]
+        eval_ms = float(np.sum(g_ms) / np.sum(g_counts))                 # per frame
+        full = [m for m, c in zip(g_ms, g_counts) if c == max(g_counts)]
+        frames_per_launch = int(max(g_counts))
+        launch_ms = float(np.mean(full))
+    else:
+        eval_ms = float(np.sum([events[i][2].elapsed_time(events[i][3]) for i in ev_idx]) / sum(ev_runs[i] for i in ev_idx))
+        frames_per_launch = 1
+        launch_ms = eval_ms
 
-    if rank == 0 and os.environ.get("FD_BENCH_GAPS") and args.eval_stream == "shared":
+    if rank == 0 and os.environ.get("FD_BENCH_GAPS") and args.eval_stream == "shared" and not batched_eval:
         # idle time on the evaluation stream between consecutive evaluations (diagnostic)
         pairs = [(a, b) for a, b in zip(ev_idx[:-1], ev_idx[1:]) if a // B == b // B and a + ev_runs[a] == b]
         gaps = np.array([events[a][3].elapsed_time(events[b][2]) * 1e3 for a, b in pairs])
@@ -413,7 +440,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_frame", tj.get("hbm_bytes_per_launch")) * frames_per_launch
             except Exception:
                 traffic = None
         line = {
@@ -433,21 +461,27 @@ def main():
                 "workload": f"{desc}, thin-plate kernel, linear term, {args.precision} evaluation, "
                             "fp64 dense solve rebuilt every step (assemble + LU + evaluate), one frame per step",
                 "n_verts": n_verts, "n_ctrl": n_ctrl,
-                "frames_per_batched_build": B, "lanes_per_gpu": n_lanes,
+                "frames_per_batched_build": B, "frames_per_evaluation_launch": frames_per_launch,
+                "lanes_per_gpu": n_lanes,
                 "parallelism": f"independent frames: {world} GPU(s) x {n_lanes} lanes x {B} frames per batched "
-                               "build (one build stream per lane, one evaluation stream), no collective",
+                               "build and per evaluation launch (one build stream per lane, one evaluation "
+                               "stream), no collective",
             },
             "roofline": {
                 # the evaluation kernel is compute-bound at this M (intensity ~182 flop/B vs ridge ~20):
                 # its roof is the fp32 rate, 157.3 TFLOP/s for VALU and MFMA alike on gfx950
                 "bound": "mfma",
-                "kernel": "k_deform32_tps_mfma" if (precision == capi.EVAL_FP32 and n_ctrl >= 49) else
+                "kernel": ("k_deform32_tps_mfma_batch" if frames_per_launch > 1 else "k_deform32_tps_mfma")
+                          if (precision == capi.EVAL_FP32 and n_ctrl >= 49) else
                           ("k_deform32" if precision == capi.EVAL_FP32 else "k_deform64"),
                 "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                "flops_per_launch": flops, "avg_launch_ms": eval_ms,
+                # a launch evaluates frames_per_launch frames (algorithmic flops per frame x frames)
+                "flops_per_launch": flops * frames_per_launch, "avg_launch_ms": launch_ms,
+                "frames_per_launch": frames_per_launch,
                 "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": achieved_gbs / PEAK_HBM_GBS, "bytes_per_launch": BYTES_PER_VERTEX * n_verts},
+                        "frac": achieved_gbs / PEAK_HBM_GBS,
+                        "bytes_per_launch": BYTES_PER_VERTEX * n_verts * frames_per_launch},
             },
             "phases_ms": {"build_per_frame_batched": build_ms, "build_batch": build_group_ms,
                           "evaluate": eval_ms, "single_cook_latency": latency_ms},

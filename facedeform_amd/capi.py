@@ -60,7 +60,7 @@ EXPORTS = [
     "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
     "fd_morph_get_qr",
     "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error",
-    "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result",
+    "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result", "fd_batch_deform_dev",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
     "fdsop_get_float", "fdsop_get_int", "fdsop_parm_count", "fdsop_parm_token", "fdsop_cook",
     "fdsop_messages", "fdsop_effective_float", "fdsop_engine",
@@ -139,6 +139,9 @@ def load() -> C.CDLL:
     L.fd_batch_set_points_dev.restype = i32
     L.fd_batch_build_async.argtypes = [vp, vp]; L.fd_batch_build_async.restype = i32
     L.fd_batch_build_result.argtypes = [vp, C.POINTER(FdReport)]; L.fd_batch_build_result.restype = i32
+    pv = C.POINTER(vp)
+    L.fd_batch_deform_dev.argtypes = [vp, vp, i64, pv, pv, pv, pv, pv, pv, pv, C.c_float, C.c_float]
+    L.fd_batch_deform_dev.restype = i32
     L.fdsop_create.argtypes = [C.POINTER(FdConfig)]; L.fdsop_create.restype = vp
     L.fdsop_destroy.argtypes = [vp]; L.fdsop_destroy.restype = None
     L.fdsop_set_float.argtypes = [vp, C.c_char_p, i32, C.c_double]; L.fdsop_set_float.restype = i32
@@ -424,6 +427,25 @@ class Batch:
 
     def build_async(self, stream_ptr: int | None = None):
         self._check(self.L.fd_batch_build_async(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def deform_dev(self, N: int, d_P_in, d_P_out, d_dist2=None, d_falloff=None, d_tangents=None, radius2=1.0,
+                   falloffrate=1.0, stream_ptr: int | None = None):
+        """One launch for all contexts: lists of device pointers (ints), one per context."""
+        n = len(self.engines)
+
+        def tab(lst):
+            if lst is None:
+                return None
+            if len(lst) != n:
+                raise ValueError("one pointer per context")
+            return (C.c_void_p * n)(*[p or None for p in lst])
+
+        tu = tv = nr = None
+        if d_tangents is not None:
+            tu, tv, nr = (tab(t) for t in d_tangents)
+        self._check(self.L.fd_batch_deform_dev(self.h, C.c_void_p(stream_ptr or 0), N, tab(d_P_in), tab(d_P_out),
+                                               tab(d_dist2), tab(d_falloff), tu, tv, nr, float(radius2),
+                                               float(falloffrate)))
 
     def build_result(self, check: bool = True):
         n = len(self.engines)

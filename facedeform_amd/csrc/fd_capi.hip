@@ -1194,6 +1194,49 @@ int fd_batch_build_result(fd_batch *b, fd_report *reports)
     return first;
 }
 
+// One launch evaluates every context of the batch on its own vertex arrays (grid y = context)
+// when they all take the default thin-plate kernel on equally sized inputs; otherwise the
+// single launches are enqueued one after the other.  Results are those of fd_deform_dev_stream
+// per context, bit for bit.
+int fd_batch_deform_dev(fd_batch *b, void *hip_stream, int64_t N, const float *const *d_P_in, float *const *d_P_out,
+                        const float *const *d_dist2, float *const *d_falloff_out, const float *const *d_tu,
+                        const float *const *d_tv, const float *const *d_nrm, float radius2, float falloffrate)
+{
+    if (!b || !d_P_in || !d_P_out) return FD_E_INVALID;
+    if (N < 0) { batch_err(b, "fd_batch_deform_dev: N < 0"); return FD_E_INVALID; }
+    const int ntab = (d_tu != nullptr) + (d_tv != nullptr) + (d_nrm != nullptr);
+    if (ntab != 0 && ntab != 3) { batch_err(b, "fd_batch_deform_dev: tu, tv, nrm tables must be all set or all NULL"); return FD_E_INVALID; }
+    if (N == 0) return FD_OK;
+    fd_ctx *c0 = b->ctxs[0];
+    int rc = use_device(c0);
+    if (rc) { batch_err(b, "%s", c0->err); return rc; }
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(c0);
+    DeformArgs args[kMaxBatch];
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        if (!d_P_in[i] || !d_P_out[i]) { batch_err(b, "fd_batch_deform_dev: NULL vertex array for context %d", i); return FD_E_INVALID; }
+        if (!c->built && !c->build_pending) { batch_err(b, "fd_batch_deform_dev: context %d has no built model", i); return FD_E_NOT_BUILT; }
+        const float *tu = d_tu ? d_tu[i] : nullptr, *tv = d_tv ? d_tv[i] : nullptr, *nr = d_nrm ? d_nrm[i] : nullptr;
+        const int ntan = (tu != nullptr) + (tv != nullptr) + (nr != nullptr);
+        if (ntan != 0 && ntan != 3) { batch_err(b, "fd_batch_deform_dev: context %d: tu, tv, nrm must be all set or all NULL", i); return FD_E_INVALID; }
+        DeformArgs &a = args[i];
+        a.N = N;
+        a.P_in = d_P_in[i]; a.P_out = d_P_out[i];
+        a.dist2 = d_dist2 ? d_dist2[i] : nullptr; a.falloff_out = d_falloff_out ? d_falloff_out[i] : nullptr;
+        a.tu = tu; a.tv = tv; a.nrm = nr;
+        a.radius2 = radius2; a.falloffrate = falloffrate;
+        a.M = c->M; a.Mpad = round_up(c->M, kRecPad); a.kind = c->kind;
+        a.rec32 = c->d_rec32; a.rec64 = c->d_rec64; a.tiles = c->d_tiles; a.tiles16 = c->d_tiles16;
+        a.model = c->d_model;
+        a.precision = c->eval_precision;
+        a.variant = c->eval_variant;
+        if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
+    }
+    hipError_t e = launch_deform_batch(args, b->n, stream);
+    if (e != hipSuccess) { batch_err(b, "launch_deform_batch failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    return FD_OK;
+}
+
 int fd_batch_size(const fd_batch *b) { return b ? b->n : 0; }
 
 }  // extern "C"

@@ -150,6 +150,7 @@ struct DeformArgs {
     int precision, variant;
 };
 hipError_t launch_deform(const DeformArgs &a, hipStream_t stream);
+hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream);
 // dist2 producer (fd_capture.hip): all pointers are device pointers, d_mask may be null
 hipError_t launch_capture_dist2(const float *d_P, int64_t N, const unsigned char *d_mask, const float *d_tri, int T,
                                 float radius2, int dofalloff, float *d_dist2, hipStream_t stream);

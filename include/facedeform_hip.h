@@ -233,6 +233,17 @@ int fd_batch_build_async(fd_batch *batch, void *hip_stream);
 /* Wait and report per context (reports may be NULL, else n entries).  Returns
  * the first non-zero per-context code. */
 int fd_batch_build_result(fd_batch *batch, fd_report *reports);
+/* Evaluate every context of the batch on its own vertex arrays with ONE launch
+ * (tables of n device pointers, host arrays; the optional tables may be NULL,
+ * and so may their entries except P).  A launch over 1M vertices spends ~12 %
+ * of its time ramping up and draining; a launch over all frames of a group
+ * does not.  Falls back to one launch per context when they do not all take
+ * the default thin-plate kernel on equally sized inputs.  Per context the
+ * result is exactly that of fd_deform_dev_stream. */
+int fd_batch_deform_dev(fd_batch *batch, void *hip_stream, int64_t N, const float *const *d_P_in,
+                        float *const *d_P_out, const float *const *d_dist2, float *const *d_falloff_out,
+                        const float *const *d_tu, const float *const *d_tv, const float *const *d_nrm,
+                        float radius2, float falloffrate);
 
 /* ---- dist2 producer (next row N2) ---------------------------------------------
  * The per-point body of ProximityCapture::capture (src/capture.cpp:58-97) on the

@@ -139,3 +139,58 @@ def test_batch_reports_singular_member(hip_lib):
     b.close()
     for e in es:
         e.close()
+
+
+def test_batched_evaluation_is_bit_identical_to_single_launches(hip_lib):
+    """fd_batch_deform_dev: one launch for all contexts (grid y = context).  Same kernel body as a
+    single launch, so every context's result must match fd_deform_dev bit for bit -- with and
+    without gate / fall-off / tangent frames, ragged N, and through the fallback (mixed kernels)."""
+    M, nb, N = 200, 5, 70_003
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    tu, tv, nn = synth.tangent_frames(P)
+    d_P = torch.from_numpy(P).to(dev)
+    d_d2 = torch.from_numpy((rng.random(N) * 0.6).astype(np.float32)).to(dev)
+    d_tan = [torch.from_numpy(a).to(dev) for a in (tu, tv, nn)]
+    engines = []
+    for f in range(nb):
+        e = capi.Engine()
+        e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+        e.set_points(rest, synth.smooth_deltas(rest, f).astype(np.float32))
+        engines.append(e)
+    b = capi.Batch(engines)
+    b.build_async(); b.build_result()
+    stream = torch.cuda.Stream(device=dev)
+    for use_d2, use_tan in ((False, False), (True, False), (True, True)):
+        outs = [torch.empty_like(d_P) for _ in range(nb)]
+        falls = [torch.full((N,), 2.0, device=dev) for _ in range(nb)]
+        refs = [torch.empty_like(d_P) for _ in range(nb)]
+        ref_falls = [torch.full((N,), 2.0, device=dev) for _ in range(nb)]
+        torch.cuda.synchronize()
+        b.deform_dev(N, [d_P.data_ptr()] * nb, [o.data_ptr() for o in outs],
+                     [d_d2.data_ptr()] * nb if use_d2 else None, [f.data_ptr() for f in falls],
+                     [[t.data_ptr()] * nb for t in d_tan] if use_tan else None, radius2=0.3, falloffrate=1.5,
+                     stream_ptr=stream.cuda_stream)
+        stream.synchronize()
+        for e, r, rf in zip(engines, refs, ref_falls):
+            e.deform_dev(N, d_P.data_ptr(), r.data_ptr(), d_dist2=d_d2.data_ptr() if use_d2 else 0, d_falloff=rf.data_ptr(),
+                         d_tu=d_tan[0].data_ptr() if use_tan else 0, d_tv=d_tan[1].data_ptr() if use_tan else 0,
+                         d_nrm=d_tan[2].data_ptr() if use_tan else 0, radius2=0.3, falloffrate=1.5)
+            e.synchronize()
+        for k in range(nb):
+            assert torch.equal(outs[k], refs[k]) and torch.equal(falls[k], ref_falls[k]), (use_d2, use_tan, k)
+        assert not torch.equal(outs[0], outs[1])            # different models did give different results
+    # fallback: one context on another kernel -> single launches, same results
+    engines[2].set_kernel(capi.KERNEL_BIHARMONIC); engines[2].build()
+    outs = [torch.empty_like(d_P) for _ in range(nb)]
+    b.deform_dev(N, [d_P.data_ptr()] * nb, [o.data_ptr() for o in outs], stream_ptr=stream.cuda_stream)
+    stream.synchronize()
+    ref = torch.empty_like(d_P)
+    for k in (1, 2):
+        engines[k].deform_dev(N, d_P.data_ptr(), ref.data_ptr()); engines[k].synchronize()
+        assert torch.equal(outs[k], ref)
+    b.close()
+    for e in engines:
+        e.close()

@@ -1,6 +1,6 @@
 """Turn gpurun_out/profiles_r01/ (tools/collect_profiles.sh) into the files committed under
 profiles/: kernel-stats CSVs, the bench JSON line, the PMC summary and traffic_c2.json."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "profiles_r01")
@@ -13,7 +13,8 @@ def counters(sub, match):
     for f in glob.glob(os.path.join(SRC, sub, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"]:
-                agg[r["Kernel_Name"].split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                m = re.search(r"(k_[a-z0-9_]+)", r["Kernel_Name"])
+                agg[m.group(1) if m else r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
 
@@ -34,14 +35,16 @@ def main():
                 open(os.path.join(DST, f"{TAG}_{name}_line.json"), "w").write(lines[-1])
 
     out = []
-    kern = "k_deform32"
+    kern = "k_deform32_tps_mfma_batch"
+    frames = 32                       # tools/collect_profiles.sh evaluates 32 frames per launch
     fetch = counters("pmc_fetch", kern)
     write = counters("pmc_write", kern)
     sq = counters("pmc_sq", kern)
     mf = counters("pmc_mfma", kern)
     kname = next(iter(fetch), next(iter(sq), "?"))
     out.append(f"rocprofv3 --pmc <counters> --kernel-trace (one counter group per run), evaluation kernel {kname} at C2 "
-               f"(N=1e6, M=256), isolated launches (tests/tools/eval_variants.py)")
+               f"(N=1e6, M=256), {frames} frames per launch as in bench.py (tests/tools/batch_eval_timing.py 32 batched); "
+               f"counter values are per launch")
     traffic = {}
     if fetch and write:
         fk = mean(next(iter(fetch.values()))["FETCH_SIZE"])
@@ -49,14 +52,16 @@ def main():
         hbm = fk * 1024 * 2.0 + wk * 1024
         out.append(f"FETCH_SIZE {fk:.1f} KiB raw; x2 (gfx950 correction, MI355X_MICROARCH.md) = {fk * 2048 / 1e6:.2f} MB")
         out.append(f"WRITE_SIZE {wk:.1f} KiB = {wk * 1024 / 1e6:.2f} MB")
-        out.append(f"HBM bytes per launch {hbm / 1e6:.2f} MB vs algorithmic 28.0 MB (P in 12, P out 12, fd_falloff 4) + model tiles")
+        out.append(f"HBM bytes per launch {hbm / 1e6:.2f} MB = {hbm / frames / 1e6:.2f} MB per frame vs algorithmic 28.0 MB per frame "
+                   f"(P in 12 + P out 12 + fd_falloff 4): every frame reads its input once and writes its outputs once")
         traffic = {
-            "kernel": kname, "config": "C2: N=1e6, M=256, dist2=NULL, falloff written",
+            "kernel": kname, "config": "C2: N=1e6, M=256, dist2=NULL, fd_falloff written, 32 frames per launch (same input mesh, own outputs)",
             "FETCH_SIZE_KiB_raw": fk, "fetch_correction": 2.0,
             "fetch_correction_note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a coalesced "
                                      "streaming read; x2 gives P (12.0 MB) + model, which calibrates the factor",
-            "WRITE_SIZE_KiB": wk, "hbm_bytes_per_launch": hbm,
-            "algorithmic_bytes_per_launch": {"P_in": 12e6, "P_out": 12e6, "fd_falloff": 4e6, "model_tiles": 17 * 1280},
+            "WRITE_SIZE_KiB": wk, "hbm_bytes_per_launch": hbm, "frames_per_launch": frames,
+            "hbm_bytes_per_frame": hbm / frames,
+            "algorithmic_bytes_per_frame": {"P_in": 12e6, "P_out": 12e6, "fd_falloff": 4e6, "model_tiles": 17 * 768},
         }
         json.dump(traffic, open(os.path.join(DST, "traffic_c2.json"), "w"), indent=1)
     for agg in (sq, mf):
