@@ -56,6 +56,12 @@ struct EvalParams {
     const DevModel *model;
 };
 
+// per-frame parameters of a batched launch (blockIdx.y picks the frame); travels as a kernel argument
+struct EvalBatch {
+    EvalParams p[kMaxBatch];
+};
+static_assert(sizeof(EvalBatch) <= 4000, "the table must fit the kernel argument segment");
+
 // ---- kernels phi'(d2) (constant factors live in the packed weights) ----------
 template <int KIND>
 __device__ __forceinline__ float phi32(float d2, float s)
@@ -222,7 +228,7 @@ __device__ __forceinline__ f32x2 phi32(f32x2 d2, float s)
 
 // V vertices per lane in Q = V / W registers; vertex v sits in register v / W, component v % W
 template <int KIND, int V, bool USE_LDS, typename LaneT>
-__global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
+__device__ __forceinline__ void deform32_body(const EvalParams &p)
 {
     using L = Lanes<LaneT>;
     constexpr int W = L::W;
@@ -386,6 +392,19 @@ __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
         float disp[3] = {(float)accx[v], (float)accy[v], (float)accz[v]};
         epilogue_store(p, i, pos, disp, d2v[v]);
     }
+}
+
+template <int KIND, int V, bool USE_LDS, typename LaneT>
+__global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
+{
+    deform32_body<KIND, V, USE_LDS, LaneT>(p);
+}
+
+// several frames in one launch (the default variant only: packed lanes, scalar-loaded records, V = 4)
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_deform32_batch(const EvalBatch args)
+{
+    deform32_body<KIND, 4, false, f32x2>(args.p[blockIdx.y]);
 }
 
 // ---- thin-plate evaluation with d2 on the bf16 matrix pipe --------------------------------
@@ -625,11 +644,6 @@ void k_deform32_tps_mfma(const EvalParams p, int ngroups)
 // vertex arrays (the table travels as a kernel argument).  A 1M-vertex launch spends ~12 % of
 // its time ramping up and draining; launches that are 8-32x larger do not (measured: 56 us per
 // frame alone, 50 us per frame when evaluations overlap).
-struct EvalBatch {
-    EvalParams p[kMaxBatch];
-};
-static_assert(sizeof(EvalBatch) <= 4000, "the table must fit the kernel argument segment");
-
 template <int TV, bool HALF>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_deform32_tps_mfma_batch(const EvalBatch args, int ngroups)
@@ -827,12 +841,16 @@ static EvalParams make_params(const DeformArgs &a)
 hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    bool one = n > 1 && n <= kMaxBatch;
-    for (int i = 0; i < n && one; ++i)
-        one = a[i].kind == FD_KERNEL_THIN_PLATE && a[i].precision == FD_EVAL_FP32 && a[i].variant <= 0 &&
-              a[i].tiles16 != nullptr && a[i].Mpad >= 64 && a[i].Mpad == a[0].Mpad && a[i].N == a[0].N && a[i].N > 0;
+    // same default fp32 kernel for all, equally sized inputs?
+    bool same = n > 1 && n <= kMaxBatch;
+    for (int i = 0; i < n && same; ++i)
+        same = a[i].precision == FD_EVAL_FP32 && a[i].variant <= 0 && a[i].N == a[0].N && a[i].N > 0 &&
+               a[i].Mpad == a[0].Mpad && a[i].kind == a[0].kind;
     static const bool bf16_tiles = getenv("FD_MFMA_BF16") != nullptr;
-    if (!one || bf16_tiles) {
+    bool mfma = same && a[0].kind == FD_KERNEL_THIN_PLATE && a[0].Mpad >= 64 && !bf16_tiles;
+    for (int i = 0; i < n && mfma; ++i) mfma = a[i].tiles16 != nullptr;
+    const bool valu = same && !mfma && !(a[0].kind == FD_KERNEL_THIN_PLATE && a[0].Mpad >= 64);
+    if (!mfma && !valu) {
         for (int i = 0; i < n; ++i) {
             const hipError_t e = launch_deform(a[i], stream);
             if (e != hipSuccess) return e;
@@ -842,6 +860,23 @@ hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream)
     EvalBatch args;
     for (int i = 0; i < n; ++i) args.p[i] = make_params(a[i]);
     for (int i = n; i < kMaxBatch; ++i) args.p[i] = args.p[0];
+    if (valu) {
+        const int64_t per = (int64_t)kBlock * 4;
+        const dim3 grid((unsigned)((a[0].N + per - 1) / per), (unsigned)n);
+        switch (a[0].kind) {
+        case FD_KERNEL_GAUSSIAN:
+        case FD_KERNEL_GAUSSIAN_QNN:
+            hipLaunchKernelGGL((k_deform32_batch<FD_KERNEL_GAUSSIAN>), grid, dim3(kBlock), 0, stream, args); break;
+        case FD_KERNEL_THIN_PLATE:
+            hipLaunchKernelGGL((k_deform32_batch<FD_KERNEL_THIN_PLATE>), grid, dim3(kBlock), 0, stream, args); break;
+        case FD_KERNEL_BIHARMONIC:
+            hipLaunchKernelGGL((k_deform32_batch<FD_KERNEL_BIHARMONIC>), grid, dim3(kBlock), 0, stream, args); break;
+        case FD_KERNEL_CUBIC:
+            hipLaunchKernelGGL((k_deform32_batch<FD_KERNEL_CUBIC>), grid, dim3(kBlock), 0, stream, args); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     constexpr int TV = 4;
     const int64_t per = (int64_t)kBlock / 64 * 16 * TV;
     const int64_t ngroups = (a[0].N + per - 1) / per;

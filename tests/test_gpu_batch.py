@@ -141,11 +141,17 @@ def test_batch_reports_singular_member(hip_lib):
         e.close()
 
 
-def test_batched_evaluation_is_bit_identical_to_single_launches(hip_lib):
+@pytest.mark.parametrize("kind,params,M", [
+    (capi.KERNEL_THIN_PLATE, [], 200),              # matrix-pipe kernel, batched
+    (capi.KERNEL_GAUSSIAN_QNN, [1.0, 5.0], 200),    # packed-VALU kernel, batched (the SOP's default model)
+    (capi.KERNEL_THIN_PLATE, [], 40),               # thin-plate below the matrix-pipe threshold
+    (capi.KERNEL_CUBIC, [], 96),
+])
+def test_batched_evaluation_is_bit_identical_to_single_launches(hip_lib, kind, params, M):
     """fd_batch_deform_dev: one launch for all contexts (grid y = context).  Same kernel body as a
     single launch, so every context's result must match fd_deform_dev bit for bit -- with and
     without gate / fall-off / tangent frames, ragged N, and through the fallback (mixed kernels)."""
-    M, nb, N = 200, 5, 70_003
+    nb, N = 5, 70_003
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(21)
     P = synth.head_mesh(N)
@@ -157,7 +163,7 @@ def test_batched_evaluation_is_bit_identical_to_single_launches(hip_lib):
     engines = []
     for f in range(nb):
         e = capi.Engine()
-        e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+        e.set_kernel(kind, params); e.set_term(0)
         e.set_points(rest, synth.smooth_deltas(rest, f).astype(np.float32))
         engines.append(e)
     b = capi.Batch(engines)
@@ -183,7 +189,7 @@ def test_batched_evaluation_is_bit_identical_to_single_launches(hip_lib):
             assert torch.equal(outs[k], refs[k]) and torch.equal(falls[k], ref_falls[k]), (use_d2, use_tan, k)
         assert not torch.equal(outs[0], outs[1])            # different models did give different results
     # fallback: one context on another kernel -> single launches, same results
-    engines[2].set_kernel(capi.KERNEL_BIHARMONIC); engines[2].build()
+    engines[2].set_kernel(capi.KERNEL_BIHARMONIC if kind != capi.KERNEL_BIHARMONIC else capi.KERNEL_CUBIC); engines[2].build()
     outs = [torch.empty_like(d_P) for _ in range(nb)]
     b.deform_dev(N, [d_P.data_ptr()] * nb, [o.data_ptr() for o in outs], stream_ptr=stream.cuda_stream)
     stream.synchronize()

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from facedeform_amd import capi, synth
 N, M = 1_000_000, 256
+KIND, KPARAMS = {"thin_plate": (capi.KERNEL_THIN_PLATE, []), "qnn": (capi.KERNEL_GAUSSIAN_QNN, [1.0, 5.0])}[os.environ.get("FD_EVAL_KERNEL", "thin_plate")]
 dev = torch.device("cuda", 0)
 P = synth.head_mesh(N); rest = synth.control_points(M, "head")
 d_P = torch.from_numpy(P).to(dev)
@@ -13,7 +14,7 @@ modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["single", "batched"]
 for B in Bs:
     es = []
     for f in range(B):
-        e = capi.Engine(); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+        e = capi.Engine(); e.set_kernel(KIND, KPARAMS); e.set_term(0)
         e.set_points(rest, synth.smooth_deltas(rest, f % 8).astype(np.float32)); e.set_stream(stream.cuda_stream); es.append(e)
     b = capi.Batch(es); b.build_async(stream.cuda_stream); b.build_result()
     outs = [torch.empty_like(d_P) for _ in range(B)]
