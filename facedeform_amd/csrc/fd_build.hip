@@ -453,9 +453,37 @@ __global__ __launch_bounds__(TMAX) void k_lu_panel(const BatchSlot *tab, int lda
     FD_STAMP_FLUSH
 }
 
+// Row interchanges of elimination step `step` applied to the 16 columns starting at c0 and
+// nothing else: brings the L columns of the first panel of a pair into the row order the
+// second panel chose (LAPACK's laswp on the left columns).
+__global__ __launch_bounds__(256) void k_lu_apply_moves(const BatchSlot *tab, int lda, int step, int c0)
+{
+    double *A = tab[blockIdx.z].A;
+    const int *moves = tab[blockIdx.z].moves + (size_t)step * kMovesStride;
+    __shared__ int s_moves[kMovesStride];
+    const int tid = threadIdx.x;
+    if (tid < kMovesStride) s_moves[tid] = moves[tid];
+    __syncthreads();
+    const int nmov = s_moves[0];
+    double tmp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * 256;
+        tmp[q] = 0.0;
+        if (e < nmov * kColBlock) tmp[q] = A[(size_t)(c0 + (e & 15)) * lda + s_moves[2 + 2 * (e >> 4)]];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * 256;
+        if (e < nmov * kColBlock) A[(size_t)(c0 + (e & 15)) * lda + s_moves[1 + 2 * (e >> 4)]] = tmp[q];
+    }
+}
+
 // ---- LU trailing update ---------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda, int npad, int k0, int step, int cb0)
+__global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda, int npad, int k0, int step, int cb0,
+                                                  int nlists)
 {
     double *A = tab[blockIdx.z].A;
     const int *moves = tab[blockIdx.z].moves + (size_t)step * kMovesStride;
@@ -472,23 +500,27 @@ __global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda,
 
     // 1. row interchanges of this panel, restricted to my 16 columns: the move list comes
     //    in with one coalesced load; every moved row is read before any is written
-    //    (sources and destinations overlap)
+    //    (sources and destinations overlap).  A 32-wide update over a PAIR of 16-wide panels
+    //    (nlists = 2) applies the first panel's list, then the second's.
     __shared__ int s_moves[2 * 2 * NB + 1];
-    if (tid < 2 * 2 * NB + 1) s_moves[tid] = moves[tid];
-    __syncthreads();
-    const int nmov = s_moves[0];
-    double tmp[4];
+    for (int l = 0; l < nlists; ++l) {
+        __syncthreads();
+        if (tid < 2 * 2 * NB + 1) s_moves[tid] = moves[(size_t)l * kMovesStride + tid];
+        __syncthreads();
+        const int nmov = s_moves[0];
+        double tmp[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + q * 256;
-        tmp[q] = 0.0;
-        if (e < nmov * kColBlock) tmp[q] = A[(size_t)(c0 + (e & 15)) * lda + s_moves[2 + 2 * (e >> 4)]];
-    }
-    __syncthreads();
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            tmp[q] = 0.0;
+            if (e < nmov * kColBlock) tmp[q] = A[(size_t)(c0 + (e & 15)) * lda + s_moves[2 + 2 * (e >> 4)]];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + q * 256;
-        if (e < nmov * kColBlock) A[(size_t)(c0 + (e & 15)) * lda + s_moves[1 + 2 * (e >> 4)]] = tmp[q];
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            if (e < nmov * kColBlock) A[(size_t)(c0 + (e & 15)) * lda + s_moves[1 + 2 * (e >> 4)]] = tmp[q];
+        }
     }
     for (int e = tid; e < NB * NB; e += 256) {
         const int r = e % NB, cc = e / NB;
@@ -954,7 +986,7 @@ void lu_step(const BuildBuffers &b, int k0, int step, LuStreams &st)
     if (ncb <= 0) return;
     if (!st.aux) {
         hipLaunchKernelGGL((k_lu_trail<NB>), dim3(ncb, 1, nb), dim3(256), 0, st.main, b.d_slots, b.lda, b.npad, k0,
-                           step, 0);
+                           step, 0, 1);
         return;
     }
     const int next_k0 = k0 + NB;
@@ -968,15 +1000,51 @@ void lu_step(const BuildBuffers &b, int k0, int step, LuStreams &st)
     if (na > 0) {
         if (st.rest_pending) { (void)hipStreamWaitEvent(st.main, st.ev_rest[st.last_rest], 0); st.rest_pending = false; }
         hipLaunchKernelGGL((k_lu_trail<NB>), dim3(na, 1, nb), dim3(256), 0, st.main, b.d_slots, b.lda, b.npad, k0,
-                           step, 0);
+                           step, 0, 1);
     }
     if (ncb > na) {
         hipLaunchKernelGGL((k_lu_trail<NB>), dim3(ncb - na, 1, nb), dim3(256), 0, st.aux, b.d_slots, b.lda, b.npad, k0,
-                           step, na);
+                           step, na, 1);
         (void)hipEventRecord(st.ev_rest[par], st.aux);
         st.rest_pending = true;
         st.last_rest = par;
     }
+}
+
+// Two consecutive 16-wide panels can share ONE 32-deep trailing update: halves the passes over
+// the trailing matrix where the panel has to be 16 wide (1024 < rows <= 2048; the trailing
+// updates there are bound by HBM traffic -- 37 MB read + written per step at order 2080).
+bool pair_at(int npad, int k0)
+{
+    // (the opt-in two-stream look-ahead splits single steps and does not pair)
+    static const bool off = getenv("FD_NO_PANEL_PAIRS") != nullptr || getenv("FD_LOOKAHEAD") != nullptr;
+    return !off && panel_width(npad, k0) == 16 && k0 + 16 < npad && panel_width(npad, k0 + 16) == 16;
+}
+
+// panel(k0) -> one-block update of the next 16 columns -> panel(k0 + 16) -> the second panel's
+// row interchanges on the first panel's L columns -> 32-deep update of everything to the right
+void lu_pair_step(const BuildBuffers &b, int k0, int step, hipStream_t stream)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    for (int half = 0; half < 2; ++half) {
+        const int kk = k0 + 16 * half;
+        const int nrem = b.npad - kk;
+        int threads = round_up((nrem + 1) / 2, 64);          // 2 rows per lane at NB = 16
+        if (threads < 64) threads = 64;
+        if (threads <= 512)
+            hipLaunchKernelGGL((k_lu_panel<16, 512>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad,
+                               b.n, kk, step + half);
+        else
+            hipLaunchKernelGGL((k_lu_panel<16, 1024>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad,
+                               b.n, kk, step + half);
+        if (half == 0)
+            hipLaunchKernelGGL((k_lu_trail<16>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, 0, 1);
+        else
+            hipLaunchKernelGGL(k_lu_apply_moves, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, step + 1, k0);
+    }
+    const int ncb = (b.ncols - (k0 + 32) + kColBlock - 1) / kColBlock;
+    if (ncb > 0)
+        hipLaunchKernelGGL((k_lu_trail<32>), dim3(ncb, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, 0, 2);
 }
 
 }  // namespace
@@ -1046,6 +1114,12 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
     for (int q = 0; q < 2; ++q) { st.ev_panel[q] = b.aux_events[q]; st.ev_rest[q] = b.aux_events[2 + q]; }
     int k0 = 0, step = 0;
     while (k0 < b.npad) {
+        if (!st.aux && pair_at(b.npad, k0)) {
+            lu_pair_step(b, k0, step, stream);
+            k0 += 32;
+            step += 2;
+            continue;
+        }
         const int w = panel_width(b.npad, k0);
         if (w == 32) lu_step<32>(b, k0, step, st);
         else if (w == 16) lu_step<16>(b, k0, step, st);
@@ -1100,12 +1174,19 @@ hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const Point
     }
     int k0 = 0, step = 0;
     while (k0 < b.npad) {
+        if (pair_at(b.npad, k0)) {   // as in launch_build: one 32-deep update for the pair of panels
+            const int cb = (b.npad - (k0 + 32)) / kColBlock;
+            hipLaunchKernelGGL((k_lu_trail<32>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb, 2);
+            k0 += 32;
+            step += 2;
+            continue;
+        }
         const int w = panel_width(b.npad, k0);
         const int cb = (b.npad - (k0 + w)) / kColBlock;      // the RHS block among this step's column blocks
         if (w == 32)
-            hipLaunchKernelGGL((k_lu_trail<32>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb);
+            hipLaunchKernelGGL((k_lu_trail<32>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb, 1);
         else
-            hipLaunchKernelGGL((k_lu_trail<16>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb);
+            hipLaunchKernelGGL((k_lu_trail<16>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb, 1);
         k0 += w;
         ++step;
     }
