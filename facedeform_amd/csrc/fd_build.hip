@@ -456,8 +456,9 @@ __global__ __launch_bounds__(TMAX) void k_lu_panel(const BatchSlot *tab, int lda
 // Row interchanges of elimination step `step` applied to the 16 columns starting at c0 and
 // nothing else: brings the L columns of the first panel of a pair into the row order the
 // second panel chose (LAPACK's laswp on the left columns).
-__global__ __launch_bounds__(256) void k_lu_apply_moves(const BatchSlot *tab, int lda, int step, int c0)
+__global__ __launch_bounds__(256) void k_lu_apply_moves(const BatchSlot *tab, int lda, int step, int c0_first)
 {
+    const int c0 = c0_first + (int)blockIdx.x * kColBlock;
     double *A = tab[blockIdx.z].A;
     const int *moves = tab[blockIdx.z].moves + (size_t)step * kMovesStride;
     __shared__ int s_moves[kMovesStride];
@@ -1011,40 +1012,62 @@ void lu_step(const BuildBuffers &b, int k0, int step, LuStreams &st)
     }
 }
 
-// Two consecutive 16-wide panels can share ONE 32-deep trailing update: halves the passes over
-// the trailing matrix where the panel has to be 16 wide (1024 < rows <= 2048; the trailing
-// updates there are bound by HBM traffic -- 37 MB read + written per step at order 2080).
-bool pair_at(int npad, int k0)
+// Consecutive panels can share ONE deep trailing update: np panels of width w, then a single
+// update of depth np * w over everything to their right.  That divides the passes over the
+// trailing matrix by np where they are bound by HBM traffic (37 MB read + written per step at
+// order 2080).  Inside the group every panel is followed by a narrow update of the group's own
+// remaining columns, and its row interchanges are applied to the L columns of the panels before
+// it (LAPACK's laswp on the left), so that the group ends up as one proper np*w-wide LU panel.
+// Returns the number of panels to group at k0 (1 = ordinary step).
+int group_at(int npad, int k0, bool enabled)
 {
-    // (the opt-in two-stream look-ahead splits single steps and does not pair)
-    static const bool off = getenv("FD_NO_PANEL_PAIRS") != nullptr || getenv("FD_LOOKAHEAD") != nullptr;
-    return !off && panel_width(npad, k0) == 16 && k0 + 16 < npad && panel_width(npad, k0 + 16) == 16;
+    if (!enabled) return 1;
+    const int w = panel_width(npad, k0);
+    const int nrem = npad - k0;
+    int want = 1;
+    if (w == 16) want = 4;                       // 1024 < rows <= 2048: depth 64
+    else if (w == 32 && nrem > 512) want = 2;    // large 32-wide panels: depth 64; small systems stay launch-lean
+    int np = 1;
+    while (np < want && k0 + np * w < npad && panel_width(npad, k0 + np * w) == w) ++np;
+    if (np == 3) np = 2;                         // depths 32 and 64 are instantiated
+    return np;
 }
 
-// panel(k0) -> one-block update of the next 16 columns -> panel(k0 + 16) -> the second panel's
-// row interchanges on the first panel's L columns -> 32-deep update of everything to the right
-void lu_pair_step(const BuildBuffers &b, int k0, int step, hipStream_t stream)
+template <int W>
+void launch_panel(const BuildBuffers &b, int kk, int step, hipStream_t stream)
+{
+    constexpr int R = 32 / W;
+    const unsigned nb = (unsigned)b.nbatch;
+    const int nrem = b.npad - kk;
+    int threads = round_up((nrem + R - 1) / R, 64);
+    if (threads < 64) threads = 64;
+    if (threads <= 512)
+        hipLaunchKernelGGL((k_lu_panel<W, 512>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad, b.n, kk, step);
+    else
+        hipLaunchKernelGGL((k_lu_panel<W, 1024>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad, b.n, kk, step);
+}
+
+template <int W>
+void lu_group_step(const BuildBuffers &b, int k0, int step, int np, hipStream_t stream)
 {
     const unsigned nb = (unsigned)b.nbatch;
-    for (int half = 0; half < 2; ++half) {
-        const int kk = k0 + 16 * half;
-        const int nrem = b.npad - kk;
-        int threads = round_up((nrem + 1) / 2, 64);          // 2 rows per lane at NB = 16
-        if (threads < 64) threads = 64;
-        if (threads <= 512)
-            hipLaunchKernelGGL((k_lu_panel<16, 512>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad,
-                               b.n, kk, step + half);
-        else
-            hipLaunchKernelGGL((k_lu_panel<16, 1024>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad,
-                               b.n, kk, step + half);
-        if (half == 0)
-            hipLaunchKernelGGL((k_lu_trail<16>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, 0, 1);
-        else
-            hipLaunchKernelGGL(k_lu_apply_moves, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, step + 1, k0);
+    constexpr int WB = W / kColBlock;                 // 16-column blocks per panel
+    for (int i = 0; i < np; ++i) {
+        const int kk = k0 + W * i;
+        launch_panel<W>(b, kk, step + i, stream);
+        if (i > 0)                                    // my interchanges on the L columns of panels 0 .. i-1
+            hipLaunchKernelGGL(k_lu_apply_moves, dim3(i * WB, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, step + i, k0);
+        if (i + 1 < np)                               // my update of the group's remaining columns
+            hipLaunchKernelGGL((k_lu_trail<W>), dim3((np - 1 - i) * WB, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad,
+                               kk, step + i, 0, 1);
     }
-    const int ncb = (b.ncols - (k0 + 32) + kColBlock - 1) / kColBlock;
-    if (ncb > 0)
-        hipLaunchKernelGGL((k_lu_trail<32>), dim3(ncb, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, 0, 2);
+    const int depth = W * np;
+    const int ncb = (b.ncols - (k0 + depth) + kColBlock - 1) / kColBlock;
+    if (ncb <= 0) return;
+    if (depth == 32)
+        hipLaunchKernelGGL((k_lu_trail<32>), dim3(ncb, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, 0, np);
+    else
+        hipLaunchKernelGGL((k_lu_trail<64>), dim3(ncb, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, 0, np);
 }
 
 }  // namespace
@@ -1114,10 +1137,13 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
     for (int q = 0; q < 2; ++q) { st.ev_panel[q] = b.aux_events[q]; st.ev_rest[q] = b.aux_events[2 + q]; }
     int k0 = 0, step = 0;
     while (k0 < b.npad) {
-        if (!st.aux && pair_at(b.npad, k0)) {
-            lu_pair_step(b, k0, step, stream);
-            k0 += 32;
-            step += 2;
+        const int np = st.aux ? 1 : group_at(b.npad, k0, b.group_panels != 0);
+        if (np > 1) {
+            const int wg = panel_width(b.npad, k0);
+            if (wg == 16) lu_group_step<16>(b, k0, step, np, stream);
+            else lu_group_step<32>(b, k0, step, np, stream);
+            k0 += wg * np;
+            step += np;
             continue;
         }
         const int w = panel_width(b.npad, k0);
@@ -1174,11 +1200,16 @@ hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const Point
     }
     int k0 = 0, step = 0;
     while (k0 < b.npad) {
-        if (pair_at(b.npad, k0)) {   // as in launch_build: one 32-deep update for the pair of panels
-            const int cb = (b.npad - (k0 + 32)) / kColBlock;
-            hipLaunchKernelGGL((k_lu_trail<32>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb, 2);
-            k0 += 32;
-            step += 2;
+        const int np = group_at(b.npad, k0, b.group_panels != 0);
+        if (np > 1) {   // as in launch_build: one deep update for the group of panels
+            const int depth = panel_width(b.npad, k0) * np;
+            const int cb = (b.npad - (k0 + depth)) / kColBlock;
+            if (depth == 32)
+                hipLaunchKernelGGL((k_lu_trail<32>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb, np);
+            else
+                hipLaunchKernelGGL((k_lu_trail<64>), dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.lda, b.npad, k0, step, cb, np);
+            k0 += depth;
+            step += np;
             continue;
         }
         const int w = panel_width(b.npad, k0);

@@ -29,6 +29,7 @@ struct fd_ctx {
     // fd_set_deltas: a full build with the current rest points / kernel / term has been enqueued
     // (its factorisation sits in d_A), and the next build only has new right-hand sides
     bool have_factor = false;
+    bool factor_grouped = false;   // the factorisation in d_A was built with grouped panels (a batched build)
     bool deltas_only = false;
     hipGraphExec_t resolve_exec = nullptr;
 
@@ -482,6 +483,7 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.Mpad = round_up(ctx->M, kRecPad);
     b.d_slots = ctx->d_slot;
     b.nbatch = 1;
+    b.group_panels = 0;
     b.aux_stream = nullptr;
     for (hipEvent_t &e : b.aux_events) e = nullptr;
 }
@@ -500,9 +502,10 @@ int fd_build_async(fd_ctx *ctx)
     fill_build_buffers(ctx, b);
     if (ctx->deltas_only && ctx->have_factor) {
         // fd_set_deltas: right-hand sides only, through the factorisation of the last full build
+        b.group_panels = ctx->factor_grouped ? 1 : 0;
         hipStream_t st = cur_stream(ctx);
         fd_ctx::GraphKey rkey{};
-        rkey.M = ctx->M; rkey.kind = ctx->kind; rkey.term = ctx->term; rkey.nparams = ctx->nparams;
+        rkey.M = ctx->M; rkey.kind = ctx->kind; rkey.term = ctx->term | (b.group_panels << 8); rkey.nparams = ctx->nparams;
         memcpy(rkey.params, ctx->params, sizeof(rkey.params));
         rkey.A = ctx->d_A; rkey.rest = ctx->d_rest; rkey.rec32 = ctx->d_rec32;
         if (ctx->use_graph && (!ctx->resolve_exec || memcmp(&rkey, &ctx->resolve_key, sizeof(rkey)) != 0)) {
@@ -576,6 +579,7 @@ int fd_build_async(fd_ctx *ctx)
     ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
     ctx->have_factor = true;
+    ctx->factor_grouped = false;
     ctx->deltas_only = false;
     ctx->build_pending = true;
     ctx->built = false;
@@ -1129,6 +1133,8 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     fill_build_buffers(c0, bb);
     bb.d_slots = b->d_slots;
     bb.nbatch = b->n;
+    static const bool no_groups = getenv("FD_NO_PANEL_PAIRS") != nullptr;
+    bb.group_panels = (b->n >= 4 && !no_groups && !getenv("FD_LOOKAHEAD")) ? 1 : 0;
     if (make_lookahead(&b->lu_stream, b->lu_events)) {
         bb.aux_stream = b->lu_stream;
         for (int q = 0; q < 4; ++q) bb.aux_events[q] = b->lu_events[q];
@@ -1174,7 +1180,8 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         fd_ctx *c = b->ctxs[i];
         c->wait_event = b->ev1; c->wait_stream = stream; c->wait_batch = b;
         c->tev0 = b->ev0; c->tev_mid = b->ev_mid; c->tev1 = b->ev1;
-        c->have_factor = true;       // a batched build leaves the same factorisation a single one does
+        c->have_factor = true;       // a batched build leaves a factorisation fd_set_deltas can reuse
+        c->factor_grouped = bb.group_panels != 0;
         c->deltas_only = false;
         c->build_pending = true;
         c->built = false;

@@ -123,6 +123,10 @@ struct BuildBuffers {
     int Mpad;
     const BatchSlot *d_slots;         // device table, nbatch entries
     int nbatch;
+    // Panels grouped under one deep trailing update (fd_build.hip group_at): pays when the
+    // trailing updates are HBM-bound, i.e. for batches; a lone system is launch-bound and stays
+    // ungrouped.  The factorisation's layout depends on it, so fd_set_deltas must replay it.
+    int group_panels;
     // LU look-ahead: second stream + {panel done, rest done} x 2 events; aux_stream == nullptr
     // runs every step on the one stream
     hipStream_t aux_stream;

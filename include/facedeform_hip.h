@@ -210,10 +210,13 @@ void fd_host_free(void *p);
  * chains.  Contexts that share M, kernel, parameters and term -- the frames of
  * one rig, or several facedeform nodes of one cook graph -- can therefore be
  * assembled and factorised together: one launch chain, one workgroup column per
- * context.  Each context ends up exactly as after its own fd_build_async (the
- * kernels and their arithmetic are the same; results are bit-identical) and is
+ * context.  Each context ends up as after its own fd_build_async and is
  * evaluated with the usual fd_deform* calls; those wait for the batch where
- * they run on another stream.  Destroy the batch before its contexts. */
+ * they run on another stream.  Same kernels and pivots; up to order 512 the
+ * results are bit-identical to single builds, above that a batch of four or
+ * more groups its panels under deeper trailing updates (they are HBM-bound
+ * there) and the weights agree to rounding.  Destroy the batch before its
+ * contexts. */
 typedef struct fd_batch fd_batch;
 #define FD_MAX_BATCH 32
 fd_batch *fd_batch_create(fd_ctx *const *ctxs, int n);          /* 1..FD_MAX_BATCH contexts of one device */

@@ -200,3 +200,42 @@ def test_batched_evaluation_is_bit_identical_to_single_launches(hip_lib, kind, p
     b.close()
     for e in engines:
         e.close()
+
+
+def test_large_batches_group_panels(hip_lib, oracle):
+    """From four systems up a batched build groups its panels under deep trailing updates (they
+    are HBM-bound there).  Same pivots, another summation order: the weights agree with a single
+    build to rounding, with the oracle as usual, and fd_set_deltas on such a factorisation replays
+    the grouped sequence bit for bit."""
+    M, nb = 1100, 4                  # 32-wide panels above 512 rows are paired, 16-wide ones grouped by four
+    rest = synth.control_points(M, "head")
+    # deltas as the SOP forms them: float32(deformed - rest)
+    d = [((rest + synth.smooth_deltas(rest, f)).astype(np.float32) - rest).astype(np.float32) for f in range(nb + 1)]
+    es = []
+    for f in range(nb):
+        e = capi.Engine(); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+        e.set_points(rest, d[f]); es.append(e)
+    b = capi.Batch(es)
+    b.build_async(); reps = b.build_result()
+    assert [r.terminationtype for r in reps] == [1] * nb
+    single = capi.Engine(); single.set_kernel(capi.KERNEL_THIN_PLATE); single.set_term(0)
+    single.set_points(rest, d[2]); single.build()
+    Wb, _ = es[2].get_weights(); Ws, _ = single.get_weights()
+    scale = np.abs(Ws).max()
+    assert np.abs(Wb - Ws).max() <= 1e-10 * scale
+    table = oracle.control_table(rest, (rest + synth.smooth_deltas(rest, 2)).astype(np.float32))
+    assert np.array_equal(table[:, 3:], d[2].astype(np.float64))
+    rc, tt, W_ref, _ = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+    assert np.abs(Wb - W_ref).max() <= 1e-8 * scale
+    # new deltas through the grouped factorisation == a fresh batched build with those deltas
+    es[1].set_deltas(d[nb]); assert es[1].build().terminationtype == 1
+    W_fast, _ = es[1].get_weights()
+    es2 = []
+    for f in range(nb):
+        e = capi.Engine(); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0)
+        e.set_points(rest, d[nb] if f == 1 else d[f]); es2.append(e)
+    b2 = capi.Batch(es2); b2.build_async(); b2.build_result()
+    assert np.array_equal(W_fast, es2[1].get_weights()[0])
+    b.close(); b2.close(); single.close()
+    for e in es + es2:
+        e.close()
