@@ -54,7 +54,7 @@ EXPORTS = [
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
     "fd_mesh_set", "fd_mesh_size", "fd_deform_mesh",
-    "fd_capture_dist2", "fd_capture_dist2_dev",
+    "fd_capture_dist2", "fd_capture_dist2_dev", "fd_capture_islands", "fd_capture_islands_dev",
     "fd_morph_create", "fd_morph_destroy", "fd_morph_last_error", "fd_morph_init", "fd_morph_init_dev",
     "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
     "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
@@ -115,6 +115,8 @@ def load() -> C.CDLL:
     L.fd_deform_mesh.argtypes = [vp, vp, vp, C.c_float, C.c_float]; L.fd_deform_mesh.restype = i32
     L.fd_capture_dist2.argtypes = [vp, i64, vp, vp, i32, vp, C.c_float, i32, vp]; L.fd_capture_dist2.restype = i32
     L.fd_capture_dist2_dev.argtypes = [vp, i64, vp, vp, i32, vp, C.c_float, i32, vp]; L.fd_capture_dist2_dev.restype = i32
+    L.fd_capture_islands.argtypes = [vp, i64, vp, vp, vp, i32, vp, i32, vp]; L.fd_capture_islands.restype = i32
+    L.fd_capture_islands_dev.argtypes = [vp, i64, vp, vp, vp, i32, vp, i32, vp]; L.fd_capture_islands_dev.restype = i32
     L.fd_morph_create.argtypes = [C.POINTER(FdConfig)]; L.fd_morph_create.restype = vp
     L.fd_morph_destroy.argtypes = [vp]; L.fd_morph_destroy.restype = None
     L.fd_morph_last_error.argtypes = [vp]; L.fd_morph_last_error.restype = C.c_char_p
@@ -294,6 +296,17 @@ class Engine:
             if a is not None and (a.dtype != np.float32 or not a.flags.c_contiguous):
                 raise ValueError("arrays must be C-contiguous float32")
         self._check(self.L.fd_deform_mesh(self.ctx, _np_ptr(P_out), _np_ptr(falloff), float(radius2), float(falloffrate)))
+
+    def capture_islands(self, P, offsets, neighbours, rig, max_edges):
+        """ProximityCapture::findIslands as a byte mask (host arrays; CSR adjacency of the mesh's edges)."""
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+        rig = np.ascontiguousarray(rig, np.float32).reshape(-1, 3)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        neighbours = np.ascontiguousarray(neighbours, np.int32)
+        mask = np.zeros(P.shape[0], np.uint8)
+        self._check(self.L.fd_capture_islands(self.ctx, P.shape[0], _np_ptr(P), _np_ptr(offsets), _np_ptr(neighbours),
+                                              rig.shape[0], _np_ptr(rig), int(max_edges), _np_ptr(mask)))
+        return mask
 
     def capture_dist2(self, P, triangles, radius2, dofalloff=True, mask=None):
         """ProximityCapture's per-point squared distance to the rig surface (host arrays)."""

@@ -796,6 +796,55 @@ int fd_capture_dist2(fd_ctx *ctx, int64_t N, const float *P, const unsigned char
     return FD_OK;
 }
 
+int fd_capture_islands_dev(fd_ctx *ctx, int64_t N, const float *d_P, const int64_t *d_offsets, const int *d_neighbours,
+                           int M, const float *d_rig_xyz, int max_edges, unsigned char *d_mask)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (N < 0 || M < 0 || max_edges < 0 || (N > 0 && (!d_P || !d_offsets || !d_mask)) || (M > 0 && !d_rig_xyz)) {
+        set_err(ctx, "fd_capture_islands: bad sizes or NULL arrays");
+        return FD_E_INVALID;
+    }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    FD_HIP(ctx, launch_capture_islands(d_P, N, d_offsets, d_neighbours, d_rig_xyz, M, max_edges, d_mask, cur_stream(ctx)));
+    return FD_OK;
+}
+
+int fd_capture_islands(fd_ctx *ctx, int64_t N, const float *P, const int64_t *offsets, const int *neighbours, int M,
+                       const float *rig_xyz, int max_edges, unsigned char *mask)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (N < 0 || M < 0 || max_edges < 0 || (N > 0 && (!P || !offsets || !mask)) || (M > 0 && !rig_xyz)) {
+        set_err(ctx, "fd_capture_islands: bad sizes or NULL arrays");
+        return FD_E_INVALID;
+    }
+    if (N == 0) return FD_OK;
+    const int64_t E = offsets[N];
+    if (E < 0 || (E > 0 && !neighbours)) { set_err(ctx, "fd_capture_islands: bad adjacency"); return FD_E_INVALID; }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    hipStream_t s = cur_stream(ctx);
+    float *d_P = nullptr, *d_rig = nullptr;
+    int64_t *d_off = nullptr;
+    int *d_nb = nullptr;
+    unsigned char *d_mask = nullptr;
+    hipError_t e = hipMalloc((void **)&d_P, sizeof(float) * 3 * (size_t)N);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_off, sizeof(int64_t) * (size_t)(N + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_nb, sizeof(int) * (size_t)(E > 0 ? E : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_mask, (size_t)N);
+    if (e == hipSuccess && M > 0) e = hipMalloc((void **)&d_rig, sizeof(float) * 3 * (size_t)M);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_P, P, sizeof(float) * 3 * (size_t)N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && E > 0) e = hipMemcpyAsync(d_nb, neighbours, sizeof(int) * (size_t)E, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && M > 0) e = hipMemcpyAsync(d_rig, rig_xyz, sizeof(float) * 3 * (size_t)M, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_capture_islands(d_P, N, d_off, d_nb, d_rig, M, max_edges, d_mask, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(mask, d_mask, (size_t)N, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    for (void *p : {(void *)d_P, (void *)d_off, (void *)d_nb, (void *)d_mask, (void *)d_rig}) if (p) (void)hipFree(p);
+    if (e != hipSuccess) { set_err(ctx, "fd_capture_islands failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    return FD_OK;
+}
+
 void *fd_host_alloc(size_t bytes)
 {
     void *p = nullptr;

@@ -114,7 +114,71 @@ __global__ __launch_bounds__(kCapBlock) void k_capture_dist2(const float *P, int
     dist2[i] = out;
 }
 
+// ---- islands: ProximityCapture::findIslands (reference src/capture.cpp:101-141) ---------------
+// one workgroup per rig point: nearest mesh point (ties to the lower index), written as level 1
+__global__ __launch_bounds__(kCapBlock) void k_islands_seed(const float *P, int64_t N, const float *rig, unsigned char *level)
+{
+    __shared__ float s_d[kCapBlock / 64];
+    __shared__ long long s_i[kCapBlock / 64];
+    const float a[3] = {rig[3 * blockIdx.x], rig[3 * blockIdx.x + 1], rig[3 * blockIdx.x + 2]};
+    float best = INFINITY;
+    long long bi = 0x7fffffffffffffffll;
+    for (int64_t i = threadIdx.x; i < N; i += kCapBlock) {
+        const float d[3] = {P[3 * i] - a[0], P[3 * i + 1] - a[1], P[3 * i + 2] - a[2]};
+        const float dd = dot3(d, d);
+        if (dd < best) { best = dd; bi = i; }          // increasing i: the first minimum of this thread
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(best, off);
+        const long long oi = __shfl_xor(bi, off);
+        if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kCapBlock / 64; ++w)
+            if (s_d[w] < best || (s_d[w] == best && s_i[w] < bi)) { best = s_d[w]; bi = s_i[w]; }
+        if (bi < N) level[bi] = 1;
+    }
+}
+
+// one breadth-first level: every point at `cur` marks its unreached neighbours cur + 1
+// (several parents may write the same value into one neighbour: harmless)
+__global__ __launch_bounds__(kCapBlock) void k_islands_expand(unsigned char *level, int64_t N, const int64_t *offsets,
+                                                               const int *neighbours, int cur)
+{
+    const int64_t v = (int64_t)blockIdx.x * kCapBlock + threadIdx.x;
+    if (v >= N || level[v] != (unsigned char)cur) return;
+    for (int64_t e = offsets[v]; e < offsets[v + 1]; ++e) {
+        const int u = neighbours[e];
+        if (level[u] == 0) level[u] = (unsigned char)(cur + 1);
+    }
+}
+
+__global__ __launch_bounds__(kCapBlock) void k_islands_finish(unsigned char *level, int64_t N)
+{
+    const int64_t v = (int64_t)blockIdx.x * kCapBlock + threadIdx.x;
+    if (v < N) level[v] = level[v] ? 1 : 0;
+}
+
 }  // namespace
+
+// d_mask doubles as the level array while the rings grow (level + 1; 0 = not reached)
+hipError_t launch_capture_islands(const float *d_P, int64_t N, const int64_t *d_offsets, const int *d_neighbours,
+                                  const float *d_rig, int M, int max_edges, unsigned char *d_mask, hipStream_t stream)
+{
+    if (N <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_mask, 0, (size_t)N, stream);
+    if (e != hipSuccess) return e;
+    if (M <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((N + kCapBlock - 1) / kCapBlock);
+    hipLaunchKernelGGL(k_islands_seed, dim3((unsigned)M), dim3(kCapBlock), 0, stream, d_P, N, d_rig, d_mask);
+    if (max_edges > 250) max_edges = 250;         // levels live in a byte
+    for (int cur = 1; cur <= max_edges; ++cur)
+        hipLaunchKernelGGL(k_islands_expand, dim3(grid), dim3(kCapBlock), 0, stream, d_mask, N, d_offsets, d_neighbours, cur);
+    hipLaunchKernelGGL(k_islands_finish, dim3(grid), dim3(kCapBlock), 0, stream, d_mask, N);
+    return hipGetLastError();
+}
 
 hipError_t launch_capture_dist2(const float *d_P, int64_t N, const unsigned char *d_mask, const float *d_tri, int T,
                                 float radius2, int dofalloff, float *d_dist2, hipStream_t stream)

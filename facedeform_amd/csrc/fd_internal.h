@@ -155,6 +155,9 @@ struct DeformArgs {
 };
 hipError_t launch_deform(const DeformArgs &a, hipStream_t stream);
 hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream);
+// island mask (fd_capture.hip): nearest mesh point per rig point + max_edges breadth-first rings
+hipError_t launch_capture_islands(const float *d_P, int64_t N, const int64_t *d_offsets, const int *d_neighbours,
+                                  const float *d_rig, int M, int max_edges, unsigned char *d_mask, hipStream_t stream);
 // dist2 producer (fd_capture.hip): all pointers are device pointers, d_mask may be null
 hipError_t launch_capture_dist2(const float *d_P, int64_t N, const unsigned char *d_mask, const float *d_tri, int T,
                                 float radius2, int dofalloff, float *d_dist2, hipStream_t stream);

@@ -263,6 +263,19 @@ int fd_capture_dist2_dev(fd_ctx *ctx, int64_t N, const float *d_P, const unsigne
                          const float *d_tri_xyz, float radius2, int dofalloff, float *d_dist2);
 int fd_capture_dist2(fd_ctx *ctx, int64_t N, const float *P, const unsigned char *mask, int T,
                      const float *tri_xyz, float radius2, int dofalloff, float *dist2);
+/* The island mask itself: ProximityCapture::findIslands (src/capture.cpp:101-141).
+ * For every rig point the nearest mesh point (GEO_PointTree::findNearestIdx;
+ * ties to the lower index), then every mesh point within max_edges edges of it
+ * (GQ_Detail::groupEdgePoints, the start point included).  The handle classes
+ * only partition the islands into groups capture() treats alike, so the product
+ * is their union, mask[i] in {0, 1}.  The mesh's edges come as a CSR adjacency
+ * (offsets[N + 1], neighbours[offsets[N]]), which a static mesh needs building
+ * once.  max_edges is capped at 250. */
+int fd_capture_islands_dev(fd_ctx *ctx, int64_t N, const float *d_P, const int64_t *d_offsets,
+                           const int *d_neighbours, int M, const float *d_rig_xyz, int max_edges,
+                           unsigned char *d_mask);
+int fd_capture_islands(fd_ctx *ctx, int64_t N, const float *P, const int64_t *offsets, const int *neighbours,
+                       int M, const float *rig_xyz, int max_edges, unsigned char *mask);
 
 /* ---- morph-space reprojection (next row N1) ---------------------------------
  * Replaces DirectBSEdit (src/dbse.hpp:7-33, src/dbse.cpp:9-87) and the loop

@@ -548,3 +548,38 @@ void fdo_capture_dist2(const float *P_xyz, int64_t N, const unsigned char *mask,
     }
 }
 
+/* src/capture.cpp:101-141 */
+void fdo_capture_islands(const float *P_xyz, int64_t N, const int64_t *offsets, const int32_t *neighbours,
+                         const float *rig_xyz, int M, int max_edges, unsigned char *mask)
+{
+    int *level = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
+    int64_t *queue = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    for (int64_t i = 0; i < N; ++i) mask[i] = 0;
+    for (int m = 0; m < M && N > 0; ++m) {
+        /* :120-121 nearest mesh point of the rig point */
+        const double a[3] = {rig_xyz[3 * m], rig_xyz[3 * m + 1], rig_xyz[3 * m + 2]};
+        double best = INFINITY;
+        int64_t bi = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            const double dx = P_xyz[3 * i] - a[0], dy = P_xyz[3 * i + 1] - a[1], dz = P_xyz[3 * i + 2] - a[2];
+            const double d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; bi = i; }
+        }
+        /* :132 groupEdgePoints(target, max_edges): breadth first over the edges */
+        for (int64_t i = 0; i < N; ++i) level[i] = -1;
+        int64_t head = 0, tail = 0;
+        level[bi] = 0; queue[tail++] = bi;
+        while (head < tail) {
+            const int64_t v = queue[head++];
+            mask[v] = 1;                                             /* :133-134 combine into the handle's group */
+            if (level[v] >= max_edges) continue;
+            for (int64_t e = offsets[v]; e < offsets[v + 1]; ++e) {
+                const int32_t u = neighbours[e];
+                if (level[u] < 0) { level[u] = level[v] + 1; queue[tail++] = u; }
+            }
+        }
+    }
+    free(level);
+    free(queue);
+}
+

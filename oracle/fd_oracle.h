@@ -118,6 +118,15 @@ void fdo_morph_displace(const double *shapes, int64_t N, int S, const double *w,
 void fdo_capture_dist2(const float *P_xyz, int64_t N, const unsigned char *mask, const float *tri_xyz, int T,
                        float radius2, int dofalloff, float *dist2);
 
+/* ProximityCapture::findIslands (src/capture.cpp:101-141): for every rig point the nearest mesh
+ * point (GEO_PointTree::findNearestIdx; ties go to the lower index here), then every mesh point
+ * within max_edges edges of it (GQ_Detail::groupEdgePoints; the start point included).  The
+ * handle classes only partition the result into groups that capture() treats alike, so the
+ * product is their union: mask[i] = 1 for island points.  The mesh's edges come as a CSR
+ * adjacency (offsets[N+1], neighbours[offsets[N]]). */
+void fdo_capture_islands(const float *P_xyz, int64_t N, const int64_t *offsets, const int32_t *neighbours,
+                         const float *rig_xyz, int M, int max_edges, unsigned char *mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ class Oracle:
         L.fdo_morph_displace.restype = None
         L.fdo_capture_dist2.argtypes = [_f32p, C.c_int64, C.c_void_p, _f32p, C.c_int, C.c_float, C.c_int, _f32p]
         L.fdo_capture_dist2.restype = None
+        L.fdo_capture_islands.argtypes = [_f32p, C.c_int64, C.c_void_p, C.c_void_p, _f32p, C.c_int, C.c_int, C.c_void_p]
+        L.fdo_capture_islands.restype = None
 
     # -- A2
     def control_table(self, rest, deform):
@@ -183,4 +185,15 @@ class Oracle:
         self.lib.fdo_capture_dist2(_ptr(P, _f32p), P.shape[0], None if m is None else m.ctypes.data, _ptr(tri, _f32p),
                                    tri.shape[0], float(radius2), int(bool(dofalloff)), _ptr(out, _f32p))
         return out
+
+    def capture_islands(self, P, offsets, neighbours, rig, max_edges):
+        P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+        rig = np.ascontiguousarray(rig, np.float32).reshape(-1, 3)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        neighbours = np.ascontiguousarray(neighbours, np.int32)
+        assert offsets.shape[0] == P.shape[0] + 1 and offsets[-1] == neighbours.shape[0]
+        mask = np.zeros(P.shape[0], np.uint8)
+        self.lib.fdo_capture_islands(_ptr(P, _f32p), P.shape[0], offsets.ctypes.data, neighbours.ctypes.data,
+                                     _ptr(rig, _f32p), rig.shape[0], int(max_edges), mask.ctypes.data)
+        return mask
 

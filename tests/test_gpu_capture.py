@@ -105,3 +105,45 @@ def test_many_triangles_and_ragged_n(hip_lib, oracle):
     ref = oracle.capture_dist2(P, tris, 1e30, True)
     assert np.all(np.abs(out - ref) <= 2e-6 * (ref + 16.0))
     e.close()
+
+
+def _knn_adjacency(P, k=6):
+    """Symmetric k-nearest-neighbour graph of a point cloud as a CSR adjacency (a stand-in for the
+    mesh's edges: the synthetic meshes are lattices without topology)."""
+    from scipy.spatial import cKDTree
+    tree = cKDTree(P)
+    _, idx = tree.query(P, k=k + 1)
+    pairs = set()
+    for i in range(P.shape[0]):
+        for j in idx[i, 1:]:
+            pairs.add((i, int(j))); pairs.add((int(j), i))
+    nbrs = [[] for _ in range(P.shape[0])]
+    for i, j in sorted(pairs):
+        nbrs[i].append(j)
+    offsets = np.zeros(P.shape[0] + 1, np.int64)
+    offsets[1:] = np.cumsum([len(n) for n in nbrs])
+    return offsets, np.concatenate([np.array(n, np.int32) for n in nbrs])
+
+
+def test_islands_match_oracle_and_feed_the_capture(hip_lib, oracle):
+    """fd_capture_islands against the oracle on a k-NN graph of the head mesh, for several ring
+    counts, then the whole capture chain: islands -> dist2 -> deform."""
+    N, M = 30_000, 40
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    offsets, nb = _knn_adjacency(P)
+    e = capi.Engine()
+    for k in (0, 1, 4, 9):
+        got = e.capture_islands(P, offsets, nb, rest, k)
+        ref = oracle.capture_islands(P, offsets, nb, rest, k)
+        assert np.array_equal(got, ref), k
+        assert ref.sum() >= M // 2 and (k == 0 or ref.sum() > M)
+    assert e.capture_islands(P, offsets, nb, rest[:0], 4).sum() == 0
+    mask = e.capture_islands(P, offsets, nb, rest, 6)
+    tris = _rig_triangles(rest)
+    r2 = np.float32(0.04)
+    d2 = e.capture_dist2(P, tris, r2, True, mask)
+    assert np.array_equal(d2, oracle.capture_dist2(P, tris, r2, True, mask)) or \
+        np.all(np.abs(d2 - oracle.capture_dist2(P, tris, r2, True, mask))[(d2 >= 0)] <= 2e-6 * 2.0)
+    assert np.all(d2[mask == 0] == 0.0)
+    e.close()
