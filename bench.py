@@ -114,60 +114,78 @@ def cpu_baseline(cfg_name, P, rest, deform, max_pairs):
 
 
 def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev, rehearse):
-    """BASELINE config 5: ONE mesh, contiguous page-aligned vertex ranges per rank.  Per step:
-    rank 0 assembles + solves, exports the model blob into device memory, ONE broadcast (RCCL
-    over xGMI with the nccl backend), every rank imports it and evaluates its own range.  The
-    mesh is resident on every rank; only the ~26 KB blob moves.  Strong scaling."""
+    """BASELINE config 5: ONE mesh, contiguous page-aligned vertex ranges per rank.  Frames are
+    cooked in groups: rank 0 assembles + solves the group's models with ONE batched build and
+    exports them into one device buffer, ONE broadcast per group (RCCL over xGMI with the nccl
+    backend), every rank imports the models and evaluates its own vertex range for all frames of
+    the group with one launch.  Two lanes alternate, so rank 0's next build overlaps the current
+    evaluations.  The mesh is resident on every rank; only ~28 KB per frame move.  Strong scaling."""
     from facedeform_amd import dist as fdist
     n_verts, n_ctrl, mesh_kind, desc = CONFIGS["c5"]
     lo, hi = fdist.vertex_range(n_verts, rank, world)
     n_mine = hi - lo
+    B = max(1, min(args.inflight, 8))                 # frames per group (10M-vertex frames are large)
+    n_lanes = 2
     P_host = synth.head_mesh(n_verts)
     rest_host = synth.control_points(n_ctrl, mesh_kind)
     deltas_host = np.stack([synth.smooth_deltas(rest_host, f) for f in range(N_FRAMES)])
     d_P = torch.from_numpy(P_host[lo:hi]).to(dev)
-    d_out = torch.empty_like(d_P)
-    d_fall = torch.zeros(max(n_mine, 1), device=dev, dtype=torch.float32)
     d_rest = torch.from_numpy(rest_host).to(dev)
     d_deltas = torch.from_numpy(deltas_host).to(dev)
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    eng = capi.Engine(device=local_rank, variant=args.variant)
-    eng.set_stream(stream.cuda_stream)
-    eng.set_kernel(capi.KERNEL_THIN_PLATE)
-    eng.set_term(capi.TERM_LINEAR)
-    eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr(), n_ctrl)
-    eng.build()
-    nbytes = eng.model_bytes()
-    blob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-    blob_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory() if rehearse else None
     delta_stride = n_ctrl * 3 * 4
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    lanes = []
+    nbytes = None
+    for _ in range(n_lanes):
+        stream = torch.cuda.Stream(device=dev)
+        engines = []
+        for _ in range(B):
+            e = capi.Engine(device=local_rank, variant=args.variant)
+            e.set_stream(stream.cuda_stream)
+            e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
+            e.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr(), n_ctrl)
+            engines.append(e)
+        batch = capi.Batch(engines)
+        batch.build_async(stream.cuda_stream); batch.build_result()
+        nbytes = engines[0].model_bytes()
+        lanes.append({"stream": stream, "engines": engines, "batch": batch,
+                      "blob": torch.zeros((B, nbytes), dtype=torch.uint8, device=dev),
+                      "blob_host": torch.zeros((B, nbytes), dtype=torch.uint8).pin_memory() if rehearse else None,
+                      "out": [torch.empty_like(d_P) for _ in range(B)],
+                      "fall": [torch.zeros(max(n_mine, 1), device=dev, dtype=torch.float32) for _ in range(B)]})
+    n_groups = (args.steps + B - 1) // B
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_groups)]
 
-    def step(i, e=None):
-        frame = i % N_FRAMES
-        if e: e[0].record(stream)
-        if rank == 0:
-            eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr() + frame * delta_stride, n_ctrl)
-            eng.build_async()
+    def group(g, first, e=None):
+        """Frames first .. first + B - 1 (always a full group: the last one may cook spare frames)."""
+        ln = lanes[g % n_lanes]
+        stream, engines, batch, blob = ln["stream"], ln["engines"], ln["batch"], ln["blob"]
+        frames = [(first + k) % N_FRAMES for k in range(B)]
+        with torch.cuda.stream(stream):
+            if e: e[0].record(stream)
+            if rank == 0:
+                batch.set_points_dev([d_rest.data_ptr()] * B, [d_deltas.data_ptr() + f * delta_stride for f in frames], n_ctrl)
+                batch.build_async(stream.cuda_stream)
+                if world > 1:
+                    for k, eng in enumerate(engines):
+                        eng.export_model_dev(blob[k].data_ptr(), nbytes)      # waits for the build status
+            if e: e[1].record(stream)
             if world > 1:
-                eng.export_model_dev(blob.data_ptr(), nbytes)      # waits for the build status
-        if e: e[1].record(stream)
-        if world > 1:
-            if rehearse:                                            # gloo: through host memory
-                if rank == 0:
-                    blob_host.copy_(blob, non_blocking=False)
-                dist.broadcast(blob_host, src=0)
+                if rehearse:                                            # gloo: through host memory
+                    if rank == 0:
+                        ln["blob_host"].copy_(blob, non_blocking=False)
+                    dist.broadcast(ln["blob_host"], src=0)
+                    if rank != 0:
+                        blob.copy_(ln["blob_host"], non_blocking=False)
+                else:
+                    dist.broadcast(blob, src=0)
                 if rank != 0:
-                    blob.copy_(blob_host, non_blocking=False)
-            else:
-                dist.broadcast(blob, src=0)
-            if rank != 0:
-                eng.import_model_dev(blob.data_ptr(), nbytes, n_ctrl)
-        if e: e[2].record(stream)
-        if n_mine > 0:
-            eng.deform_dev(n_mine, d_P.data_ptr(), d_out.data_ptr(), d_falloff=d_fall.data_ptr())
-        if e: e[3].record(stream)
+                    for k, eng in enumerate(engines):
+                        eng.import_model_dev(blob[k].data_ptr(), nbytes, n_ctrl)
+            if e: e[2].record(stream)
+            if n_mine > 0:
+                batch.deform_dev(n_mine, [d_P.data_ptr()] * B, [o.data_ptr() for o in ln["out"]],
+                                 d_falloff=[f.data_ptr() for f in ln["fall"]], stream_ptr=stream.cuda_stream)
+            if e: e[3].record(stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -175,23 +193,24 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    for g in range((args.warmup + B - 1) // B + n_lanes):
+        group(g, g * B)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, ev[i])
+    for g in range(n_groups):
+        group(g, g * B, ev[g])
     sync_all()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    frames_done = n_groups * B                    # >= args.steps; the surplus is work done, not credited
     if rank == 0:
         build_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         bcast_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
         eval_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
-        flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_mine
+        flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_mine * B
         tf = flops / (eval_ms * 1e-3) / 1e12
         print(json.dumps({
             "metric": "deformed Mverts/sec, one 10M-vert mesh at 512 ctrl pts split across the GPUs",
@@ -199,17 +218,23 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc + ", thin-plate kernel, linear term, model rebuilt on rank 0 every step, "
-                                   "one model broadcast per step", "n_verts": n_verts, "n_ctrl": n_ctrl,
-                       "verts_on_rank0": n_mine, "model_blob_bytes": nbytes,
-                       "parallelism": f"vertex ranges over {world} GPU(s), 1 broadcast/step"},
-            "roofline": {"bound": "mfma", "kernel": "k_deform32_tps_mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+            "config": {"workload": desc + ", thin-plate kernel, linear term, models rebuilt on rank 0 every step "
+                                   f"({B} per batched build), one broadcast per {B} frames", "n_verts": n_verts,
+                       "n_ctrl": n_ctrl, "verts_on_rank0": n_mine, "model_blob_bytes": nbytes,
+                       "frames_per_group": B, "frames_cooked": frames_done,
+                       "parallelism": f"vertex ranges over {world} GPU(s), 1 broadcast per {B} frames, {n_lanes} lanes"},
+            "roofline": {"bound": "mfma", "kernel": "k_deform32_tps_mfma_batch" if B > 1 else "k_deform32_tps_mfma",
+                         "achieved": tf, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
-                         "flops_per_launch": flops, "avg_launch_ms": eval_ms},
-            "phases_ms": {"build_rank0": build_ms, "broadcast_and_import": bcast_ms, "evaluate": eval_ms},
+                         "flops_per_launch": flops, "avg_launch_ms": eval_ms, "frames_per_launch": B},
+            "phases_ms": {"build_group_rank0": build_ms, "broadcast_and_import": bcast_ms, "evaluate_group": eval_ms},
         }), flush=True)
-    eng.set_stream(None)
-    eng.close()
+    torch.cuda.synchronize()
+    for ln in lanes:
+        ln["batch"].close()
+        for e in ln["engines"]:
+            e.set_stream(None)
+            e.close()
     if world > 1:
         dist.destroy_process_group()
 
