@@ -177,8 +177,14 @@ __device__ __forceinline__ void epilogue_store(const EvalParams &p, int64_t i, c
         normalize3(n[0], n[1], n[2]);
         project_to_tangents(u, v, n, disp);
     }
-    float falloff = fminf(dist2 / p.radius2, 1.f);
-    falloff = powf(1.f - falloff, p.falloffrate);
+    // :423-424.  Without a dist2 attribute the value is 0: min(0 / r2, 1) = +-0 and pow(1, rate) = 1
+    // for every rate (C99), so the library powf -- a few dozen instructions per vertex -- is
+    // skipped; r2 == 0 (0/0) keeps the general path.
+    float falloff = 1.f;
+    if (p.dist2 != nullptr || !(p.radius2 != 0.f)) {
+        falloff = fminf(dist2 / p.radius2, 1.f);
+        falloff = powf(1.f - falloff, p.falloffrate);
+    }
     if (p.falloff_out) p.falloff_out[i] = falloff;
     p.P_out[3 * i] = pos[0] + disp[0] * falloff;
     p.P_out[3 * i + 1] = pos[1] + disp[1] * falloff;
@@ -458,6 +464,22 @@ __device__ __forceinline__ GroupIn<TV> load_group(const EvalParams &p, int64_t v
     return in;
 }
 
+// x + y across lane halves / rows: with X = value of tile a and Y = value of tile b,
+// swap32_sum gives rows 0,1 = X.row g + X.row g+2 and rows 2,3 = the same of Y;
+// swap16_sum(S, T) then gives row 0 = S.row0 + S.row1, row 1 = T.row0 + T.row1, row 2 =
+// S.row2 + S.row3, row 3 = T.row2 + T.row3.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap32_sum(float x, float y)
+{
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_sum(float x, float y)
+{
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // HALF = false: bf16 x 3 pieces, K = 32 (MfmaTile).  HALF = true: fp16 x 2 pieces, K = 16
 // (MfmaTileH): half the matrix-pipe time and operand bytes, about twice the d2 rounding error.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -552,7 +574,7 @@ __device__ __forceinline__ void deform32_tps_mfma_body(const EvalParams &p, int 
 #pragma unroll
         for (int t = 0; t < TV; ++t)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { acc[t][c] = (f32x2){0.f, 0.f}; acc2[t][c] = 0.f; }
+            for (int c = 0; c < 3; ++c) { acc[t][c] = (f32x2){0.f, 0.f}; if (!wave_work) acc2[t][c] = 0.f; }
 
         for (int ct0 = 0; ct0 < ntiles; ct0 += kTileChunk) {
             const int nct = ntiles - ct0 < kTileChunk ? ntiles - ct0 : kTileChunk;
@@ -583,13 +605,16 @@ __device__ __forceinline__ void deform32_tps_mfma_body(const EvalParams &p, int 
                         }
                     }
                 }
-                // second-level fp32 sums: a run is at most 4 * kTileChunk = 96 terms per slot
+                // second-level fp32 sums: a run is at most 4 * kTileChunk = 96 terms per slot.
+                // (the first chunk assigns; the accumulators are only cleared if another chunk follows)
+                const bool first = ct0 == 0, more = ct0 + kTileChunk < ntiles;
 #pragma unroll
                 for (int t = 0; t < TV; ++t)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        acc2[t][c] += acc[t][c].x + acc[t][c].y;
-                        acc[t][c] = (f32x2){0.f, 0.f};
+                        const float run = acc[t][c].x + acc[t][c].y;
+                        acc2[t][c] = first ? run : acc2[t][c] + run;
+                        if (more) acc[t][c] = (f32x2){0.f, 0.f};
                     }
             }
         }
@@ -598,16 +623,15 @@ __device__ __forceinline__ void deform32_tps_mfma_body(const EvalParams &p, int 
         // vertex j, and lane group g finishes tile g of every quartet
 #pragma unroll
         for (int q = 0; q < TV / 4; ++q) {
-            float mine[3] = {0.f, 0.f, 0.f};
+            // v_permlane32_swap + add folds rows g and g + 2 of two values at once, v_permlane16_swap
+            // + add finishes: lane group g ends up with the total of tile g (tools/permlane_swap_test.hip)
+            float mine[3];
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float v = acc2[4 * q + tt][c];
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
-                    if (tt == g) mine[c] = v;
-                }
+            for (int c = 0; c < 3; ++c) {
+                const float s02 = swap32_sum(acc2[4 * q + 0][c], acc2[4 * q + 2][c]);
+                const float s13 = swap32_sum(acc2[4 * q + 1][c], acc2[4 * q + 3][c]);
+                mine[c] = swap16_sum(s02, s13);
+            }
             const int64_t i = vbase + 16 * (4 * q + g) + j;
             if (i >= p.N) continue;
             const float pos[3] = {in.pos[q][0], in.pos[q][1], in.pos[q][2]};
