@@ -500,7 +500,6 @@ __device__ __forceinline__ void deform32_tps_mfma_body(const EvalParams &p, int 
     const int ntiles = p.Mpad / 16;
     const float n0 = p.model->norm32[0], n1 = p.model->norm32[1], n2 = p.model->norm32[2];
     const float inv_s = p.model->norm32[3];
-    const float nsel = g == 0 ? n0 : (g == 1 ? n1 : n2);
     const bool built = p.model->terminationtype == 1;
     const bool resident = ntiles <= kTileChunk;     // the whole model fits: stage it once
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -529,19 +528,27 @@ __device__ __forceinline__ void deform32_tps_mfma_body(const EvalParams &p, int 
         }
 
         // B operand (vertex side) of every vertex tile of this wave
+        // this lane's own vertices (tile g of every quartet, column j), normalised once: the
+        // B-operand slots of all lane groups fetch from here by shuffle, and the epilogue reuses it
+        float npos[TV / 4][3], xx_own[TV / 4], m2pos[TV / 4][3];
+#pragma unroll
+        for (int q = 0; q < TV / 4; ++q) {
+            npos[q][0] = (in.pos[q][0] - n0) * inv_s;
+            npos[q][1] = (in.pos[q][1] - n1) * inv_s;
+            npos[q][2] = (in.pos[q][2] - n2) * inv_s;
+            xx_own[q] = __builtin_fmaf(npos[q][2], npos[q][2], __builtin_fmaf(npos[q][1], npos[q][1], npos[q][0] * npos[q][0]));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) m2pos[q][c] = -2.f * npos[q][c];
+        }
         Operand bop[TV];
 #pragma unroll
         for (int t = 0; t < TV; ++t) {
-            // coordinate g of vertex (tile t, column j): it sits in lane group t & 3 of quartet t / 4
+            // vertex (tile t, column j) sits in lane group t & 3 of quartet t / 4
             const int srcl = 16 * (t & 3) + j;
-            const float c0 = __shfl(in.pos[t / 4][0], srcl), c1 = __shfl(in.pos[t / 4][1], srcl),
-                        c2 = __shfl(in.pos[t / 4][2], srcl);
-            const float craw = g == 0 ? c0 : (g == 1 ? c1 : c2);
-            const float comp = g < 3 ? (craw - nsel) * inv_s : 0.f;
-            float xx = comp * comp;
-            xx += __shfl_xor(xx, 16);
-            xx += __shfl_xor(xx, 32);
-            const float v2 = g < 3 ? -2.f * comp : xx;
+            const float c0 = __shfl(m2pos[t / 4][0], srcl), c1 = __shfl(m2pos[t / 4][1], srcl),
+                        c2 = __shfl(m2pos[t / 4][2], srcl), xs = __shfl(xx_own[t / 4], srcl);
+            // lane group g < 3 carries -2 x'_g, group 3 carries |x'|^2
+            const float v2 = g == 0 ? c0 : (g == 1 ? c1 : (g == 2 ? c2 : xs));
             if constexpr (HALF) {
                 const _Float16 h = (_Float16)v2;
                 const _Float16 l = (_Float16)(v2 - (float)h);
@@ -642,8 +649,8 @@ __device__ __forceinline__ void deform32_tps_mfma_body(const EvalParams &p, int 
                 }
                 continue;
             }
-            const float x = (pos[0] - n0) * inv_s, y = (pos[1] - n1) * inv_s, z = (pos[2] - n2) * inv_s;
-            const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+            const float x = npos[q][0], y = npos[q][1], z = npos[q][2];
+            const float xx = xx_own[q];
             const float *a = p.model->poly32;
             float disp[3];
 #pragma unroll
