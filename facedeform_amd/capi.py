@@ -19,6 +19,7 @@ FD_E_INVALID, FD_E_NOMEM, FD_E_DEVICE, FD_E_SINGULAR, FD_E_DUPLICATE, FD_E_NOT_B
 KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC = range(5)
 TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
 EVAL_FP32, EVAL_FP64 = 0, 1
+SOLVER_AUTO, SOLVER_LU = 0, 1
 FDSOP_OK, FDSOP_MESSAGE, FDSOP_WARNING, FDSOP_ERROR = range(4)
 
 _f32p = C.POINTER(C.c_float)
@@ -27,7 +28,7 @@ _f64p = C.POINTER(C.c_double)
 
 class FdConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int), ("device", C.c_int), ("eval_precision", C.c_int),
-                ("eval_variant", C.c_int), ("reserved", C.c_int * 4)]
+                ("eval_variant", C.c_int), ("solver", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class FdReport(C.Structure):
@@ -175,13 +176,13 @@ def _np_ptr(a):
 class Engine:
     """Thin object wrapper over fd_ctx.  Host arrays are numpy; device pointers are ints."""
 
-    def __init__(self, device: int = -1, precision: int = EVAL_FP32, variant: int = 0, _borrowed=None):
+    def __init__(self, device: int = -1, precision: int = EVAL_FP32, variant: int = 0, solver: int = 0, _borrowed=None):
         self.L = load()
         self._own = _borrowed is None
         if _borrowed is not None:
             self.ctx = _borrowed
             return
-        cfg = FdConfig(C.sizeof(FdConfig), device, precision, variant)
+        cfg = FdConfig(C.sizeof(FdConfig), device, precision, variant, solver)
         self.ctx = self.L.fd_create(C.byref(cfg))
         if not self.ctx:
             raise FdError(FD_E_NO_DEVICE, self.L.fd_last_error(None).decode())

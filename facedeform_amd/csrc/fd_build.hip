@@ -1072,26 +1072,56 @@ void lu_group_step(const BuildBuffers &b, int k0, int step, int np, hipStream_t 
 
 }  // namespace
 
-static void launch_backsub(const BuildBuffers &b, hipStream_t stream)
+static void launch_backsub(const BuildBuffers &b, hipStream_t stream, int rows)
 {
     const unsigned nb = (unsigned)b.nbatch;
-    {
-        if (b.npad <= 512) {
-            const size_t ybytes = sizeof(double) * 3 * (size_t)b.npad;
-            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), ybytes, stream, b.d_slots, b.lda,
-                               b.npad, 0, b.npad);
-        } else {
-            constexpr int W = 256;      // rows per diagonal range (a multiple of 32, like npad)
-            for (int hi = b.npad; hi > 0; hi -= W) {
-                const int lo = hi > W ? hi - W : 0;
-                hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)(hi - lo),
-                                   stream, b.d_slots, b.lda, b.npad, lo, hi);
-                if (lo > 0)
-                    hipLaunchKernelGGL(k_backsub_update, dim3((lo + 255) / 256, 1, nb), dim3(256), 0, stream,
-                                       b.d_slots, b.lda, b.npad, lo, hi - lo);
-            }
+    if (rows <= 512) {
+        const size_t ybytes = sizeof(double) * 3 * (size_t)rows;
+        hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), ybytes, stream, b.d_slots, b.lda,
+                           b.npad, 0, rows);
+    } else {
+        constexpr int W = 256;      // rows per diagonal range (a multiple of 32, like npad)
+        for (int hi = rows; hi > 0; hi -= W) {
+            const int lo = hi > W ? hi - W : 0;
+            hipLaunchKernelGGL((k_backsub_all<256>), dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)(hi - lo),
+                               stream, b.d_slots, b.lda, b.npad, lo, hi);
+            if (lo > 0)
+                hipLaunchKernelGGL(k_backsub_update, dim3((lo + 255) / 256, 1, nb), dim3(256), 0, stream,
+                                   b.d_slots, b.lda, b.npad, lo, hi - lo);
         }
     }
+}
+
+hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int rows)
+{
+    launch_backsub(b, stream, rows);
+    return hipGetLastError();
+}
+
+// the kernel block alone: phi + lambda on the diagonal for i, j < M, identity padding up to npad_a
+hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    if (npad_a <= 512) {
+        const unsigned g = (unsigned)(npad_a + 31) / 32;
+        hipLaunchKernelGGL((k_assemble<2>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, b.M, b.M, npad_a,
+                           b.lda, b.kind, 0, b.lambda);
+    } else {
+        const unsigned g = (unsigned)(npad_a + 63) / 64;
+        hipLaunchKernelGGL((k_assemble<4>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, b.M, b.M, npad_a,
+                           b.lda, b.kind, 0, b.lambda);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare_rhs(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
+{
+    static const PointSrc none{};
+    const int threads = 256;
+    const int blocks = (b.npad + threads - 1) / threads;
+    hipLaunchKernelGGL(k_prepare_rhs, dim3(blocks, 1, (unsigned)b.nbatch), dim3(threads), 0, stream, b.d_slots,
+                       src ? *src : none, src ? 1 : 0, b.M, b.npad, b.lda);
+    return hipGetLastError();
 }
 
 // centres, right-hand sides, status reset.  src == nullptr: read the contexts' own copies of
@@ -1109,6 +1139,7 @@ hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const Point
 // everything after k_prepare: radii, assembly, LU, back-substitution, packing
 hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
 {
+    if (b.spd) return launch_build_spd(b, stream, ev_mid);
     const int M = b.M;
     const unsigned nb = (unsigned)b.nbatch;
     {
@@ -1156,7 +1187,7 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
     }
     // rejoin: whatever part-B update is still running on the aux stream
     if (st.rest_pending) (void)hipStreamWaitEvent(st.main, st.ev_rest[st.last_rest], 0);
-    launch_backsub(b, stream);
+    launch_backsub(b, stream, b.npad);
     hipError_t e = launch_pack(b, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
@@ -1189,6 +1220,7 @@ hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream)
 // the RHS block is exactly one of the trailing update's column blocks.
 hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
 {
+    if (b.spd) return launch_resolve_spd(b, stream, src);
     static const PointSrc none{};
     const unsigned nb = (unsigned)b.nbatch;
     if (b.npad > 2048) return hipErrorInvalidValue;
@@ -1221,7 +1253,7 @@ hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const Point
         k0 += w;
         ++step;
     }
-    launch_backsub(b, stream);
+    launch_backsub(b, stream, b.npad);
     hipError_t e = launch_pack(b, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();

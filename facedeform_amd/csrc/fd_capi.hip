@@ -17,6 +17,7 @@ struct fd_ctx {
     hipStream_t stream_ = nullptr;          // fd_set_stream; nullptr: own_stream
     int eval_precision = FD_EVAL_FP32;
     int eval_variant = 0;
+    int solver = FD_SOLVER_AUTO;
 
     // model configuration
     int M = 0, kind = FD_KERNEL_GAUSSIAN_QNN, term = FD_TERM_LINEAR, nparams = 0;
@@ -44,6 +45,7 @@ struct fd_ctx {
     Rec64 *d_rec64 = nullptr;
     MfmaTile *d_tiles = nullptr;
     MfmaTileH *d_tiles16 = nullptr;
+    double *d_ns = nullptr;          // null-space solver state (fd_nullspace.hip)
     DevModel *d_model = nullptr;
     DevModel *h_model = nullptr;  // pinned mirror
     // where the build kernels find the buffers above: a one-entry device table (a single build
@@ -165,6 +167,7 @@ static int dev_alloc(fd_ctx *ctx, T **p, size_t count)
 }
 
 static int order_of(const fd_ctx *ctx) { return ctx->M + term_cols(ctx->term); }
+static bool use_spd(const fd_ctx *ctx);
 
 static int ensure_model_capacity(fd_ctx *ctx, int M)
 {
@@ -180,6 +183,7 @@ static int ensure_model_capacity(fd_ctx *ctx, int M)
         if ((rc = dev_alloc(ctx, &ctx->d_rec64, (size_t)Mpad))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_tiles, (size_t)Mpad / 16))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_tiles16, (size_t)Mpad / 16))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_ns, ns_doubles(M)))) return rc;
         ctx->cap_M = M;
     }
     return FD_OK;
@@ -229,6 +233,7 @@ static int sync_slot(fd_ctx *ctx)
     t.ipiv = ctx->d_ipiv; t.moves = ctx->d_moves;
     t.rec32 = ctx->d_rec32; t.rec64 = ctx->d_rec64; t.tiles = ctx->d_tiles; t.tiles16 = ctx->d_tiles16;
     t.model = ctx->d_model;
+    t.ns = ctx->d_ns;
     if (ctx->alloc_gen != 0 && memcmp(&t, &ctx->h_slot, sizeof(t)) == 0) return FD_OK;
     // a buffer moved: hipFree in dev_alloc has drained the device, nothing reads the old table
     FD_HIP(ctx, hipMemcpy(ctx->d_slot, &t, sizeof(t), hipMemcpyHostToDevice));
@@ -282,6 +287,7 @@ fd_ctx *fd_create(const fd_config *cfg)
     if (cfg) {
         ctx->eval_precision = cfg->eval_precision == FD_EVAL_FP64 ? FD_EVAL_FP64 : FD_EVAL_FP32;
         ctx->eval_variant = cfg->eval_variant;
+        ctx->solver = cfg->solver == FD_SOLVER_LU ? FD_SOLVER_LU : FD_SOLVER_AUTO;
     }
     hipDeviceProp_t prop;
     if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
@@ -320,7 +326,7 @@ void fd_destroy(fd_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream_ || ctx->own_stream) (void)hipStreamSynchronize(cur_stream(ctx));
     void *bufs[] = {ctx->d_rest, ctx->d_delta, ctx->d_centres, ctx->d_radii, ctx->d_W, ctx->d_A,
-                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_tiles16, ctx->d_model, ctx->d_slot,
+                    ctx->d_X, ctx->d_ipiv, ctx->d_moves, ctx->d_rec32, ctx->d_rec64, ctx->d_tiles, ctx->d_tiles16, ctx->d_ns, ctx->d_model, ctx->d_slot,
                     ctx->d_P, ctx->d_dist2, ctx->d_fall, ctx->d_tu, ctx->d_tv, ctx->d_nrm,
                     ctx->m_P, ctx->m_dist2, ctx->m_tu, ctx->m_tv, ctx->m_nrm, ctx->m_out, ctx->m_fall};
     for (void *p : bufs) if (p) (void)hipFree(p);
@@ -389,7 +395,7 @@ static int set_deltas_common(fd_ctx *ctx, const float *delta, int M, bool on_dev
                      "fd_set_kernel / fd_set_term / fd_import_model discard it)", M);
         return FD_E_NOT_BUILT;
     }
-    if (round_up(order_of(ctx), 32) > 2048) {
+    if (!use_spd(ctx) && round_up(order_of(ctx), 32) > 2048) {
         set_err(ctx, "fd_set_deltas: supported up to order 2048 (M = %d here); use fd_set_points", M);
         return FD_E_INVALID;
     }
@@ -466,6 +472,14 @@ static double ctx_lambda(const fd_ctx *ctx)
     return ctx->nparams > idx ? ctx->params[idx] : 0.0;
 }
 
+// FD_SOLVER=lu keeps every system on the pivoted LU (A/B measurements, tests of that path)
+static bool use_spd(const fd_ctx *ctx)
+{
+    static const char *env = getenv("FD_SOLVER");
+    if ((env && strcmp(env, "lu") == 0) || ctx->solver == FD_SOLVER_LU) return false;
+    return spd_applicable(ctx->kind, ctx->term, ctx_lambda(ctx), ctx->M);
+}
+
 static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
 {
     b.M = ctx->M;
@@ -484,6 +498,7 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.d_slots = ctx->d_slot;
     b.nbatch = 1;
     b.group_panels = 0;
+    b.spd = use_spd(ctx) ? 1 : 0;
     b.aux_stream = nullptr;
     for (hipEvent_t &e : b.aux_events) e = nullptr;
 }

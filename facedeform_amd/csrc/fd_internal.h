@@ -9,6 +9,15 @@
 
 namespace fd {
 
+// A pointer fetched from a table in memory is a generic pointer to the compiler: every access
+// through it becomes a flat_load / flat_store, which counts on BOTH wait counters and so
+// serialises against LDS traffic.  The build kernels take their buffers from the batch table, so
+// they say explicitly that these live in global memory.
+#define FD_GLOBAL __attribute__((address_space(1)))
+typedef double FD_GLOBAL gdouble;
+typedef const double FD_GLOBAL gcdouble;
+template <typename T> __host__ __device__ __forceinline__ T FD_GLOBAL *as_global(T *p) { return (T FD_GLOBAL *)p; }
+
 // ---- solved model as the evaluation kernels read it --------------------------
 // One record per centre, 32 B: the unit a scalar s_load_dwordx8 fetches.
 //   s  = per-centre kernel scale (Gaussian: -log2(e)/R_j^2, otherwise 0)
@@ -106,6 +115,7 @@ struct BatchSlot {
     MfmaTile *tiles;                  // Mpad / 16 tiles (thin-plate only)
     MfmaTileH *tiles16;               // the fp16 form of the same tiles
     DevModel *model;
+    double *ns;                       // null-space solver state (fd_nullspace.hip): ns_doubles(M) doubles
 };
 
 // Caller-owned device arrays of control points, one pair per model of a batch (kernel argument).
@@ -127,6 +137,10 @@ struct BuildBuffers {
     // trailing updates are HBM-bound, i.e. for batches; a lone system is launch-bound and stays
     // ungrouped.  The factorisation's layout depends on it, so fd_set_deltas must replay it.
     int group_panels;
+    // Symmetric definite path (fd_nullspace.hip): the polynomial constraints are eliminated with
+    // Householder reflectors and the projected kernel block, order M - T, is Cholesky-factorised
+    // -- no pivot search, so the panel is no longer one workgroup's serial chain.
+    int spd;
     // LU look-ahead: second stream + {panel done, rest done} x 2 events; aux_stream == nullptr
     // runs every step on the one stream
     hipStream_t aux_stream;
@@ -138,6 +152,18 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
 hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream);
 hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream);
+// pieces of the LU pipeline the null-space path reuses: the kernel block alone (order M, identity
+// padding to npad_a) and back-substitution with the upper triangle over rows [0, rows)
+hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a);
+hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int rows);
+hipError_t launch_prepare_rhs(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
+
+// ---- null-space Cholesky build (fd_nullspace.hip) -----------------------------------
+// Which (kernel, term, lambda) make the projected block positive definite; M large enough to project.
+bool spd_applicable(int kind, int term, double lambda, int M);
+static inline size_t ns_doubles(int M) { return (size_t)12 * (size_t)M + 64 + (size_t)(M / 32 + 2) * 34 * 32; }
+hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
+hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 
 // ---- evaluation (fd_eval.hip) --------------------------------------------------
 struct DeformArgs {

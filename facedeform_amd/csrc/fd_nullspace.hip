@@ -1,0 +1,736 @@
+// fd_nullspace.hip -- the symmetric definite build: null-space projection + blocked Cholesky.
+//
+// Same system as fd_build.hip (replaces alglib::rbfbuildmodel, reference
+// src/SOP_FaceDeform.cpp:363-368, in north_star's dense formulation)
+//
+//     [ K   P ] [ w ]   [ f ]        K = Phi + lambda*I  (M x M, symmetric)
+//     [ P^T 0 ] [ a ] = [ 0 ]        P = [1 x y z]       (M x T)
+//
+// but solved without pivoting.  For the kernels that are conditionally positive definite of the
+// order their polynomial term covers (thin-plate and cubic with the linear term, biharmonic with
+// a constant or linear term, the fixed-radius Gaussian with any term) K is positive definite on
+// the null space of P^T.  With P = Q [0; R] (T Householder reflectors, R in the LAST T rows):
+//
+//     w = Q [y; 0],   B = Q^T K Q,   B11 y = (Q^T f)_1,   R a = (Q^T f)_2 - B21 y
+//
+// and B11 (order n1 = M - T) has a Cholesky factorisation.  Partial pivoting made the LU panel a
+// serial chain on ONE workgroup (fd_build.hip: ~0.8-1.6 us per column, 3.3 of 6.6 ms at order
+// 2052); here only the 32 x 32 diagonal block is sequential, the rows below it are independent.
+//
+// Pipeline (every kernel indexes the batch table with blockIdx.z, like the LU kernels):
+//   k_ns_reflectors   one workgroup: Householder vectors V (M x T), tau, R, the compact-WY factor
+//   k_ns_rhs          one workgroup: f <- Q^T f in the right-hand-side columns of A
+//   k_assemble        (fd_build.hip) K into A, full square
+//   k_ns_kv           Y = K V
+//   k_ns_w            W = Y Tm - (1/2) V (Tm^T V^T Y Tm), so that B = K - V W^T - W V^T
+//   k_ns_rotate       lower triangle of B11 in place, B21 aside, identity padding to npc
+//   per 32 columns:   k_chol_solve (the rows below the diagonal block and the right-hand sides:
+//                     X L11^T = A21, one row per thread) and k_chol_trail (A22 -= L21 L21^T,
+//                     lower triangle, v_mfma_f64_16x16x4_f64) whose last workgroup updates and
+//                     factorises the NEXT diagonal block (one wave, rows in registers) beside the
+//                     others -- the sequential part is off the critical path.
+//                     The right-hand sides ride along as three extra rows, so the forward solve
+//                     costs nothing; L^T is mirrored into the upper triangle as it is produced,
+//   k_backsub_*       (fd_build.hip) so the LU back-substitution kernels solve L^T y = z as is
+//   k_ns_recover      a from R, w = Q [y; 0], into X in the layout k_pack expects.
+//
+// fd_set_deltas (launch_resolve_spd) sends new right-hand sides through the same kernels with the
+// matrix work switched off: identical operands in identical order, bit-identical weights.
+#include "fd_internal.h"
+
+namespace fd {
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr double kEps = 2.220446049250313e-16;
+constexpr int kNB = 32;                 // Cholesky block width
+constexpr int kSlab = 256;              // rows per workgroup of the panel's triangular solve
+
+// small block of the solver state, after V, W and B21 (each M x 4)
+constexpr int kTau = 0;                 // tau[4]
+constexpr int kR = 4;                   // R[k][c], row k = pivot row M-1-k
+constexpr int kTm = 20;                 // compact WY: Q = I - V Tm V^T, upper triangular
+constexpr int kG = 36;                  // (Q^T f) in the pivot rows: g[k][c]
+constexpr int kSmall = 64;
+// after the small block: the factorised diagonal blocks, one per 32 columns -- L11 column-major
+// (32 x 32, zeros above the diagonal) followed by the reciprocals of its diagonal: what the
+// triangular solves stage into LDS, in the full build and in fd_set_deltas alike.
+constexpr int kLdStride = 34 * 32;
+__device__ __forceinline__ gdouble *ld_block(double *ns, int M, int k0) { return as_global(ns) + (size_t)12 * M + kSmall + (size_t)(k0 / kNB) * kLdStride; }
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// N sums over a 256-thread workgroup at once; every thread gets all of them
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double *scratch /* [4][N] */, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        for (int off = 32; off >= 1; off >>= 1) v[q] += __shfl_xor(v[q], off);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) scratch[(tid >> 6) * N + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = (scratch[q] + scratch[N + q]) + (scratch[2 * N + q] + scratch[3 * N + q]);
+}
+
+// ---- reflectors ----------------------------------------------------------------------
+// LAPACK dlarfg turned upside down: reflector k acts on rows 0 .. M-1-k and leaves its beta in
+// row M-1-k, so the null-space block comes FIRST in the rotated system and the Cholesky starts
+// at row 0 on tile boundaries.
+__global__ __launch_bounds__(256) void k_ns_reflectors(const BatchSlot *tab, int M, int T)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *centres = as_global(s.centres);
+    gdouble *V = as_global(s.ns), *small = V + (size_t)12 * M;
+    __shared__ double s_red[4 * 8];
+    const int tid = threadIdx.x;
+
+    double cn[4] = {0.0, 0.0, 0.0, 0.0};     // squared norms of the columns of P
+    for (int i = tid; i < M; i += 256) {
+        const double p[4] = {1.0, centres[3 * i], centres[3 * i + 1], centres[3 * i + 2]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double v = t < T ? p[t] : 0.0;
+            V[4 * (size_t)i + t] = v;
+            cn[t] = fma(v, v, cn[t]);
+        }
+    }
+    block_sum_n<4>(cn, s_red, tid);          // its barriers also publish V
+    bool singular = false;
+    for (int k = 0; k < T; ++k) {
+        const int piv = M - 1 - k;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0}; // sigma, then x . column c for c = k+1 ..
+        for (int i = tid; i < piv; i += 256) {
+            const double x = V[4 * (size_t)i + k];
+            acc[0] = fma(x, x, acc[0]);
+            for (int c = k + 1; c < T; ++c) acc[c - k] = fma(x, V[4 * (size_t)i + c], acc[c - k]);
+        }
+        block_sum_n<4>(acc, s_red, tid);
+        const double xp = V[4 * (size_t)piv + k];
+        const double sigma = acc[0];
+        const double norm = sqrt(fma(xp, xp, sigma));
+        double beta = xp, tau = 0.0, scale = 0.0;
+        if (sigma > 0.0) {
+            beta = xp >= 0.0 ? -norm : norm;
+            tau = (beta - xp) / beta;
+            scale = 1.0 / (xp - beta);
+        }
+        if (!(norm > 64.0 * (double)M * kEps * sqrt(cn[k]))) singular = true;   // P has no full column rank (NaN too)
+        double sc[4] = {0.0, 0.0, 0.0, 0.0};  // v . column c
+        double prow[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int c = k + 1; c < T; ++c) { prow[c] = V[4 * (size_t)piv + c]; sc[c] = fma(scale, acc[c - k], prow[c]); }
+        __syncthreads();                      // everyone has read the pivot row
+        for (int i = tid; i < piv; i += 256) {
+            const double v = V[4 * (size_t)i + k] * scale;
+            V[4 * (size_t)i + k] = v;
+            for (int c = k + 1; c < T; ++c) V[4 * (size_t)i + c] = fma(-tau * sc[c], v, V[4 * (size_t)i + c]);
+        }
+        if (tid == 0) {
+            small[kTau + k] = tau;
+            small[kR + 4 * k + k] = beta;
+            V[4 * (size_t)piv + k] = 1.0;
+            for (int c = k + 1; c < T; ++c) {
+                small[kR + 4 * k + c] = fma(-tau, sc[c], prow[c]);
+                V[4 * (size_t)piv + c] = 0.0;   // the later reflectors end above this row
+            }
+        }
+        __syncthreads();
+    }
+    // compact WY factor (dlarft, forward columnwise) from the Gram matrix of V
+    double gram[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+    for (int i = tid; i < M; i += 256) {
+        const double v0 = V[4 * (size_t)i], v1 = V[4 * (size_t)i + 1], v2 = V[4 * (size_t)i + 2], v3 = V[4 * (size_t)i + 3];
+        gram[0] = fma(v0, v1, gram[0]); gram[1] = fma(v0, v2, gram[1]); gram[2] = fma(v0, v3, gram[2]);
+        gram[3] = fma(v1, v2, gram[3]); gram[4] = fma(v1, v3, gram[4]); gram[5] = fma(v2, v3, gram[5]);
+    }
+    block_sum_n<8>(gram, s_red, tid);
+    if (tid == 0) {
+        double G[4][4] = {};
+        G[0][1] = gram[0]; G[0][2] = gram[1]; G[0][3] = gram[2]; G[1][2] = gram[3]; G[1][3] = gram[4]; G[2][3] = gram[5];
+        double Tm[4][4] = {};
+        for (int k = 0; k < T; ++k) {
+            const double tau = small[kTau + k];
+            Tm[k][k] = tau;
+            for (int a = 0; a < k; ++a) {
+                double v = 0.0;
+                for (int b = a; b < k; ++b) v = fma(Tm[a][b], G[b][k], v);
+                Tm[a][k] = -tau * v;
+            }
+        }
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) small[kTm + 4 * a + b] = Tm[a][b];
+        for (int k = T; k < 4; ++k) small[kTau + k] = 0.0;
+        if (singular) s.model->sing_flag = 1;
+    }
+}
+
+// f <- Q^T f = H_{T-1} .. H_0 f in the right-hand-side columns; the pivot rows' values go aside
+// (they belong to the polynomial equations) and read as zero padding afterwards.
+__global__ __launch_bounds__(256) void k_ns_rhs(const BatchSlot *tab, int M, int T, int npad, int lda)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *V = as_global(s.ns);
+    gdouble *small = as_global(s.ns) + (size_t)12 * M;
+    gdouble *f0 = as_global(s.A) + (size_t)npad * lda, *f1 = f0 + lda, *f2 = f1 + lda;
+    __shared__ double s_red[4 * 3];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < T; ++k) {
+        const int piv = M - 1 - k;
+        const double tau = small[kTau + k];
+        double d[3] = {0.0, 0.0, 0.0};
+        for (int i = tid; i <= piv; i += 256) {
+            const double v = V[4 * (size_t)i + k];
+            d[0] = fma(v, f0[i], d[0]); d[1] = fma(v, f1[i], d[1]); d[2] = fma(v, f2[i], d[2]);
+        }
+        block_sum_n<3>(d, s_red, tid);
+        for (int i = tid; i <= piv; i += 256) {
+            const double v = V[4 * (size_t)i + k];
+            f0[i] = fma(-tau * d[0], v, f0[i]); f1[i] = fma(-tau * d[1], v, f1[i]); f2[i] = fma(-tau * d[2], v, f2[i]);
+        }
+        __syncthreads();
+    }
+    if (tid < T) {
+        const int piv = M - 1 - tid;
+        small[kG + 3 * tid] = f0[piv]; small[kG + 3 * tid + 1] = f1[piv]; small[kG + 3 * tid + 2] = f2[piv];
+        f0[piv] = 0.0; f1[piv] = 0.0; f2[piv] = 0.0;
+    }
+}
+
+// ---- Y = K V ---------------------------------------------------------------------------
+// 64 rows per workgroup, one row per lane (consecutive lanes walk a column of A: coalesced); the
+// four waves split the columns and their partial sums are added in a fixed order
+__global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int lda)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *A = as_global(s.A), *V = as_global(s.ns);
+    gdouble *Y = as_global(s.ns) + (size_t)4 * M;
+    __shared__ double s_part[4][64][4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = blockIdx.x * 64 + lane;
+    const int ic = i < M ? i : M - 1;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int per = ((M + 3) / 4 + 7) & ~7;            // columns per wave, a multiple of the unroll
+    const int jlo = wave * per, jhi = jlo + per < M ? jlo + per : M;
+    for (int j0 = jlo; j0 < jhi; j0 += 8) {
+        double a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int j = j0 + q < M ? j0 + q : M - 1; a[q] = A[(size_t)j * lda + ic]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (j0 + q < jhi) {
+                gcdouble *v = V + 4 * (size_t)(j0 + q);     // wave-uniform: scalar loads
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = fma(a[q], v[t], acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s_part[wave][lane][t] = acc[t];
+    __syncthreads();
+    if (wave == 0 && i < M) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            Y[4 * (size_t)i + t] = (s_part[0][lane][t] + s_part[1][lane][t]) + (s_part[2][lane][t] + s_part[3][lane][t]);
+    }
+}
+
+// ---- W = Y Tm - (1/2) V G,  G = Tm^T (V^T Y) Tm ---------------------------------------------
+__global__ __launch_bounds__(256) void k_ns_w(const BatchSlot *tab, int M)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *V = as_global(s.ns), *small = V + (size_t)12 * M;
+    gdouble *Y = as_global(s.ns) + (size_t)4 * M;          // becomes W
+    __shared__ double s_red[4 * 16];
+    const int tid = threadIdx.x;
+    double S[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) S[q] = 0.0;
+    for (int i = tid; i < M; i += 256) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) S[4 * a + b] = fma(V[4 * (size_t)i + a], Y[4 * (size_t)i + b], S[4 * a + b]);
+    }
+    block_sum_n<16>(S, s_red, tid);
+    double Tm[16], G[16], ST[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Tm[q] = small[kTm + q];
+    // V^T K V is symmetric in exact arithmetic: use the mean of the two roundings so that G is
+    // exactly symmetric and B = K - V W^T - W V^T stays a symmetric update
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {       // ST = Ssym Tm
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = fma(0.5 * (S[4 * a + c] + S[4 * c + a]), Tm[4 * c + b], v);
+            ST[4 * a + b] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {       // G = Tm^T ST
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = fma(Tm[4 * c + a], ST[4 * c + b], v);
+            G[4 * a + b] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) { const double m = 0.5 * (G[4 * a + b] + G[4 * b + a]); G[4 * a + b] = m; G[4 * b + a] = m; }
+    __syncthreads();
+    for (int i = tid; i < M; i += 256) {
+        double y[4], v[4], w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { y[t] = Y[4 * (size_t)i + t]; v[t] = V[4 * (size_t)i + t]; }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double z = 0.0, h = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { z = fma(y[a], Tm[4 * a + b], z); h = fma(v[a], G[4 * a + b], h); }
+            w[b] = fma(-0.5, h, z);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Y[4 * (size_t)i + t] = w[t];
+    }
+}
+
+// ---- B = K - V W^T - W V^T, lower triangle of the leading n1 x n1 block in place ----------------
+// Rows n1 .. M-1 (pivot row M-1-k = equation of polynomial coefficient k) go to B21 and read as
+// padding afterwards; columns n1 .. npc-1 become identity padding.
+__global__ __launch_bounds__(256) void k_ns_rotate(const BatchSlot *tab, int M, int T, int npc, int lda)
+{
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (ti < tj) return;
+    const BatchSlot &s = tab[blockIdx.z];
+    gdouble *A = as_global(s.A);
+    gcdouble *V = as_global(s.ns), *W = V + (size_t)4 * M;
+    gdouble *B21 = as_global(s.ns) + (size_t)8 * M;
+    const int n1 = M - T;
+    const int i = ti * 32 + (threadIdx.x & 31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = tj * 32 + (threadIdx.x >> 5) + 8 * q;
+        if (j >= npc || i < j) continue;
+        if (j >= n1) {
+            if (i < npc) A[(size_t)j * lda + i] = i == j ? 1.0 : 0.0;
+            continue;
+        }
+        if (i >= M) continue;                 // zero padding rows, written by the assembly
+        double b = A[(size_t)j * lda + i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            b = fma(-V[4 * (size_t)i + t], W[4 * (size_t)j + t], b);
+            b = fma(-W[4 * (size_t)i + t], V[4 * (size_t)j + t], b);
+        }
+        if (i < n1) {
+            A[(size_t)j * lda + i] = b;
+        } else {
+            B21[4 * (size_t)j + (M - 1 - i)] = b;
+            if (i < npc) A[(size_t)j * lda + i] = 0.0;
+        }
+    }
+}
+
+// ---- Cholesky: diagonal block --------------------------------------------------------------------
+// sqrt(d) and 1/sqrt(d) together: hardware estimate + two coupled Newton steps (Goldschmidt)
+__device__ __forceinline__ void sqrt_rsqrt(double d, double &root, double &inv)
+{
+    const double y0 = __builtin_amdgcn_rsq(d);
+    double g = d * y0, h = 0.5 * y0;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-g, g, d);                        // one correction of the root itself
+    root = fma(r, h, g);
+    inv = 2.0 * h;
+}
+
+constexpr int kLdsRow = kNB + 2;          // even: rows stay 16-byte aligned for ds_read_b128
+
+// The 32 x 32 block at (kb, kb): optionally its share of the trailing update of step kprev first
+// (C -= Lr Lr^T with Lr = rows kb .. kb+31 of that step's panel), then the factorisation by wave 0
+// -- row i in lane i, columns right-looking, multipliers broadcast with v_readlane -- then L11 to
+// the side store (what the triangular solves read), into A below the diagonal, and mirrored above
+// it as the U = L^T the back-substitution kernels read.  256 threads, all of them must call.
+__device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda, int n1, int kb, int kprev,
+                                             double (*sC)[kLdsRow], double (*sR)[kLdsRow], double *sInv)
+{
+    gdouble *A = as_global(s.A);
+    DevModel FD_GLOBAL *model = as_global(s.model);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < kNB * kNB; e += 256) {
+        const int r = e & 31, c = e >> 5;
+        sC[r][c] = A[(size_t)(kb + c) * lda + kb + r];
+        if (kprev >= 0) sR[r][c] = A[(size_t)(kprev + c) * lda + kb + r];
+    }
+    __syncthreads();
+    if (kprev >= 0) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            const int r = e & 31, c = e >> 5;
+            double acc = sC[r][c];
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) acc = fma(-sR[r][k], sR[c][k], acc);
+            v[q] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            sC[e & 31][e >> 5] = v[q];
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        const int i = tid & 31;
+        double a[kNB];
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) a[c] = sC[i][c];
+        const double amax = __longlong_as_double((long long)model->amax_bits);
+        const double tiny = (double)n1 * kEps * amax;
+        double pmin = INFINITY, pmax = 0.0, myinv = 0.0;
+        bool singular = false;
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) {
+            const double d = readlane_f64(a[j], j);
+            const bool ok = d > tiny;            // false for NaN and for a lost definiteness
+            if (kb + j < n1) {
+                if (!ok) singular = true;
+                const double ad = fabs(d);
+                pmin = ad < pmin ? ad : pmin;
+                pmax = ad > pmax ? ad : pmax;
+            }
+            double root, inv;
+            sqrt_rsqrt(ok ? d : 1.0, root, inv);
+            if (!ok) inv = 0.0;
+            a[j] = i == j ? root : a[j] * inv;
+            if (i == j) myinv = inv;
+#pragma unroll
+            for (int k = j + 1; k < kNB; ++k) {
+                const double lkj = readlane_f64(a[j], k);
+                a[k] = fma(-a[j], lkj, a[k]);
+            }
+        }
+        if (tid < 32) {
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) sC[i][c] = a[c];
+            sInv[i] = myinv;
+        }
+        if (tid == 0) {
+            model->iterations = kb + kNB < n1 ? kb + kNB : n1;
+            if (singular) model->sing_flag = 1;
+            if (pmax > 0.0 || pmin < INFINITY) {
+                atomicMin((unsigned long long *)&model->pivmin_bits, (unsigned long long)__double_as_longlong(pmin));
+                atomicMax((unsigned long long *)&model->pivmax_bits, (unsigned long long)__double_as_longlong(pmax));
+            }
+        }
+    }
+    __syncthreads();
+    gdouble *Ld = ld_block(s.ns, M, kb);
+    for (int e = tid; e < kNB * kNB; e += 256) {
+        const int r = e & 31, c = e >> 5;
+        const double l = r >= c ? sC[r][c] : sC[c][r];
+        Ld[e] = r >= c ? l : 0.0;
+        A[(size_t)(kb + c) * lda + kb + r] = l;
+    }
+    if (tid < kNB) Ld[kNB * kNB + tid] = sInv[tid];
+}
+
+// the first diagonal block has no trailing update before it
+__global__ __launch_bounds__(256) void k_chol_first(const BatchSlot *tab, int M, int lda, int n1)
+{
+    __shared__ __attribute__((aligned(16))) double sC[kNB][kLdsRow];
+    __shared__ double sInv[kNB];
+    __builtin_amdgcn_s_setprio(3);
+    factor_block(tab[blockIdx.z], M, lda, n1, 0, -1, sC, sC, sInv);
+}
+
+// ---- Cholesky: rows below the diagonal block ---------------------------------------------------
+// X L11^T = A21, one row per thread, L11 and the reciprocals of its diagonal from the side store.
+// Workgroups 0 .. nslab-1 take 256 matrix rows each (and mirror their result into the upper
+// triangle); workgroup nslab takes the three right-hand-side rows, which live transposed in the
+// RHS columns of A.  fd_set_deltas launches that last workgroup alone.
+__global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M, int lda, int npad, int npc, int k0, int nslab)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gdouble *A = as_global(s.A);
+    __shared__ __attribute__((aligned(16))) double sL[kNB][kLdsRow];
+    __shared__ double sInv[kNB];
+    const int tid = threadIdx.x;
+    const bool rhs = (int)blockIdx.x == nslab;
+    __builtin_amdgcn_s_setprio(3);
+
+    // column k of L11 contiguous (the side store is column-major already): the update of step k
+    // reads it in one burst of 16-byte LDS loads
+    gcdouble *Ld = ld_block(s.ns, M, k0);
+    for (int e = tid; e < kNB * kNB; e += 256) sL[e >> 5][e & 31] = Ld[e];
+    if (tid < kNB) sInv[tid] = Ld[kNB * kNB + tid];
+    __syncthreads();
+
+    gdouble *rowp;
+    size_t cstride;
+    bool active;
+    int grow = 0;
+    if (!rhs) {
+        grow = k0 + kNB + (int)blockIdx.x * kSlab + tid;
+        active = grow < npc;
+        rowp = A + (size_t)k0 * lda + grow;
+        cstride = (size_t)lda;
+    } else {
+        active = tid < 3;
+        rowp = A + (size_t)(npad + tid) * lda + k0;
+        cstride = 1;
+    }
+    if (!active) return;
+    double x[kNB];
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) x[c] = rowp[(size_t)c * cstride];
+    // right-looking: x_k is final once columns 0 .. k-1 have been applied; its update of the
+    // columns to the right is 31-k independent fmas (a dot-product form would be one dependent
+    // chain per element, and there is one wave per SIMD to hide it)
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) {
+        x[k] *= sInv[k];
+        double lk[kNB];
+#pragma unroll
+        for (int c = (k + 1) & ~1; c < kNB; ++c) lk[c] = sL[k][c];
+#pragma unroll
+        for (int c = k + 1; c < kNB; ++c) x[c] = fma(-x[k], lk[c], x[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) rowp[(size_t)c * cstride] = x[c];
+    if (!rhs) {
+        gdouble *up = A + (size_t)grow * lda + k0;     // row k0+c of column grow: U[k0+c][grow] = L[grow][k0+c]
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) up[c] = x[c];
+    }
+}
+
+// ---- Cholesky: trailing update ---------------------------------------------------------------
+// A22 -= L21 L21^T on the 16 x 16 tiles at and below the diagonal, plus the right-hand-side tile
+// of every 16-column block (three live rows, stored transposed in the RHS columns), with
+// v_mfma_f64_16x16x4_f64.  Workgroup (cb, chunk) takes every (4 * nchunk)-th tile of column block
+// cb, two in flight per wave.  The LAST workgroup is different: it updates the next diagonal block
+// by itself and factorises it while the others are busy -- the only sequential part of the
+// factorisation runs beside the trailing update instead of after it.  (The tiles of that block
+// are skipped by everybody else.)  rhs_only (fd_set_deltas): the right-hand-side tiles alone.
+__global__ __launch_bounds__(256) void k_chol_trail(const BatchSlot *tab, int M, int lda, int npad, int npc, int n1, int k0,
+                                                    int nchunk, int rhs_only)
+{
+    const BatchSlot &slot = tab[blockIdx.z];
+    gdouble *A = as_global(slot.A);
+    const int tid = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
+    if (!rhs_only && blockIdx.x == gridDim.x - 1) {
+        __shared__ __attribute__((aligned(16))) double sC[kNB][kLdsRow];
+        __shared__ __attribute__((aligned(16))) double sR[kNB][kLdsRow];
+        __shared__ double sInv[kNB];
+        factor_block(slot, M, lda, n1, k0 + kNB, k0, sC, sR, sInv);
+        return;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int cb = (int)blockIdx.x / nchunk, chunk = (int)blockIdx.x % nchunk;
+    const int c0 = k0 + kNB + cb * 16;
+    constexpr int S = kNB / 4;
+
+    double u[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) u[s] = -A[(size_t)(k0 + g + 4 * s) * lda + c0 + c];
+
+    const int mtiles = (npc - c0) / 16;               // matrix tiles of this column block; index mtiles = RHS tile
+    // tiles of the next diagonal block belong to the factorising workgroup
+    const int skip = rhs_only ? mtiles : (cb == 0 ? 2 : (cb == 1 ? 1 : 0));
+    const int stride = 4 * nchunk;
+    for (int t0 = skip + chunk * 4 + wave; t0 <= mtiles; t0 += 2 * stride) {
+        const int t1 = t0 + stride;
+        const bool two = t1 <= mtiles;
+        gdouble *cp[2];
+        size_t rs[2];
+        double av[2][S];
+        double4_t acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = q == 0 ? t0 : (two ? t1 : t0);
+            if (t < mtiles) {
+                const int r0 = c0 + t * 16;
+                cp[q] = A + (size_t)(c0 + c) * lda + r0 + g;
+                rs[q] = 4;
+                gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
+#pragma unroll
+                for (int s = 0; s < S; ++s) av[q][s] = aptr[(size_t)(4 * s) * lda];
+            } else {
+                cp[q] = A + (size_t)(npad + g) * lda + c0 + c;
+                rs[q] = (size_t)4 * lda;
+                gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
+#pragma unroll
+                for (int s = 0; s < S; ++s) av[q][s] = aptr[4 * s];
+            }
+            acc[q][0] = cp[q][0]; acc[q][1] = cp[q][rs[q]]; acc[q][2] = cp[q][2 * rs[q]]; acc[q][3] = cp[q][3 * rs[q]];
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][s], u[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][s], u[s], acc[1], 0, 0, 0);
+        }
+        cp[0][0] = acc[0][0]; cp[0][rs[0]] = acc[0][1]; cp[0][2 * rs[0]] = acc[0][2]; cp[0][3 * rs[0]] = acc[0][3];
+        if (two) { cp[1][0] = acc[1][0]; cp[1][rs[1]] = acc[1][1]; cp[1][2 * rs[1]] = acc[1][2]; cp[1][3 * rs[1]] = acc[1][3]; }
+    }
+}
+
+// ---- recover a and w ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ns_recover(const BatchSlot *tab, int M, int T, int npad)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *V = as_global(s.ns), *B21 = V + (size_t)8 * M, *small = V + (size_t)12 * M;
+    gdouble *X = as_global(s.X);
+    __shared__ double s_red[4 * 12];
+    const int tid = threadIdx.x;
+    const int n1 = M - T;
+
+    // (B21 y)[k][c]
+    double q[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) q[e] = 0.0;
+    for (int j = tid; j < n1; j += 256) {
+        const double y0 = X[j], y1 = X[(size_t)npad + j], y2 = X[2 * (size_t)npad + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double b = B21[4 * (size_t)j + k];
+            q[3 * k] = fma(b, y0, q[3 * k]); q[3 * k + 1] = fma(b, y1, q[3 * k + 1]); q[3 * k + 2] = fma(b, y2, q[3 * k + 2]);
+        }
+    }
+    block_sum_n<12>(q, s_red, tid);
+    // R a = g - B21 y, row k of R sits in pivot row M-1-k and is upper triangular in (k, c)
+    double a[4][3];
+    for (int k = T - 1; k >= 0; --k)
+        for (int c = 0; c < 3; ++c) {
+            double v = small[kG + 3 * k + c] - q[3 * k + c];
+            for (int cc = k + 1; cc < T; ++cc) v = fma(-small[kR + 4 * k + cc], a[cc][c], v);
+            a[k][c] = v / small[kR + 4 * k + k];
+        }
+    // w = Q [y; 0] = H_0 .. H_{T-1} [y; 0]
+    for (int i = n1 + tid; i < npad; i += 256) { X[i] = 0.0; X[(size_t)npad + i] = 0.0; X[2 * (size_t)npad + i] = 0.0; }
+    __syncthreads();
+    for (int k = T - 1; k >= 0; --k) {
+        const int piv = M - 1 - k;
+        const double tau = small[kTau + k];
+        double d[3] = {0.0, 0.0, 0.0};
+        for (int i = tid; i <= piv; i += 256) {
+            const double v = V[4 * (size_t)i + k];
+            d[0] = fma(v, X[i], d[0]); d[1] = fma(v, X[(size_t)npad + i], d[1]); d[2] = fma(v, X[2 * (size_t)npad + i], d[2]);
+        }
+        block_sum_n<3>(d, s_red, tid);
+        for (int i = tid; i <= piv; i += 256) {
+            const double v = V[4 * (size_t)i + k];
+            X[i] = fma(-tau * d[0], v, X[i]);
+            X[(size_t)npad + i] = fma(-tau * d[1], v, X[(size_t)npad + i]);
+            X[2 * (size_t)npad + i] = fma(-tau * d[2], v, X[2 * (size_t)npad + i]);
+        }
+        __syncthreads();
+    }
+    if (tid < 3 * T) {
+        const int k = tid / 3, c = tid % 3;
+        X[(size_t)c * npad + M + k] = a[k][c];
+    }
+    // the report counts eliminated unknowns: n1 by the Cholesky, T constraints by the reflectors,
+    // T coefficients through R
+    if (tid == 0 && s.model->iterations >= n1) s.model->iterations = M + T;
+}
+
+// the factorisation loop; with rhs_only the matrix is left alone and only the right-hand-side rows
+// travel through the stored factor
+void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, int rhs_only)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    if (!rhs_only) hipLaunchKernelGGL(k_chol_first, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, n1);
+    for (int k0 = 0; k0 < npc; k0 += kNB) {
+        const int below = npc - k0 - kNB;
+        const int nslab = rhs_only ? 0 : (below + kSlab - 1) / kSlab;
+        hipLaunchKernelGGL(k_chol_solve, dim3(nslab + 1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
+                           k0, nslab);
+        if (below > 0) {
+            const int ncb = below / 16;
+            // enough workgroups to cover the device while the trailing matrix is large
+            int nchunk = rhs_only ? 1 : (ncb + 15) / 16;
+            nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
+            hipLaunchKernelGGL(k_chol_trail, dim3(ncb * nchunk + (rhs_only ? 0 : 1), 1, nb), dim3(256), 0, stream, b.d_slots,
+                               b.M, b.lda, b.npad, npc, n1, k0, nchunk, rhs_only);
+        }
+    }
+}
+
+}  // namespace
+
+bool spd_applicable(int kind, int term, double lambda, int M)
+{
+    if (M < 16 || !(lambda >= 0.0)) return false;
+    switch (kind) {
+    case FD_KERNEL_GAUSSIAN: return true;                                   // positive definite by itself
+    case FD_KERNEL_THIN_PLATE: return term == FD_TERM_LINEAR;               // conditionally p.d. of order 2
+    case FD_KERNEL_CUBIC: return term == FD_TERM_LINEAR;                    // order 2
+    case FD_KERNEL_BIHARMONIC: return term != FD_TERM_ZERO;                 // -r: order 1
+    default: return false;                                                  // QNN radii: Phi is not symmetric
+    }
+}
+
+// everything after k_prepare
+hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    const int M = b.M, T = b.T;
+    const int n1 = M - T, npc = round_up(n1, kNB), npa = round_up(M, 32);
+    if (T > 0) {
+        hipLaunchKernelGGL(k_ns_reflectors, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T);
+        hipLaunchKernelGGL(k_ns_rhs, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
+    }
+    hipError_t e = launch_assemble_block(b, stream, npa);
+    if (e != hipSuccess) return e;
+    if (T > 0) {
+        hipLaunchKernelGGL(k_ns_kv, dim3((M + 63) / 64, 1, nb), dim3(256), 0, stream, b.d_slots, M, b.lda);
+        hipLaunchKernelGGL(k_ns_w, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M);
+        const unsigned g = (unsigned)((npc > M ? npc : M) + 31) / 32;
+        hipLaunchKernelGGL(k_ns_rotate, dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, T, npc, b.lda);
+    }
+    if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+    launch_factor(b, stream, npc, n1, 0);
+    e = launch_backsub_rows(b, stream, npc);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ns_recover, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad);
+    return launch_pack(b, stream);
+}
+
+// fd_set_deltas: new right-hand sides through the stored reflectors and Cholesky factor
+hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    const int M = b.M, T = b.T;
+    const int n1 = M - T, npc = round_up(n1, kNB);
+    hipError_t e = launch_prepare_rhs(b, stream, src);
+    if (e != hipSuccess) return e;
+    if (T > 0) hipLaunchKernelGGL(k_ns_rhs, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
+    launch_factor(b, stream, npc, n1, 1);
+    e = launch_backsub_rows(b, stream, npc);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ns_recover, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad);
+    return launch_pack(b, stream);
+}
+
+}  // namespace fd

@@ -67,6 +67,16 @@ enum { FD_TERM_LINEAR = 0, FD_TERM_CONST = 1, FD_TERM_ZERO = 2 };
  * weights).  The solve is always fp64. */
 enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
 
+/* Direct solver of the dense system.  AUTO: where the kernel is conditionally positive definite
+ * of the order its polynomial term covers (thin-plate and cubic with the linear term, biharmonic
+ * with a constant or linear term, the fixed-radius Gaussian with any term; lambda >= 0, M >= 16)
+ * the polynomial constraints are eliminated with Householder reflectors and the projected kernel
+ * block is Cholesky-factorised -- no pivot search; everything else (QNN radii make Phi
+ * non-symmetric) goes through LU with partial pivoting.  LU forces the latter everywhere.  Both
+ * are fp64 direct solves of the same system: their weights agree to rounding (~1e-12 relative
+ * on the benchmark rigs), far inside the parity tolerance. */
+enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1 };
+
 typedef struct fd_ctx fd_ctx;
 
 typedef struct fd_config {
@@ -74,13 +84,14 @@ typedef struct fd_config {
     int device;          /* HIP device ordinal; -1 = the calling thread's current */
     int eval_precision;  /* FD_EVAL_*                                            */
     int eval_variant;    /* 0 = auto; otherwise a kernel variant id (tuning/tests) */
-    int reserved[4];
+    int solver;          /* FD_SOLVER_*                                           */
+    int reserved[3];
 } fd_config;
 
 /* Replaces alglib::rbfreport as read at src/SOP_FaceDeform.cpp:365-373. */
 typedef struct fd_report {
     int terminationtype; /* 1 ok; -5 coincident centres; -4 solver failure       */
-    int iterationscount; /* elimination steps taken by the direct solver         */
+    int iterationscount; /* unknowns eliminated by the direct solver (n when done) */
     int n;               /* order of the solved system (M + term columns)        */
     int reserved;
     double pivot_ratio;  /* min|pivot| / max|pivot| of the LU (cheap rcond proxy) */

@@ -1,0 +1,166 @@
+"""GPU: the two direct solvers of the dense system (include/facedeform_hip.h FD_SOLVER_*).
+
+AUTO sends the conditionally positive definite (kernel, term) pairs through the null-space
+Cholesky (facedeform_amd/csrc/fd_nullspace.hip) and everything else through the pivoted LU
+(fd_build.hip); LU forces the latter.  Both solve the system of reference
+src/SOP_FaceDeform.cpp:331-368 in north_star's dense form, so their weights must agree with each
+other and with the fp64 oracle to rounding, and every behaviour at the boundary (termination
+types, reports, fd_set_deltas, batches) must be the same whichever one ran."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import parity_ratio
+from facedeform_amd import capi, synth
+from oracle import fd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+SPD_CASES = [
+    (capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR),
+    (capi.KERNEL_THIN_PLATE, [1e-3], capi.TERM_LINEAR),         # smoothing on the diagonal
+    (capi.KERNEL_CUBIC, [], capi.TERM_LINEAR),
+    (capi.KERNEL_BIHARMONIC, [], capi.TERM_LINEAR),
+    (capi.KERNEL_BIHARMONIC, [], capi.TERM_CONST),
+    (capi.KERNEL_GAUSSIAN, [0.35], capi.TERM_LINEAR),
+    (capi.KERNEL_GAUSSIAN, [0.35], capi.TERM_CONST),
+    (capi.KERNEL_GAUSSIAN, [0.35, 1e-2], capi.TERM_ZERO),       # no projection at all: plain Cholesky
+]
+
+
+def _engine(kind, params, term, rest, delta, solver):
+    e = capi.Engine(solver=solver)
+    e.set_kernel(kind, params); e.set_term(term)
+    e.set_points(rest, delta)
+    return e
+
+
+@pytest.mark.parametrize("M", [16, 37, 256, 300, 700])
+@pytest.mark.parametrize("kind,params,term", SPD_CASES)
+def test_cholesky_and_lu_agree_with_each_other_and_the_oracle(hip_lib, oracle, M, kind, params, term):
+    """M = 16 is the smallest system AUTO projects; 37 and 300 leave ragged last blocks and pivot
+    rows that straddle the 32-row tiles; 700 takes the ranged back-substitution."""
+    rest = synth.control_points(M, "head")
+    deform = synth.deformed_rig(rest, 2)
+    delta = (deform - rest).astype(np.float32)
+    if kind == capi.KERNEL_GAUSSIAN and M > 300:
+        params = [0.12] + list(params[1:])     # a fixed radius of 0.35 over 700 centres is numerically singular
+    table = oracle.control_table(rest, deform)
+    rc, tt, W, radii = oracle.build(table, kind, params, term)
+    assert tt == 1
+    got = {}
+    for solver in (capi.SOLVER_AUTO, capi.SOLVER_LU):
+        e = _engine(kind, params, term, rest, delta, solver)
+        rep = e.build()
+        T = (4, 1, 0)[term]
+        assert rep.terminationtype == 1 and rep.n == M + T and rep.iterationscount == M + T
+        assert 0.0 < rep.pivot_ratio <= 1.0
+        got[solver], _ = e.get_weights()
+        e.close()
+    scale = np.abs(W).max()
+    # fp64 direct solves of one system: cond * eps apart (cond up to ~1e5 for these rigs)
+    assert np.abs(got[capi.SOLVER_AUTO] - got[capi.SOLVER_LU]).max() <= 2e-9 * scale
+    for solver, Wg in got.items():
+        assert np.abs(Wg - W).max() <= 2e-9 * scale, solver
+    if kind != capi.KERNEL_GAUSSIAN or term != capi.TERM_ZERO or M > 16:
+        assert not np.array_equal(got[capi.SOLVER_AUTO], got[capi.SOLVER_LU])   # two different eliminations really ran
+
+
+def test_pairs_outside_the_definite_family_take_lu_whatever_is_asked(hip_lib):
+    """QNN radii (non-symmetric Phi), thin-plate without the linear term, -r without any term,
+    negative smoothing, tiny rigs: AUTO must not project them -- identical bits to LU."""
+    rest = synth.control_points(200, "head")
+    delta = synth.smooth_deltas(rest, 1).astype(np.float32)
+    cases = [(capi.KERNEL_GAUSSIAN_QNN, [1.0, 5.0], capi.TERM_LINEAR, rest, delta),
+             (capi.KERNEL_THIN_PLATE, [], capi.TERM_CONST, rest, delta),
+             (capi.KERNEL_THIN_PLATE, [], capi.TERM_ZERO, rest, delta),
+             (capi.KERNEL_CUBIC, [], capi.TERM_CONST, rest, delta),
+             (capi.KERNEL_BIHARMONIC, [], capi.TERM_ZERO, rest, delta),
+             (capi.KERNEL_THIN_PLATE, [-1e-4], capi.TERM_LINEAR, rest, delta),
+             (capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest[:12], delta[:12])]
+    for kind, params, term, r, d in cases:
+        W = []
+        for solver in (capi.SOLVER_AUTO, capi.SOLVER_LU):
+            e = _engine(kind, params, term, r, d, solver)
+            assert e.build().terminationtype == 1
+            W.append(e.get_weights()[0])
+            e.close()
+        assert np.array_equal(W[0], W[1]), (kind, term)
+
+
+def test_failures_report_the_same_way(hip_lib):
+    """-5 for coincident centres, -4 for a polynomial block without full column rank (all centres
+    in one plane under the linear term) and for a poisoned matrix; never an exception or a hang."""
+    rest = synth.control_points(64, "head")
+    delta = synth.smooth_deltas(rest, 0).astype(np.float32)
+    for solver in (capi.SOLVER_AUTO, capi.SOLVER_LU):
+        dup = rest.copy(); dup[9] = dup[40]
+        e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, dup, delta, solver)
+        assert e.build(check=False).terminationtype == -5
+        flat = rest.copy(); flat[:, 2] = 0.25
+        e.set_points(flat, delta)
+        assert e.build(check=False).terminationtype == -4
+        nan = rest.copy(); nan[3, 1] = np.nan
+        e.set_points(nan, delta)
+        assert e.build(check=False).terminationtype in (-4, -5)
+        e.set_points(rest, delta)
+        assert e.build().terminationtype == 1                      # and the context recovers
+        e.close()
+
+
+@pytest.mark.parametrize("M", [256, 2048])
+def test_displacements_of_both_solvers_pass_parity(hip_lib, oracle, M):
+    """End to end at the benchmark rig sizes: build with either solver, evaluate in fp32, compare
+    with the oracle at 1e-5 relative per-vertex displacement."""
+    rest = synth.control_points(M, "head")
+    deform = synth.deformed_rig(rest, 1)
+    P = synth.head_mesh(1_000_000)[::250]
+    table = oracle.control_table(rest, deform)
+    rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], fo.TERM_LINEAR)
+    ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    for solver in (capi.SOLVER_AUTO, capi.SOLVER_LU):
+        e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, rest, (deform - rest).astype(np.float32), solver)
+        assert e.build().terminationtype == 1
+        out, _ = e.deform(P)
+        assert parity_ratio(out, ref, P, 1e-5) <= 1.0, solver
+        e.close()
+
+
+def test_resolve_and_batches_on_the_cholesky_path(hip_lib):
+    """fd_set_deltas above the LU fast path's order limit (the Cholesky factor has none), and a
+    batch of contexts against single builds: bit-identical, as on the LU path."""
+    M = 2500
+    rest = synth.control_points(M, "head")
+    d = [synth.smooth_deltas(rest, f).astype(np.float32) for f in range(2)]
+    fast, full = capi.Engine(), capi.Engine()
+    for e in (fast, full):
+        e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
+    fast.set_points(rest, d[0]); fast.build()
+    fast.set_deltas(d[1])
+    assert fast.build().terminationtype == 1
+    full.set_points(rest, d[1]); full.build()
+    assert np.array_equal(fast.get_weights()[0], full.get_weights()[0])
+    fast.close(); full.close()
+
+    M = 700
+    rest = synth.control_points(M, "head")
+    dev = torch.device("cuda:0")
+    d_rest = torch.from_numpy(rest).to(dev)
+    es = [capi.Engine() for _ in range(5)]
+    d_del = []
+    for f, e in enumerate(es):
+        e.set_kernel(capi.KERNEL_CUBIC); e.set_term(capi.TERM_LINEAR)
+        d_del.append(torch.from_numpy(synth.smooth_deltas(rest, f).astype(np.float32)).to(dev))
+    b = capi.Batch(es)
+    b.set_points_dev([d_rest.data_ptr()] * 5, [t.data_ptr() for t in d_del], M)
+    b.build_async(); reps = b.build_result()
+    assert all(r.terminationtype == 1 for r in reps)
+    for f, e in enumerate(es):
+        single = capi.Engine()
+        single.set_kernel(capi.KERNEL_CUBIC); single.set_term(capi.TERM_LINEAR)
+        single.set_points(rest, synth.smooth_deltas(rest, f).astype(np.float32)); single.build()
+        assert np.array_equal(single.get_weights()[0], e.get_weights()[0]), f
+        single.close()
+    b.close()
+    for e in es:
+        e.close()
