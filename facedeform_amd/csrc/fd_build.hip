@@ -1092,6 +1092,14 @@ static void launch_backsub(const BuildBuffers &b, hipStream_t stream, int rows)
     }
 }
 
+// push the solved rows [row_lo, row_lo + w) into the right-hand sides of the rows above them
+hipError_t launch_backsub_update(const BuildBuffers &b, hipStream_t stream, int row_lo, int w)
+{
+    hipLaunchKernelGGL(k_backsub_update, dim3((row_lo + 255) / 256, 1, (unsigned)b.nbatch), dim3(256), 0, stream, b.d_slots,
+                       b.lda, b.npad, row_lo, w);
+    return hipGetLastError();
+}
+
 hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int rows)
 {
     launch_backsub(b, stream, rows);

@@ -157,11 +157,12 @@ hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream);
 hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a);
 hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int rows);
 hipError_t launch_prepare_rhs(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
+hipError_t launch_backsub_update(const BuildBuffers &b, hipStream_t stream, int row_lo, int w);
 
 // ---- null-space Cholesky build (fd_nullspace.hip) -----------------------------------
 // Which (kernel, term, lambda) make the projected block positive definite; M large enough to project.
 bool spd_applicable(int kind, int term, double lambda, int M);
-static inline size_t ns_doubles(int M) { return (size_t)12 * (size_t)M + 64 + (size_t)(M / 32 + 2) * 34 * 32; }
+static inline size_t ns_doubles(int M) { return (size_t)12 * (size_t)M + 64 + (size_t)(M / 32 + 2) * 66 * 32; }
 hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
 hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 

@@ -31,7 +31,9 @@
 //                     others -- the sequential part is off the critical path.
 //                     The right-hand sides ride along as three extra rows, so the forward solve
 //                     costs nothing; L^T is mirrored into the upper triangle as it is produced,
-//   k_backsub_*       (fd_build.hip) so the LU back-substitution kernels solve L^T y = z as is
+//   k_backsub_inv     L^T y = z with the inverted diagonal blocks (a by-product of k_chol_solve's
+//                     otherwise idle right-hand-side workgroup); k_backsub_update (fd_build.hip)
+//                     chains 256-row ranges above order 512
 //   k_ns_recover      a from R, w = Q [y; 0], into X in the layout k_pack expects.
 //
 // fd_set_deltas (launch_resolve_spd) sends new right-hand sides through the same kernels with the
@@ -56,8 +58,10 @@ constexpr int kG = 36;                  // (Q^T f) in the pivot rows: g[k][c]
 constexpr int kSmall = 64;
 // after the small block: the factorised diagonal blocks, one per 32 columns -- L11 column-major
 // (32 x 32, zeros above the diagonal) followed by the reciprocals of its diagonal: what the
-// triangular solves stage into LDS, in the full build and in fd_set_deltas alike.
-constexpr int kLdStride = 34 * 32;
+// triangular solves stage into LDS, in the full build and in fd_set_deltas alike; then the
+// inverse of L11, which turns the back-substitution's 32-step triangle into a matrix product.
+constexpr int kLdStride = 66 * 32;
+constexpr int kLdInv = 34 * 32;         // offset of inverse(L11), row-major [k][j], inside a block
 __device__ __forceinline__ gdouble *ld_block(double *ns, int M, int k0) { return as_global(ns) + (size_t)12 * M + kSmall + (size_t)(k0 / kNB) * kLdStride; }
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane)
@@ -210,31 +214,42 @@ __global__ __launch_bounds__(256) void k_ns_rhs(const BatchSlot *tab, int M, int
 
 // ---- Y = K V ---------------------------------------------------------------------------
 // 64 rows per workgroup, one row per lane (consecutive lanes walk a column of A: coalesced); the
-// four waves split the columns and their partial sums are added in a fixed order
+// four waves split the columns, each with its slice of V in LDS, and their partial sums are added
+// in a fixed order
 __global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int lda)
 {
     const BatchSlot &s = tab[blockIdx.z];
     gcdouble *A = as_global(s.A), *V = as_global(s.ns);
     gdouble *Y = as_global(s.ns) + (size_t)4 * M;
+    __shared__ __attribute__((aligned(16))) double s_v[4][64][4];
     __shared__ double s_part[4][64][4];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     const int ic = i < M ? i : M - 1;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const int per = ((M + 3) / 4 + 7) & ~7;            // columns per wave, a multiple of the unroll
+    const int per = ((M + 3) / 4 + 63) & ~63;          // columns per wave, a multiple of the LDS slice
     const int jlo = wave * per, jhi = jlo + per < M ? jlo + per : M;
-    for (int j0 = jlo; j0 < jhi; j0 += 8) {
-        double a[8];
+    for (int j0 = jlo; j0 < jhi; j0 += 64) {
+        {
+            const int j = j0 + lane;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const int j = j0 + q < M ? j0 + q : M - 1; a[q] = A[(size_t)j * lda + ic]; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (j0 + q < jhi) {
-                gcdouble *v = V + 4 * (size_t)(j0 + q);     // wave-uniform: scalar loads
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = fma(a[q], v[t], acc[t]);
-            }
+            for (int t = 0; t < 4; ++t) s_v[wave][lane][t] = j < jhi ? V[4 * (size_t)j + t] : 0.0;   // my wave's slice only
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+        for (int q0 = 0; q0 < 64; q0 += 8) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int j = j0 + q0 + q < M ? j0 + q0 + q : M - 1; a[q] = A[(size_t)j * lda + ic]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = fma(a[q], s_v[wave][q0 + q][t], acc[t]);     // zero beyond jhi
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) s_part[wave][lane][t] = acc[t];
@@ -364,7 +379,7 @@ constexpr int kLdsRow = kNB + 2;          // even: rows stay 16-byte aligned for
 
 // The 32 x 32 block at (kb, kb): optionally its share of the trailing update of step kprev first
 // (C -= Lr Lr^T with Lr = rows kb .. kb+31 of that step's panel), then the factorisation by wave 0
-// -- row i in lane i, columns right-looking, multipliers broadcast with v_readlane -- then L11 to
+// -- rows in registers, columns right-looking, multipliers broadcast through LDS -- then L11 to
 // the side store (what the triangular solves read), into A below the diagonal, and mirrored above
 // it as the U = L^T the back-substitution kernels read.  256 threads, all of them must call.
 __device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda, int n1, int kb, int kprev,
@@ -372,6 +387,7 @@ __device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda,
 {
     gdouble *A = as_global(s.A);
     DevModel FD_GLOBAL *model = as_global(s.model);
+    __shared__ __attribute__((aligned(16))) double sCol[kNB];
     const int tid = threadIdx.x;
     for (int e = tid; e < kNB * kNB; e += 256) {
         const int r = e & 31, c = e >> 5;
@@ -399,17 +415,26 @@ __device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda,
         __syncthreads();
     }
     if (tid < 64) {
-        const int i = tid & 31;
-        double a[kNB];
+        // Row i of the block lives in lanes i and i + 32: the lower half keeps the even columns,
+        // the upper half the odd ones (16 doubles each).  Column j, once scaled, goes through a
+        // 32-double LDS line ordered by row parity, so each half fetches the multipliers of ITS
+        // columns with 16-byte broadcast reads; one v_readlane pair per column (the diagonal) is
+        // all that is left on the scalar path.  (Broadcasting every multiplier with v_readlane
+        // cost three instructions and a hazard stall per fma: 4000 instructions per block.)
+        const int i = tid & 31, h = tid >> 5;
+        double a[kNB / 2];
 #pragma unroll
-        for (int c = 0; c < kNB; ++c) a[c] = sC[i][c];
+        for (int kk = 0; kk < kNB / 2; ++kk) a[kk] = sC[i][2 * kk + h];
+        const double *colp = sCol + 16 * h;                   // L[2 kk + h][j] at colp[kk]
+        double *mine = sCol + 16 * (i & 1) + (i >> 1);        // L[i][j]
         const double amax = __longlong_as_double((long long)model->amax_bits);
         const double tiny = (double)n1 * kEps * amax;
         double pmin = INFINITY, pmax = 0.0, myinv = 0.0;
         bool singular = false;
 #pragma unroll
         for (int j = 0; j < kNB; ++j) {
-            const double d = readlane_f64(a[j], j);
+            const int hj = j & 1, jj = j >> 1;
+            const double d = readlane_f64(a[jj], j + 32 * hj);
             const bool ok = d > tiny;            // false for NaN and for a lost definiteness
             if (kb + j < n1) {
                 if (!ok) singular = true;
@@ -420,19 +445,28 @@ __device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda,
             double root, inv;
             sqrt_rsqrt(ok ? d : 1.0, root, inv);
             if (!ok) inv = 0.0;
-            a[j] = i == j ? root : a[j] * inv;
-            if (i == j) myinv = inv;
-#pragma unroll
-            for (int k = j + 1; k < kNB; ++k) {
-                const double lkj = readlane_f64(a[j], k);
-                a[k] = fma(-a[j], lkj, a[k]);
+            // lanes talk through the LDS line: to the compiler a store by one lane and a load by
+            // another are unrelated, so the order is pinned on both sides (no instructions: the
+            // wave executes its LDS operations in program order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (h == hj) {
+                const double l = i == j ? root : a[jj] * inv;
+                a[jj] = l;
+                *mine = l;
+                if (i == j) myinv = inv;
             }
-        }
-        if (tid < 32) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double lij = *mine;
+            if (hj == 0 && h == 1) a[jj] = fma(-lij, colp[jj], a[jj]);   // column j + 1 sits in the other half
 #pragma unroll
-            for (int c = 0; c < kNB; ++c) sC[i][c] = a[c];
-            sInv[i] = myinv;
+            for (int kk = jj + 1; kk < kNB / 2; ++kk) a[kk] = fma(-lij, colp[kk], a[kk]);
         }
+#pragma unroll
+        for (int kk = 0; kk < kNB / 2; ++kk) sC[i][2 * kk + h] = a[kk];
+        if (h == (i & 1)) sInv[i] = myinv;
         if (tid == 0) {
             model->iterations = kb + kNB < n1 ? kb + kNB : n1;
             if (singular) model->sing_flag = 1;
@@ -467,7 +501,8 @@ __global__ __launch_bounds__(256) void k_chol_first(const BatchSlot *tab, int M,
 // Workgroups 0 .. nslab-1 take 256 matrix rows each (and mirror their result into the upper
 // triangle); workgroup nslab takes the three right-hand-side rows, which live transposed in the
 // RHS columns of A.  fd_set_deltas launches that last workgroup alone.
-__global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M, int lda, int npad, int npc, int k0, int nslab)
+__global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M, int lda, int npad, int npc, int k0, int nslab,
+                                                    int with_inverse)
 {
     const BatchSlot &s = tab[blockIdx.z];
     gdouble *A = as_global(s.A);
@@ -477,31 +512,39 @@ __global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M,
     const bool rhs = (int)blockIdx.x == nslab;
     __builtin_amdgcn_s_setprio(3);
 
-    // column k of L11 contiguous (the side store is column-major already): the update of step k
-    // reads it in one burst of 16-byte LDS loads
-    gcdouble *Ld = ld_block(s.ns, M, k0);
-    for (int e = tid; e < kNB * kNB; e += 256) sL[e >> 5][e & 31] = Ld[e];
-    if (tid < kNB) sInv[tid] = Ld[kNB * kNB + tid];
-    __syncthreads();
-
+    // my row first: its loads fly while L11 is staged
+    gdouble *Ld = ld_block(s.ns, M, k0);
     gdouble *rowp;
     size_t cstride;
     bool active;
     int grow = 0;
+    const int unit = tid - 64;                          // RHS workgroup, second wave: row `unit` of the identity
     if (!rhs) {
         grow = k0 + kNB + (int)blockIdx.x * kSlab + tid;
         active = grow < npc;
-        rowp = A + (size_t)k0 * lda + grow;
+        rowp = A + (size_t)k0 * lda + (active ? grow : k0 + kNB);
         cstride = (size_t)lda;
     } else {
         active = tid < 3;
-        rowp = A + (size_t)(npad + tid) * lda + k0;
+        rowp = A + (size_t)(npad + (active ? tid : 0)) * lda + k0;
         cstride = 1;
     }
-    if (!active) return;
+    const bool invert = rhs && with_inverse && unit >= 0 && unit < kNB;
     double x[kNB];
 #pragma unroll
     for (int c = 0; c < kNB; ++c) x[c] = rowp[(size_t)c * cstride];
+    if (invert) {
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) x[c] = c == unit ? 1.0 : 0.0;
+    }
+
+    // column k of L11 contiguous (the side store is column-major already): the update of step k
+    // reads it in one burst of 16-byte LDS loads
+    for (int e = tid; e < kNB * kNB; e += 256) sL[e >> 5][e & 31] = Ld[e];
+    if (tid < kNB) sInv[tid] = Ld[kNB * kNB + tid];
+    __syncthreads();
+    if (!active && !invert) return;
+
     // right-looking: x_k is final once columns 0 .. k-1 have been applied; its update of the
     // columns to the right is 31-k independent fmas (a dot-product form would be one dependent
     // chain per element, and there is one wave per SIMD to hide it)
@@ -514,6 +557,13 @@ __global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M,
 #pragma unroll
         for (int c = k + 1; c < kNB; ++c) x[c] = fma(-x[k], lk[c], x[c]);
     }
+    if (invert) {
+        // e_j L11^-T = row j of L11^-T = column j of inverse(L11): stored as [k][j]
+        gdouble *inv = Ld + kLdInv;
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) inv[c * kNB + unit] = x[c];
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < kNB; ++c) rowp[(size_t)c * cstride] = x[c];
     if (!rhs) {
@@ -521,6 +571,80 @@ __global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M,
 #pragma unroll
         for (int c = 0; c < kNB; ++c) up[c] = x[c];
     }
+}
+
+// ---- back-substitution with the inverted diagonal blocks ----------------------------------------------
+// L^T y = z over the rows [row_lo, row_hi), bottom up, one workgroup: z of the range lives in LDS;
+// per 32-row block y_b = inverse(L_bb)^T z_b is 96 dot products instead of a 32-step dependent
+// chain, then the rows above in the range take the block's contribution (the mirrored U = L^T, one
+// row per thread, coalesced).  Ranges above 512 rows are chained with k_backsub_update as in the
+// LU path.  Same role and data layout as fd_build.hip's k_backsub_all.
+__global__ __launch_bounds__(256) void k_backsub_inv(const BatchSlot *tab, int M, int lda, int npad, int row_lo, int row_hi)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *A = as_global(s.A);
+    gdouble *X = as_global(s.X);
+    extern __shared__ __attribute__((aligned(16))) double s_y[];   // [3][w]
+    __shared__ double s_li[2][kNB][kNB + 1];
+    __shared__ double s_x[kNB][3];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int w = row_hi - row_lo;
+
+    for (int e = tid; e < 3 * w; e += 256) s_y[e] = A[(size_t)(npad + e / w) * lda + row_lo + e % w];
+    double nxt[4];
+    {
+        gcdouble *li = ld_block(s.ns, M, row_hi - kNB) + kLdInv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nxt[q] = li[tid + 256 * q];
+    }
+    int buf = 0;
+    for (int b0 = row_hi - kNB; b0 >= row_lo; b0 -= kNB, buf ^= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = tid + 256 * q; s_li[buf][e >> 5][e & 31] = nxt[q]; }
+        if (b0 - kNB >= row_lo) {
+            gcdouble *li = ld_block(s.ns, M, b0 - kNB) + kLdInv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nxt[q] = li[tid + 256 * q];
+        }
+        // my first row's segment of U for the update below (does not depend on y)
+        const int i0 = row_lo + tid;
+        double uik[kNB];
+        if (i0 < b0) {
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) uik[k] = A[(size_t)(b0 + k) * lda + i0];
+        }
+        __syncthreads();                 // the inverse block and the z rows of this block are in LDS
+        const int l0 = b0 - row_lo;
+        if (tid < 96) {
+            const int i = tid & 31, c = tid >> 5;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) acc = fma(s_li[buf][k][i], s_y[c * w + l0 + k], acc);   // zeros above the diagonal
+            s_x[i][c] = acc;
+        }
+        __syncthreads();
+        if (tid < 96) { const int i = tid & 31, c = tid >> 5; s_y[c * w + l0 + i] = s_x[i][c]; }
+        for (int i = i0; i < b0; i += 256) {
+            if (i != i0) {
+#pragma unroll
+                for (int k = 0; k < kNB; ++k) uik[k] = A[(size_t)(b0 + k) * lda + i];
+            }
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < kNB; ++k) {
+                a0 = fma(uik[k], s_x[k][0], a0);
+                a1 = fma(uik[k], s_x[k][1], a1);
+                a2 = fma(uik[k], s_x[k][2], a2);
+            }
+            const int li = i - row_lo;
+            s_y[li] -= a0; s_y[w + li] -= a1; s_y[2 * w + li] -= a2;
+        }
+        // the next iteration's first barrier orders these writes before its products; s_x is not
+        // rewritten before that barrier, and s_li alternates
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * w; e += 256) X[(size_t)(e / w) * npad + row_lo + e % w] = s_y[e];
 }
 
 // ---- Cholesky: trailing update ---------------------------------------------------------------
@@ -665,7 +789,7 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
         const int below = npc - k0 - kNB;
         const int nslab = rhs_only ? 0 : (below + kSlab - 1) / kSlab;
         hipLaunchKernelGGL(k_chol_solve, dim3(nslab + 1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
-                           k0, nslab);
+                           k0, nslab, rhs_only ? 0 : 1);
         if (below > 0) {
             const int ncb = below / 16;
             // enough workgroups to cover the device while the trailing matrix is large
@@ -675,6 +799,28 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
                                b.M, b.lda, b.npad, npc, n1, k0, nchunk, rhs_only);
         }
     }
+}
+
+// L^T y = z over rows [0, rows): one call up to 512 rows, 256-row ranges chained above that
+hipError_t launch_backsub_spd(const BuildBuffers &b, hipStream_t stream, int rows)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    if (rows <= 512) {
+        hipLaunchKernelGGL(k_backsub_inv, dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)rows, stream, b.d_slots,
+                           b.M, b.lda, b.npad, 0, rows);
+        return hipGetLastError();
+    }
+    constexpr int W = 256;
+    for (int hi = rows; hi > 0; hi -= W) {
+        const int lo = hi > W ? hi - W : 0;
+        hipLaunchKernelGGL(k_backsub_inv, dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)(hi - lo), stream,
+                           b.d_slots, b.M, b.lda, b.npad, lo, hi);
+        if (lo > 0) {
+            hipError_t e = launch_backsub_update(b, stream, lo, hi - lo);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipGetLastError();
 }
 
 }  // namespace
@@ -711,7 +857,7 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
     }
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     launch_factor(b, stream, npc, n1, 0);
-    e = launch_backsub_rows(b, stream, npc);
+    e = launch_backsub_spd(b, stream, npc);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ns_recover, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad);
     return launch_pack(b, stream);
@@ -727,7 +873,7 @@ hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const P
     if (e != hipSuccess) return e;
     if (T > 0) hipLaunchKernelGGL(k_ns_rhs, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
     launch_factor(b, stream, npc, n1, 1);
-    e = launch_backsub_rows(b, stream, npc);
+    e = launch_backsub_spd(b, stream, npc);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ns_recover, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad);
     return launch_pack(b, stream);
