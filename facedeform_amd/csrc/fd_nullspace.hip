@@ -431,10 +431,14 @@ __device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda,
         const double tiny = (double)n1 * kEps * amax;
         double pmin = INFINITY, pmax = 0.0, myinv = 0.0;
         bool singular = false;
+        // The diagonal of the NEXT column is formed ahead of the LDS round trip from two
+        // v_readlanes (its own old value and the multiplier l_{j+1,j}): the square-root chain of
+        // column j+1 then runs while column j's multipliers travel through LDS.  It is the same
+        // fma the owning lane performs on its register copy, so both hold the same bits.
+        double d = readlane_f64(a[0], 0);
 #pragma unroll
         for (int j = 0; j < kNB; ++j) {
             const int hj = j & 1, jj = j >> 1;
-            const double d = readlane_f64(a[jj], j + 32 * hj);
             const bool ok = d > tiny;            // false for NaN and for a lost definiteness
             if (kb + j < n1) {
                 if (!ok) singular = true;
@@ -459,6 +463,12 @@ __device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda,
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (j + 1 < kNB) {
+                const int hn = (j + 1) & 1, jn = (j + 1) >> 1;
+                const double lnext = readlane_f64(a[jj], j + 1 + 32 * hj);       // l_{j+1,j}
+                const double dold = readlane_f64(a[jn], j + 1 + 32 * hn);         // a_{j+1,j+1} before this column
+                d = fma(-lnext, lnext, dold);
+            }
             const double lij = *mine;
             if (hj == 0 && h == 1) a[jj] = fma(-lij, colp[jj], a[jj]);   // column j + 1 sits in the other half
 #pragma unroll
