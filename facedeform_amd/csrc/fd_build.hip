@@ -759,7 +759,8 @@ __device__ __forceinline__ double block_max(double v, double *scratch, int tid)
     return a > b ? a : b;
 }
 
-__global__ __launch_bounds__(256) void k_pack(const BatchSlot *tab, int npad, int M, int Mpad, int T, int kind,
+// one 128-VGPR slot: the kernel runs beside the evaluation of earlier frames (fd_nullspace.hip, FD_FIT_BESIDE_EVAL)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_pack(const BatchSlot *tab, int npad, int M, int Mpad, int T, int kind,
                                               int from_w)
 {
     const BatchSlot &slot = tab[blockIdx.z];

@@ -46,6 +46,13 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// The evaluation kernel runs four 128-VGPR waves per SIMD (fd_eval.hip) and, in a pipeline of
+// frames, fills the device while the next frames' builds run beside it.  A build wave that needs
+// more than 128 VGPRs only fits where TWO evaluation waves have retired from one SIMD at once,
+// and the dispatcher refills a single freed slot first -- such kernels were measured waiting
+// hundreds of microseconds under a running evaluation.  Keep them within one slot.
+#define FD_FIT_BESIDE_EVAL __attribute__((amdgpu_waves_per_eu(4, 8)))
+
 constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNB = 32;                 // Cholesky block width
 constexpr int kSlab = 256;              // rows per workgroup of the panel's triangular solve
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int 
 }
 
 // ---- W = Y Tm - (1/2) V G,  G = Tm^T (V^T Y) Tm ---------------------------------------------
-__global__ __launch_bounds__(256) void k_ns_w(const BatchSlot *tab, int M)
+__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_ns_w(const BatchSlot *tab, int M)
 {
     const BatchSlot &s = tab[blockIdx.z];
     gcdouble *V = as_global(s.ns), *small = V + (size_t)12 * M;
@@ -279,33 +286,27 @@ __global__ __launch_bounds__(256) void k_ns_w(const BatchSlot *tab, int M)
             for (int b = 0; b < 4; ++b) S[4 * a + b] = fma(V[4 * (size_t)i + a], Y[4 * (size_t)i + b], S[4 * a + b]);
     }
     block_sum_n<16>(S, s_red, tid);
-    double Tm[16], G[16], ST[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) Tm[q] = small[kTm + q];
-    // V^T K V is symmetric in exact arithmetic: use the mean of the two roundings so that G is
-    // exactly symmetric and B = K - V W^T - W V^T stays a symmetric update
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {       // ST = Ssym Tm
-            double v = 0.0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v = fma(0.5 * (S[4 * a + c] + S[4 * c + a]), Tm[4 * c + b], v);
-            ST[4 * a + b] = v;
-        }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {       // G = Tm^T ST
-            double v = 0.0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v = fma(Tm[4 * c + a], ST[4 * c + b], v);
-            G[4 * a + b] = v;
-        }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = a + 1; b < 4; ++b) { const double m = 0.5 * (G[4 * a + b] + G[4 * b + a]); G[4 * a + b] = m; G[4 * b + a] = m; }
+    __shared__ double s_Tm[16], s_G[16];
+    if (tid == 0) {
+        double Tm[16], ST[16];
+        for (int q = 0; q < 16; ++q) { Tm[q] = small[kTm + q]; s_Tm[q] = Tm[q]; }
+        // V^T K V is symmetric in exact arithmetic: use the mean of the two roundings so that G is
+        // exactly symmetric and B = K - V W^T - W V^T stays a symmetric update
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {       // ST = Ssym Tm
+                double v = 0.0;
+                for (int c = 0; c < 4; ++c) v = fma(0.5 * (S[4 * a + c] + S[4 * c + a]), Tm[4 * c + b], v);
+                ST[4 * a + b] = v;
+            }
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {       // G = Tm^T ST
+                double v = 0.0;
+                for (int c = 0; c < 4; ++c) v = fma(Tm[4 * c + a], ST[4 * c + b], v);
+                s_G[4 * a + b] = v;
+            }
+        for (int a = 0; a < 4; ++a)
+            for (int b = a + 1; b < 4; ++b) { const double m = 0.5 * (s_G[4 * a + b] + s_G[4 * b + a]); s_G[4 * a + b] = m; s_G[4 * b + a] = m; }
+    }
     __syncthreads();
     for (int i = tid; i < M; i += 256) {
         double y[4], v[4], w[4];
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_ns_w(const BatchSlot *tab, int M)
         for (int b = 0; b < 4; ++b) {
             double z = 0.0, h = 0.0;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) { z = fma(y[a], Tm[4 * a + b], z); h = fma(v[a], G[4 * a + b], h); }
+            for (int a = 0; a < 4; ++a) { z = fma(y[a], s_Tm[4 * a + b], z); h = fma(v[a], s_G[4 * a + b], h); }
             w[b] = fma(-0.5, h, z);
         }
 #pragma unroll
@@ -498,7 +499,7 @@ __device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda,
 }
 
 // the first diagonal block has no trailing update before it
-__global__ __launch_bounds__(256) void k_chol_first(const BatchSlot *tab, int M, int lda, int n1)
+__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_first(const BatchSlot *tab, int M, int lda, int n1)
 {
     __shared__ __attribute__((aligned(16))) double sC[kNB][kLdsRow];
     __shared__ double sInv[kNB];
@@ -511,8 +512,31 @@ __global__ __launch_bounds__(256) void k_chol_first(const BatchSlot *tab, int M,
 // Workgroups 0 .. nslab-1 take 256 matrix rows each (and mirror their result into the upper
 // triangle); workgroup nslab takes the three right-hand-side rows, which live transposed in the
 // RHS columns of A.  fd_set_deltas launches that last workgroup alone.
-__global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M, int lda, int npad, int npc, int k0, int nslab,
-                                                    int with_inverse)
+// x <- x L11^-T in registers.  Right-looking: x_k is final once columns 0 .. k-1 have been applied;
+// its update of the columns to the right is 31-k independent fmas (a dot-product form would be one
+// dependent chain per element, and there is one wave per SIMD to hide it).  sL[k][c] = L11[c][k].
+__device__ __forceinline__ void solve_row(double (&x)[kNB], const double (*sL)[kLdsRow], const double *sInv)
+{
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) {
+        x[k] *= sInv[k];
+        // eight multipliers per burst of 16-byte LDS reads: the whole column at once would not fit
+        // beside x[] in one 128-VGPR slot
+#pragma unroll
+        for (int c0 = (k + 1) & ~7; c0 < kNB; c0 += 8) {
+            double lk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) lk[q] = sL[k][c0 + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (c0 + q > k) x[c0 + q] = fma(-x[k], lk[q], x[c0 + q]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the bursts apart: hoisted together they spill x[]
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_solve(const BatchSlot *tab, int M, int lda, int npad, int npc, int k0, int nslab,
+                                                                       int with_inverse)
 {
     const BatchSlot &s = tab[blockIdx.z];
     gdouble *A = as_global(s.A);
@@ -521,52 +545,58 @@ __global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M,
     const int tid = threadIdx.x;
     const bool rhs = (int)blockIdx.x == nslab;
     __builtin_amdgcn_s_setprio(3);
-
-    // my row first: its loads fly while L11 is staged
     gdouble *Ld = ld_block(s.ns, M, k0);
-    gdouble *rowp;
-    size_t cstride;
-    bool active;
-    int grow = 0;
-    const int unit = tid - 64;                          // RHS workgroup, second wave: row `unit` of the identity
+
     if (!rhs) {
-        grow = k0 + kNB + (int)blockIdx.x * kSlab + tid;
-        active = grow < npc;
-        rowp = A + (size_t)k0 * lda + (active ? grow : k0 + kNB);
-        cstride = (size_t)lda;
-    } else {
-        active = tid < 3;
-        rowp = A + (size_t)(npad + (active ? tid : 0)) * lda + k0;
-        cstride = 1;
+        // 256 matrix rows: column c of the panel is a wave-uniform pointer, the row a 32-bit lane
+        // offset -- one address register for all 64 accesses.  The loads are issued before L11 is
+        // staged so that they fly meanwhile.
+        const int grow = k0 + kNB + (int)blockIdx.x * kSlab + tid;
+        const bool active = grow < npc;
+        const unsigned rowb = 8u * (unsigned)(active ? grow : k0 + kNB);      // BYTE offset: zext(u32) is what the saddr form takes
+        gdouble *col0 = A + (size_t)k0 * lda;
+        auto at = [&](int c) -> gdouble & {
+            // the column pointer pinned into SGPRs: left alone, the compiler folds it into 32
+            // per-lane 64-bit addresses and keeps them all alive for the stores
+            const unsigned long long p = (unsigned long long)(col0 + (size_t)c * lda);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+            return *(gdouble *)((char FD_GLOBAL *)(((unsigned long long)hi << 32) | lo) + rowb);
+        };
+        double x[kNB];
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) x[c] = at(c);
+        for (int e = tid; e < kNB * kNB; e += 256) sL[e >> 5][e & 31] = Ld[e];     // column k of L11 contiguous
+        if (tid < kNB) sInv[tid] = Ld[kNB * kNB + tid];
+        __syncthreads();
+        if (!active) return;
+        solve_row(x, sL, sInv);
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) at(c) = x[c];
+        gdouble *up = A + (size_t)grow * lda + k0;     // row k0+c of column grow: U[k0+c][grow] = L[grow][k0+c]
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) up[c] = x[c];
+        return;
     }
-    const bool invert = rhs && with_inverse && unit >= 0 && unit < kNB;
+
+    // right-hand-side workgroup: threads 0..2 take the three RHS rows (contiguous in the RHS
+    // columns of A); the second wave takes the rows of the identity, i.e. inverts L11
+    const int unit = tid - 64;
+    const bool active = tid < 3;
+    const bool invert = with_inverse && unit >= 0 && unit < kNB;
+    gdouble *rowp = A + (size_t)(npad + (active ? tid : 0)) * lda + k0;
     double x[kNB];
 #pragma unroll
-    for (int c = 0; c < kNB; ++c) x[c] = rowp[(size_t)c * cstride];
+    for (int c = 0; c < kNB; ++c) x[c] = rowp[c];
     if (invert) {
 #pragma unroll
         for (int c = 0; c < kNB; ++c) x[c] = c == unit ? 1.0 : 0.0;
     }
-
-    // column k of L11 contiguous (the side store is column-major already): the update of step k
-    // reads it in one burst of 16-byte LDS loads
     for (int e = tid; e < kNB * kNB; e += 256) sL[e >> 5][e & 31] = Ld[e];
     if (tid < kNB) sInv[tid] = Ld[kNB * kNB + tid];
     __syncthreads();
     if (!active && !invert) return;
-
-    // right-looking: x_k is final once columns 0 .. k-1 have been applied; its update of the
-    // columns to the right is 31-k independent fmas (a dot-product form would be one dependent
-    // chain per element, and there is one wave per SIMD to hide it)
-#pragma unroll
-    for (int k = 0; k < kNB; ++k) {
-        x[k] *= sInv[k];
-        double lk[kNB];
-#pragma unroll
-        for (int c = (k + 1) & ~1; c < kNB; ++c) lk[c] = sL[k][c];
-#pragma unroll
-        for (int c = k + 1; c < kNB; ++c) x[c] = fma(-x[k], lk[c], x[c]);
-    }
+    solve_row(x, sL, sInv);
     if (invert) {
         // e_j L11^-T = row j of L11^-T = column j of inverse(L11): stored as [k][j]
         gdouble *inv = Ld + kLdInv;
@@ -575,12 +605,7 @@ __global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M,
         return;
     }
 #pragma unroll
-    for (int c = 0; c < kNB; ++c) rowp[(size_t)c * cstride] = x[c];
-    if (!rhs) {
-        gdouble *up = A + (size_t)grow * lda + k0;     // row k0+c of column grow: U[k0+c][grow] = L[grow][k0+c]
-#pragma unroll
-        for (int c = 0; c < kNB; ++c) up[c] = x[c];
-    }
+    for (int c = 0; c < kNB; ++c) rowp[c] = x[c];
 }
 
 // ---- back-substitution with the inverted diagonal blocks ----------------------------------------------
@@ -589,7 +614,7 @@ __global__ __launch_bounds__(256) void k_chol_solve(const BatchSlot *tab, int M,
 // chain, then the rows above in the range take the block's contribution (the mirrored U = L^T, one
 // row per thread, coalesced).  Ranges above 512 rows are chained with k_backsub_update as in the
 // LU path.  Same role and data layout as fd_build.hip's k_backsub_all.
-__global__ __launch_bounds__(256) void k_backsub_inv(const BatchSlot *tab, int M, int lda, int npad, int row_lo, int row_hi)
+__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_backsub_inv(const BatchSlot *tab, int M, int lda, int npad, int row_lo, int row_hi)
 {
     const BatchSlot &s = tab[blockIdx.z];
     gcdouble *A = as_global(s.A);
@@ -620,16 +645,17 @@ __global__ __launch_bounds__(256) void k_backsub_inv(const BatchSlot *tab, int M
         // my first row's segment of U for the update below (does not depend on y)
         const int i0 = row_lo + tid;
         double uik[kNB];
+        gcdouble *ub = A + (size_t)b0 * lda;       // wave-uniform base, 32-bit offsets below
         if (i0 < b0) {
 #pragma unroll
-            for (int k = 0; k < kNB; ++k) uik[k] = A[(size_t)(b0 + k) * lda + i0];
+            for (int k = 0; k < kNB; ++k) uik[k] = (ub + (size_t)k * lda)[(unsigned)i0];
         }
         __syncthreads();                 // the inverse block and the z rows of this block are in LDS
         const int l0 = b0 - row_lo;
         if (tid < 96) {
             const int i = tid & 31, c = tid >> 5;
             double acc = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int k = 0; k < kNB; ++k) acc = fma(s_li[buf][k][i], s_y[c * w + l0 + k], acc);   // zeros above the diagonal
             s_x[i][c] = acc;
         }
@@ -638,14 +664,17 @@ __global__ __launch_bounds__(256) void k_backsub_inv(const BatchSlot *tab, int M
         for (int i = i0; i < b0; i += 256) {
             if (i != i0) {
 #pragma unroll
-                for (int k = 0; k < kNB; ++k) uik[k] = A[(size_t)(b0 + k) * lda + i];
+                for (int k = 0; k < kNB; ++k) uik[k] = (ub + (size_t)k * lda)[(unsigned)i];
             }
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int k = 0; k < kNB; ++k) {
-                a0 = fma(uik[k], s_x[k][0], a0);
-                a1 = fma(uik[k], s_x[k][1], a1);
-                a2 = fma(uik[k], s_x[k][2], a2);
+                const double x0 = s_x[k][0], x1 = s_x[k][1], x2 = s_x[k][2];
+                a0 = fma(uik[k], x0, a0);
+                a1 = fma(uik[k], x1, a1);
+                a2 = fma(uik[k], x2, a2);
+                // the scheduler would otherwise hoist all 96 LDS reads and spill the U row
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
             const int li = i - row_lo;
             s_y[li] -= a0; s_y[w + li] -= a1; s_y[2 * w + li] -= a2;
@@ -665,7 +694,7 @@ __global__ __launch_bounds__(256) void k_backsub_inv(const BatchSlot *tab, int M
 // by itself and factorises it while the others are busy -- the only sequential part of the
 // factorisation runs beside the trailing update instead of after it.  (The tiles of that block
 // are skipped by everybody else.)  rhs_only (fd_set_deltas): the right-hand-side tiles alone.
-__global__ __launch_bounds__(256) void k_chol_trail(const BatchSlot *tab, int M, int lda, int npad, int npc, int n1, int k0,
+__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_trail(const BatchSlot *tab, int M, int lda, int npad, int npc, int n1, int k0,
                                                     int nchunk, int rhs_only)
 {
     const BatchSlot &slot = tab[blockIdx.z];
