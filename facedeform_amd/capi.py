@@ -16,7 +16,7 @@ from . import _build
 FD_OK = 0
 FD_E_INVALID, FD_E_NOMEM, FD_E_DEVICE, FD_E_SINGULAR, FD_E_DUPLICATE, FD_E_NOT_BUILT, FD_E_NO_DEVICE = (
     -1, -2, -3, -4, -5, -6, -7)
-KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC = range(5)
+KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC, KERNEL_GAUSSIAN_ML = range(6)
 TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
 EVAL_FP32, EVAL_FP64 = 0, 1
 SOLVER_AUTO, SOLVER_LU = 0, 1
@@ -52,7 +52,7 @@ class FdsopGeo(C.Structure):
 EXPORTS = [
     "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_points",
     "fd_set_points_dev", "fd_set_deltas", "fd_set_deltas_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
-    "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_bytes",
+    "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_centres", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
     "fd_mesh_set", "fd_mesh_size", "fd_deform_mesh",
     "fd_capture_dist2", "fd_capture_dist2_dev", "fd_capture_islands", "fd_capture_islands_dev",
@@ -107,6 +107,7 @@ def load() -> C.CDLL:
     L.fd_deform_dev_stream.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float]
     L.fd_deform_dev_stream.restype = i32
     L.fd_get_weights.argtypes = [vp, _f64p, _f64p]; L.fd_get_weights.restype = i32
+    L.fd_model_centres.argtypes = [vp]; L.fd_model_centres.restype = i32
     L.fd_model_bytes.argtypes = [vp]; L.fd_model_bytes.restype = sz
     L.fd_export_model.argtypes = [vp, vp, sz, i32]; L.fd_export_model.restype = i32
     L.fd_import_model.argtypes = [vp, vp, sz, i32]; L.fd_import_model.restype = i32
@@ -341,10 +342,11 @@ class Engine:
                                                 float(falloffrate)))
 
     def get_weights(self):
-        W = np.zeros((self.M + 4, 3), np.float64)
-        radii = np.zeros(max(self.M, 1), np.float64)
+        n = int(self.L.fd_model_centres(self.ctx))     # M, or M * layers for the multilayer model
+        W = np.zeros((n + 4, 3), np.float64)
+        radii = np.zeros(max(n, 1), np.float64)
         self._check(self.L.fd_get_weights(self.ctx, W.ctypes.data_as(_f64p), radii.ctypes.data_as(_f64p)))
-        return W, radii[: self.M]
+        return W, radii[:n]
 
     def model_bytes(self) -> int:
         return int(self.L.fd_model_bytes(self.ctx))

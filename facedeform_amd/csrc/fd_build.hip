@@ -159,9 +159,9 @@ __global__ void k_qnn_cap(const BatchSlot *tab, int M, double z)
 template <int TS>
 __global__ __launch_bounds__(256) void k_assemble(const BatchSlot *tab, int M,
                                                    int n, int npad, int lda, int kind, int T,
-                                                   double lambda)
+                                                   double lambda, int radii_off)
 {
-    const double *centres = tab[blockIdx.z].centres, *radii = tab[blockIdx.z].radii;
+    const double *centres = tab[blockIdx.z].centres, *radii = tab[blockIdx.z].radii + radii_off;
     double *A = tab[blockIdx.z].A;
     DevModel *model = tab[blockIdx.z].model;
     __shared__ double s_max[4];
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (tid == 0) {
         model->norm32[3] = (float)inv_s;
         int tt = 1;
-        if (from_w) {
+        if (from_w == 1) {
             if (s_bad) tt = -4;
         } else {
             if (model->sing_flag || s_bad) tt = -4;
@@ -1108,17 +1108,17 @@ hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int ro
 }
 
 // the kernel block alone: phi + lambda on the diagonal for i, j < M, identity padding up to npad_a
-hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a)
+hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a, int radii_off)
 {
     const unsigned nb = (unsigned)b.nbatch;
     if (npad_a <= 512) {
         const unsigned g = (unsigned)(npad_a + 31) / 32;
         hipLaunchKernelGGL((k_assemble<2>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, b.M, b.M, npad_a,
-                           b.lda, b.kind, 0, b.lambda);
+                           b.lda, b.kind, 0, b.lambda, radii_off);
     } else {
         const unsigned g = (unsigned)(npad_a + 63) / 64;
         hipLaunchKernelGGL((k_assemble<4>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, b.M, b.M, npad_a,
-                           b.lda, b.kind, 0, b.lambda);
+                           b.lda, b.kind, 0, b.lambda, radii_off);
     }
     return hipGetLastError();
 }
@@ -1148,6 +1148,7 @@ hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const Point
 // everything after k_prepare: radii, assembly, LU, back-substitution, packing
 hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
 {
+    if (b.ml_layers) return launch_build_ml(b, stream, ev_mid);
     if (b.spd) return launch_build_spd(b, stream, ev_mid);
     const int M = b.M;
     const unsigned nb = (unsigned)b.nbatch;
@@ -1162,11 +1163,11 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
         if (b.npad <= 512) {
             const unsigned g = (unsigned)(b.npad + 31) / 32;
             hipLaunchKernelGGL((k_assemble<2>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
-                               b.lda, b.kind, b.T, b.lambda);
+                               b.lda, b.kind, b.T, b.lambda, 0);
         } else {
             const unsigned g = (unsigned)(b.npad + 63) / 64;
             hipLaunchKernelGGL((k_assemble<4>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
-                               b.lda, b.kind, b.T, b.lambda);
+                               b.lda, b.kind, b.T, b.lambda, 0);
         }
     }
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
@@ -1208,6 +1209,13 @@ hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream)
     hipLaunchKernelGGL(k_pack, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.npad, b.M, b.Mpad, b.T, b.kind, 0);
     if (b.kind == FD_KERNEL_THIN_PLATE)
         hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16, 1, nb), dim3(64), 0, stream, b.d_slots, b.Mpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_records(const BuildBuffers &b, hipStream_t stream, int records, int kind, int mode)
+{
+    hipLaunchKernelGGL(k_pack, dim3(1, 1, (unsigned)b.nbatch), dim3(256), 0, stream, b.d_slots, b.npad, records,
+                       round_up(records, kRecPad), b.T, kind, mode);
     return hipGetLastError();
 }
 

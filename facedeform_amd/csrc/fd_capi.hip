@@ -37,6 +37,7 @@ struct fd_ctx {
     // device buffers (grow-only)
     int cap_M = 0;                // capacity in centres
     int cap_npad = 0;
+    int cap_records = 0;             // centres / radii / weights / records: M, or M * layers for the multilayer model
     float *d_rest = nullptr, *d_delta = nullptr;
     double *d_centres = nullptr, *d_radii = nullptr, *d_W = nullptr;
     double *d_A = nullptr, *d_X = nullptr;
@@ -168,25 +169,40 @@ static int dev_alloc(fd_ctx *ctx, T **p, size_t count)
 
 static int order_of(const fd_ctx *ctx) { return ctx->M + term_cols(ctx->term); }
 static bool use_spd(const fd_ctx *ctx);
+static int ml_layers(const fd_ctx *ctx) { return ctx->kind == FD_KERNEL_GAUSSIAN_ML ? (int)ctx->params[1] : 0; }
+// Gaussian records of the solved model, and the kernel the evaluation sees
+static int model_centres(const fd_ctx *ctx) { return ctx->kind == FD_KERNEL_GAUSSIAN_ML ? ctx->M * ml_layers(ctx) : ctx->M; }
+static int eval_kind(const fd_ctx *ctx) { return ctx->kind == FD_KERNEL_GAUSSIAN_ML ? FD_KERNEL_GAUSSIAN_QNN : ctx->kind; }
+
+// the solved model's arrays: one entry per Gaussian record (= per centre, times the layers of the
+// multilayer model).  Everything in them is produced by a build or an import, so growing them loses nothing.
+static int ensure_records_capacity(fd_ctx *ctx, int n)
+{
+    int rc;
+    if (n > ctx->cap_records) {
+        const int npad = round_up(n, kRecPad);
+        if ((rc = dev_alloc(ctx, &ctx->d_centres, (size_t)n * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_radii, (size_t)n))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_W, (size_t)(n + 4) * 3))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_rec32, (size_t)npad))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_rec64, (size_t)npad))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_tiles, (size_t)npad / 16))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_tiles16, (size_t)npad / 16))) return rc;
+        ctx->cap_records = n;
+    }
+    return FD_OK;
+}
 
 static int ensure_model_capacity(fd_ctx *ctx, int M)
 {
     int rc;
     if (M > ctx->cap_M) {
-        const int Mpad = round_up(M, kRecPad);
         if ((rc = dev_alloc(ctx, &ctx->d_rest, (size_t)M * 3))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_delta, (size_t)M * 3))) return rc;
-        if ((rc = dev_alloc(ctx, &ctx->d_centres, (size_t)M * 3))) return rc;
-        if ((rc = dev_alloc(ctx, &ctx->d_radii, (size_t)M))) return rc;
-        if ((rc = dev_alloc(ctx, &ctx->d_W, (size_t)(M + 4) * 3))) return rc;
-        if ((rc = dev_alloc(ctx, &ctx->d_rec32, (size_t)Mpad))) return rc;
-        if ((rc = dev_alloc(ctx, &ctx->d_rec64, (size_t)Mpad))) return rc;
-        if ((rc = dev_alloc(ctx, &ctx->d_tiles, (size_t)Mpad / 16))) return rc;
-        if ((rc = dev_alloc(ctx, &ctx->d_tiles16, (size_t)Mpad / 16))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_ns, ns_doubles(M)))) return rc;
         ctx->cap_M = M;
     }
-    return FD_OK;
+    return ensure_records_capacity(ctx, M);
 }
 
 static int ensure_solver_capacity(fd_ctx *ctx, int npad)
@@ -426,7 +442,7 @@ int fd_set_points_dev(fd_ctx *ctx, const float *d_rest_xyz, const float *d_delta
 int fd_set_kernel(fd_ctx *ctx, int kind, const double *params, int nparams)
 {
     if (!ctx) return FD_E_INVALID;
-    if (kind < FD_KERNEL_GAUSSIAN || kind > FD_KERNEL_CUBIC || nparams < 0 || nparams > 4 ||
+    if (kind < FD_KERNEL_GAUSSIAN || kind > FD_KERNEL_GAUSSIAN_ML || nparams < 0 || nparams > 4 ||
         (nparams > 0 && !params)) {
         set_err(ctx, "fd_set_kernel: bad kind %d / nparams %d", kind, nparams);
         return FD_E_INVALID;
@@ -440,6 +456,15 @@ int fd_set_kernel(fd_ctx *ctx, int kind, const double *params, int nparams)
         if (nparams < 1) p[0] = 1.0;
         if (nparams < 2) p[1] = 5.0;
         if (!(p[0] > 0.0) || !(p[1] > 0.0)) { set_err(ctx, "fd_set_kernel: q and z must be > 0"); return FD_E_INVALID; }
+    } else if (kind == FD_KERNEL_GAUSSIAN_ML) {
+        if (nparams < 1) p[0] = 1.0;
+        if (nparams < 2) p[1] = 4.0;
+        if (nparams < 3) p[2] = 0.1;     // the SOP's defaults for radius, layers, lambda (src/SOP_FaceDeform.cpp:125-131)
+        p[1] = floor(p[1]);
+        if (!(p[0] > 0.0) || !(p[1] >= 1.0 && p[1] <= (double)kMaxLayers) || !(p[2] >= 0.0)) {
+            set_err(ctx, "fd_set_kernel: multilayer needs radius > 0, 1 <= layers <= %d, lambda >= 0", kMaxLayers);
+            return FD_E_INVALID;
+        }
     }
     if (kind == ctx->kind && nparams == ctx->nparams && memcmp(ctx->params, p, sizeof(p)) == 0)
         return FD_OK;                 // nothing changes: the model and its factorisation stay valid
@@ -468,7 +493,7 @@ int fd_set_term(fd_ctx *ctx, int term)
 
 static double ctx_lambda(const fd_ctx *ctx)
 {
-    const int idx = ctx->kind == FD_KERNEL_GAUSSIAN ? 1 : (ctx->kind == FD_KERNEL_GAUSSIAN_QNN ? 2 : 0);
+    const int idx = ctx->kind == FD_KERNEL_GAUSSIAN ? 1 : (ctx->kind == FD_KERNEL_GAUSSIAN_QNN || ctx->kind == FD_KERNEL_GAUSSIAN_ML ? 2 : 0);
     return ctx->nparams > idx ? ctx->params[idx] : 0.0;
 }
 
@@ -477,6 +502,7 @@ static bool use_spd(const fd_ctx *ctx)
 {
     static const char *env = getenv("FD_SOLVER");
     if ((env && strcmp(env, "lu") == 0) || ctx->solver == FD_SOLVER_LU) return false;
+    if (ctx->kind == FD_KERNEL_GAUSSIAN_ML) return false;          // its own pipeline (launch_build_ml)
     return spd_applicable(ctx->kind, ctx->term, ctx_lambda(ctx), ctx->M);
 }
 
@@ -488,10 +514,11 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.npad = round_up(b.n, 32);
     b.lda = b.npad;
     b.ncols = b.npad + kRhsCols;
-    b.kind = ctx->kind;
+    b.ml_layers = ml_layers(ctx);
+    b.kind = b.ml_layers ? FD_KERNEL_GAUSSIAN : ctx->kind;       // what the assembly evaluates
     b.term = ctx->term;
     b.lambda = ctx_lambda(ctx);
-    b.gauss_R = ctx->kind == FD_KERNEL_GAUSSIAN ? ctx->params[0] : 1.0;
+    b.gauss_R = (ctx->kind == FD_KERNEL_GAUSSIAN || b.ml_layers) ? ctx->params[0] : 1.0;
     b.qnn_q = ctx->params[0];
     b.qnn_z = ctx->params[1];
     b.Mpad = round_up(ctx->M, kRecPad);
@@ -512,6 +539,7 @@ int fd_build_async(fd_ctx *ctx)
     const int npad = round_up(order_of(ctx), 32);
     const bool grew = npad > ctx->cap_npad;
     if ((rc = ensure_solver_capacity(ctx, npad))) return rc;
+    if ((rc = ensure_records_capacity(ctx, model_centres(ctx)))) return rc;
     if ((rc = sync_slot(ctx))) return rc;
     BuildBuffers b;
     fill_build_buffers(ctx, b);
@@ -593,7 +621,7 @@ int fd_build_async(fd_ctx *ctx)
     FD_HIP(ctx, hipEventRecord(ctx->ev1, cur_stream(ctx)));
     ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
-    ctx->have_factor = true;
+    ctx->have_factor = b.ml_layers == 0;     // the multilayer model keeps no single factorisation to reuse
     ctx->factor_grouped = false;
     ctx->deltas_only = false;
     ctx->build_pending = true;
@@ -674,7 +702,7 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
     a.dist2 = d_dist2; a.falloff_out = d_falloff_out;
     a.tu = d_tu; a.tv = d_tv; a.nrm = d_nrm;
     a.radius2 = radius2; a.falloffrate = falloffrate;
-    a.M = ctx->M; a.Mpad = round_up(ctx->M, kRecPad); a.kind = ctx->kind;
+    a.M = model_centres(ctx); a.Mpad = round_up(a.M, kRecPad); a.kind = eval_kind(ctx);
     a.rec32 = ctx->d_rec32; a.rec64 = ctx->d_rec64; a.tiles = ctx->d_tiles; a.tiles16 = ctx->d_tiles16;
     a.model = ctx->d_model;
     a.precision = ctx->eval_precision;
@@ -972,14 +1000,17 @@ static int require_built(fd_ctx *ctx, const char *who)
     return FD_OK;
 }
 
+int fd_model_centres(const fd_ctx *ctx) { return ctx ? model_centres(ctx) : 0; }
+
 int fd_get_weights(fd_ctx *ctx, double *W, double *radii)
 {
     if (!ctx || !W) return FD_E_INVALID;
     int rc = use_device(ctx);
     if (rc) return rc;
     if ((rc = require_built(ctx, "fd_get_weights"))) return rc;
-    FD_HIP(ctx, hipMemcpyAsync(W, ctx->d_W, sizeof(double) * 3 * (size_t)(ctx->M + 4), hipMemcpyDeviceToHost, cur_stream(ctx)));
-    if (radii) FD_HIP(ctx, hipMemcpyAsync(radii, ctx->d_radii, sizeof(double) * (size_t)ctx->M, hipMemcpyDeviceToHost, cur_stream(ctx)));
+    const int n = model_centres(ctx);
+    FD_HIP(ctx, hipMemcpyAsync(W, ctx->d_W, sizeof(double) * 3 * (size_t)(n + 4), hipMemcpyDeviceToHost, cur_stream(ctx)));
+    if (radii) FD_HIP(ctx, hipMemcpyAsync(radii, ctx->d_radii, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, cur_stream(ctx)));
     FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     return FD_OK;
 }
@@ -989,7 +1020,7 @@ static size_t model_bytes_for(int M)
     return sizeof(ModelHeader) + sizeof(double) * ((size_t)M * 3 + (size_t)M + (size_t)(M + 4) * 3);
 }
 
-size_t fd_model_bytes(const fd_ctx *ctx) { return ctx ? model_bytes_for(ctx->M) : 0; }
+size_t fd_model_bytes(const fd_ctx *ctx) { return ctx ? model_bytes_for(model_centres(ctx)) : 0; }
 
 int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device)
 {
@@ -997,14 +1028,15 @@ int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device)
     int rc = use_device(ctx);
     if (rc) return rc;
     if ((rc = require_built(ctx, "fd_export_model"))) return rc;
-    const int M = ctx->M;
+    // a multilayer model travels as what it is once solved: M * layers Gaussians with their own radii
+    const int M = model_centres(ctx);
     if (capacity < model_bytes_for(M)) { set_err(ctx, "fd_export_model: buffer too small"); return FD_E_INVALID; }
     // the pinned header may still be the source of an earlier in-flight copy
     FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     ModelHeader *h = ctx->h_header;
     memset(h, 0, sizeof(*h));
     h->magic = kModelMagic;
-    h->M = M; h->kind = ctx->kind; h->term = ctx->term; h->nparams = ctx->nparams;
+    h->M = M; h->kind = eval_kind(ctx); h->term = ctx->term; h->nparams = ctx->nparams;
     h->terminationtype = 1;
     memcpy(h->params, ctx->params, sizeof(h->params));
     char *p = (char *)buf;
@@ -1034,7 +1066,7 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     } else {
         memcpy(&h, buf, sizeof(h));
     }
-    if (h.magic != kModelMagic || h.M <= 0 || h.M + 4 > kMaxOrder || h.kind < 0 || h.kind > FD_KERNEL_CUBIC ||
+    if (h.magic != kModelMagic || h.M <= 0 || h.M > kMaxOrder * kMaxLayers || h.kind < 0 || h.kind > FD_KERNEL_CUBIC ||
         h.term < 0 || h.term > 2 || h.terminationtype != 1 || bytes < model_bytes_for(h.M)) {
         set_err(ctx, "fd_import_model: not a valid model blob");
         return FD_E_INVALID;
@@ -1178,7 +1210,10 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];
         const bool grew = npad > c->cap_npad;
-        if ((rc = ensure_solver_capacity(c, npad)) || (rc = sync_slot(c))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
+        if ((rc = ensure_solver_capacity(c, npad)) || (rc = ensure_records_capacity(c, model_centres(c))) || (rc = sync_slot(c))) {
+            batch_err(b, "context %d: %s", i, c->err);
+            return rc;
+        }
         if (grew) {
             const size_t cols = (size_t)c->cap_npad + kRhsCols + 16;
             hipError_t e = hipMemsetAsync(c->d_A, 0, sizeof(double) * (size_t)c->cap_npad * cols, stream);
@@ -1244,7 +1279,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         fd_ctx *c = b->ctxs[i];
         c->wait_event = b->ev1; c->wait_stream = stream; c->wait_batch = b;
         c->tev0 = b->ev0; c->tev_mid = b->ev_mid; c->tev1 = b->ev1;
-        c->have_factor = true;       // a batched build leaves a factorisation fd_set_deltas can reuse
+        c->have_factor = bb.ml_layers == 0;   // a batched build leaves a factorisation fd_set_deltas can reuse (not the multilayer model)
         c->factor_grouped = bb.group_panels != 0;
         c->deltas_only = false;
         c->build_pending = true;
@@ -1296,7 +1331,7 @@ int fd_batch_deform_dev(fd_batch *b, void *hip_stream, int64_t N, const float *c
         a.dist2 = d_dist2 ? d_dist2[i] : nullptr; a.falloff_out = d_falloff_out ? d_falloff_out[i] : nullptr;
         a.tu = tu; a.tv = tv; a.nrm = nr;
         a.radius2 = radius2; a.falloffrate = falloffrate;
-        a.M = c->M; a.Mpad = round_up(c->M, kRecPad); a.kind = c->kind;
+        a.M = model_centres(c); a.Mpad = round_up(a.M, kRecPad); a.kind = eval_kind(c);
         a.rec32 = c->d_rec32; a.rec64 = c->d_rec64; a.tiles = c->d_tiles; a.tiles16 = c->d_tiles16;
         a.model = c->d_model;
         a.precision = c->eval_precision;

@@ -141,6 +141,9 @@ struct BuildBuffers {
     // Householder reflectors and the projected kernel block, order M - T, is Cholesky-factorised
     // -- no pivot search, so the panel is no longer one workgroup's serial chain.
     int spd;
+    // Multilayer Gaussian model (FD_KERNEL_GAUSSIAN_ML, fd_nullspace.hip launch_build_ml): number of
+    // layers, 0 for every other kind.  `kind` is then FD_KERNEL_GAUSSIAN (what the assembly evaluates).
+    int ml_layers;
     // LU look-ahead: second stream + {panel done, rest done} x 2 events; aux_stream == nullptr
     // runs every step on the one stream
     hipStream_t aux_stream;
@@ -154,7 +157,10 @@ hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream);
 hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream);
 // pieces of the LU pipeline the null-space path reuses: the kernel block alone (order M, identity
 // padding to npad_a) and back-substitution with the upper triangle over rows [0, rows)
-hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a);
+hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a, int radii_off = 0);
+// k_pack over `records` centres whose weights are already in W (mode 1: imported model, status from
+// the values alone; mode 2: built here, the factorisation's flags count too)
+hipError_t launch_pack_records(const BuildBuffers &b, hipStream_t stream, int records, int kind, int mode);
 hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int rows);
 hipError_t launch_prepare_rhs(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 hipError_t launch_backsub_update(const BuildBuffers &b, hipStream_t stream, int row_lo, int w);
@@ -165,6 +171,8 @@ bool spd_applicable(int kind, int term, double lambda, int M);
 static inline size_t ns_doubles(int M) { return (size_t)12 * (size_t)M + 64 + (size_t)(M / 32 + 2) * 66 * 32; }
 hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
 hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
+constexpr int kMaxLayers = 8;
+hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
 
 // ---- evaluation (fd_eval.hip) --------------------------------------------------
 struct DeformArgs {

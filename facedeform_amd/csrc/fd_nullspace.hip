@@ -62,6 +62,7 @@ constexpr int kTau = 0;                 // tau[4]
 constexpr int kR = 4;                   // R[k][c], row k = pivot row M-1-k
 constexpr int kTm = 20;                 // compact WY: Q = I - V Tm V^T, upper triangular
 constexpr int kG = 36;                  // (Q^T f) in the pivot rows: g[k][c]
+constexpr int kAff = 48;                // multilayer model: least-squares polynomial a[k][c]
 constexpr int kSmall = 64;
 // after the small block: the factorised diagonal blocks, one per 32 columns -- L11 column-major
 // (32 x 32, zeros above the diagonal) followed by the reciprocals of its diagonal: what the
@@ -818,6 +819,99 @@ __global__ __launch_bounds__(256) void k_ns_recover(const BatchSlot *tab, int M,
     if (tid == 0 && s.model->iterations >= n1) s.model->iterations = M + T;
 }
 
+// ---- multilayer Gaussian model (FD_KERNEL_GAUSSIAN_ML) ---------------------------------------------
+// The SOP's model = 1, alglib::rbfsetalgomultilayer(model, radius, layers, lambda)
+// (reference src/SOP_FaceDeform.cpp:346-348), in dense form: the term's polynomial is fitted to
+// the deltas FIRST, by least squares, and removed (ALGLIB's order; the other kinds solve it
+// together with the weights); then layer l = 0 .. L-1 fits what is left with Gaussians of radius
+// R / 2^l on every centre,
+//     (Phi_l + lambda I) w_l = r_l,      r_{l+1} = r_l - Phi_l w_l  (= lambda w_l),
+// each a symmetric positive definite system: the Cholesky kernels above with nothing to project.
+// The solved model is M * L Gaussian records with their own radii plus the polynomial -- exactly
+// what the per-centre-radius evaluation kernel takes.
+
+// Least-squares polynomial through the reflectors of P (k_ns_reflectors): a = R^-1 (Q^T f)_pivot rows;
+// f <- f - P a in the right-hand-side columns.  X is scratch for Q^T f.
+__global__ __launch_bounds__(256) void k_ml_affine(const BatchSlot *tab, int M, int T, int npad, int lda)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *V = as_global(s.ns), *centres = as_global(s.centres);
+    gdouble *small = as_global(s.ns) + (size_t)12 * M;
+    gdouble *f0 = as_global(s.A) + (size_t)npad * lda, *f1 = f0 + lda, *f2 = f1 + lda;
+    gdouble *x0 = as_global(s.X), *x1 = x0 + npad, *x2 = x1 + npad;
+    __shared__ double s_red[4 * 3];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < M; i += 256) { x0[i] = f0[i]; x1[i] = f1[i]; x2[i] = f2[i]; }
+    __syncthreads();
+    for (int k = 0; k < T; ++k) {
+        const int piv = M - 1 - k;
+        const double tau = small[kTau + k];
+        double d[3] = {0.0, 0.0, 0.0};
+        for (int i = tid; i <= piv; i += 256) {
+            const double v = V[4 * (size_t)i + k];
+            d[0] = fma(v, x0[i], d[0]); d[1] = fma(v, x1[i], d[1]); d[2] = fma(v, x2[i], d[2]);
+        }
+        block_sum_n<3>(d, s_red, tid);
+        for (int i = tid; i <= piv; i += 256) {
+            const double v = V[4 * (size_t)i + k];
+            x0[i] = fma(-tau * d[0], v, x0[i]); x1[i] = fma(-tau * d[1], v, x1[i]); x2[i] = fma(-tau * d[2], v, x2[i]);
+        }
+        __syncthreads();
+    }
+    double a[4][3] = {};
+    for (int k = T - 1; k >= 0; --k)
+        for (int c = 0; c < 3; ++c) {
+            double v = (c == 0 ? x0 : (c == 1 ? x1 : x2))[M - 1 - k];
+            for (int cc = k + 1; cc < T; ++cc) v = fma(-small[kR + 4 * k + cc], a[cc][c], v);
+            a[k][c] = v / small[kR + 4 * k + k];
+        }
+    for (int i = tid; i < M; i += 256) {
+        const double px = centres[3 * (size_t)i], py = centres[3 * (size_t)i + 1], pz = centres[3 * (size_t)i + 2];
+        f0[i] -= fma(a[3][0], pz, fma(a[2][0], py, fma(a[1][0], px, a[0][0])));
+        f1[i] -= fma(a[3][1], pz, fma(a[2][1], py, fma(a[1][1], px, a[0][1])));
+        f2[i] -= fma(a[3][2], pz, fma(a[2][2], py, fma(a[1][2], px, a[0][2])));
+    }
+    if (tid < 12) small[kAff + tid] = a[tid / 3][tid % 3];
+}
+
+// the records of every layer: centre j again, radius R / 2^l
+__global__ void k_ml_setup(const BatchSlot *tab, int M, int L, double R)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gdouble *centres = as_global(s.centres), *radii = as_global(s.radii);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * L) return;
+    const int l = idx / M, j = idx - l * M;
+    if (l > 0)
+        for (int c = 0; c < 3; ++c) centres[3 * (size_t)idx + c] = centres[3 * (size_t)j + c];
+    radii[idx] = ldexp(R, -l);
+}
+
+// layer l solved (X): its weights into the model, lambda w_l as the next layer's right-hand sides
+__global__ void k_ml_layer(const BatchSlot *tab, int M, int npad, int lda, int l, int last, double lambda)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *X = as_global(s.X);
+    gdouble *W = as_global(s.W), *A = as_global(s.A);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    for (int c = 0; c < 3; ++c) {
+        const double w = X[(size_t)c * npad + j];
+        W[3 * ((size_t)l * M + j) + c] = w;
+        if (!last) A[(size_t)(npad + c) * lda + j] = lambda * w;
+    }
+}
+
+__global__ void k_ml_finish(const BatchSlot *tab, int M, int T, int L)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *small = as_global(s.ns) + (size_t)12 * M;
+    gdouble *W = as_global(s.W);
+    const int t = threadIdx.x;
+    if (t < 12) { const int k = t / 3, c = t % 3; W[3 * ((size_t)M * L + k) + c] = k < T ? small[kAff + 3 * k + c] : 0.0; }
+    if (t == 0 && s.model->iterations >= M) s.model->iterations = M + T;      // all unknowns eliminated
+}
+
 // the factorisation loop; with rhs_only the matrix is left alone and only the right-hand-side rows
 // travel through the stored factor
 void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, int rhs_only)
@@ -900,6 +994,31 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ns_recover, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad);
     return launch_pack(b, stream);
+}
+
+// everything after k_prepare for the multilayer model
+hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    const int M = b.M, T = b.T, L = b.ml_layers;
+    const int npc = round_up(M, kNB);
+    if (T > 0) {
+        hipLaunchKernelGGL(k_ns_reflectors, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T);
+        hipLaunchKernelGGL(k_ml_affine, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
+    }
+    hipLaunchKernelGGL(k_ml_setup, dim3((M * L + 255) / 256, 1, nb), dim3(256), 0, stream, b.d_slots, M, L, b.gauss_R);
+    if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+    for (int l = 0; l < L; ++l) {
+        hipError_t e = launch_assemble_block(b, stream, npc, l * M);
+        if (e != hipSuccess) return e;
+        launch_factor(b, stream, npc, M, 0);
+        e = launch_backsub_spd(b, stream, npc);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ml_layer, dim3((M + 255) / 256, 1, nb), dim3(256), 0, stream, b.d_slots, M, b.npad, b.lda, l,
+                           l + 1 == L ? 1 : 0, b.lambda);
+    }
+    hipLaunchKernelGGL(k_ml_finish, dim3(1, 1, nb), dim3(64), 0, stream, b.d_slots, M, T, L);
+    return launch_pack_records(b, stream, M * L, FD_KERNEL_GAUSSIAN_QNN, 2);
 }
 
 // fd_set_deltas: new right-hand sides through the stored reflectors and Cholesky factor

@@ -309,8 +309,10 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
         const double p[1] = {smoothing};
         rc = fd_set_kernel(ctx, kind, p, 1);
     } else if (model_index == 1) {   // ALGLIB_MODEL_ML: rbfsetalgomultilayer(model, radius, layers, lambda)
-        const double p[2] = {(double)radius, (double)lambda};
-        rc = fd_set_kernel(ctx, FD_KERNEL_GAUSSIAN, p, 2);
+        // the engine's multilayer model takes up to 8 layers: beyond that the radius has shrunk
+        // 256-fold and the remaining layers see only lambda^8 of the residual
+        const double p[3] = {(double)radius, (double)(layers < 8 ? layers : 8), (double)lambda};
+        rc = fd_set_kernel(ctx, FD_KERNEL_GAUSSIAN_ML, p, 3);
     } else {                         // ALGLIB_MODEL_QNN: rbfsetalgoqnn(model, qcoef, zcoef)
         const double p[3] = {(double)qcoef, (double)zcoef, smoothing};
         rc = fd_set_kernel(ctx, FD_KERNEL_GAUSSIAN_QNN, p, 3);

@@ -50,13 +50,23 @@ enum {
  *   FD_KERNEL_THIN_PLATE    r^2 ln r                params {[lambda]}
  *   FD_KERNEL_BIHARMONIC    -r                      params {[lambda]}
  *   FD_KERNEL_CUBIC         r^3                     params {[lambda]}
- * lambda is added to the diagonal of the kernel block (smoothing); default 0. */
+ * lambda is added to the diagonal of the kernel block (smoothing); default 0.
+ *   FD_KERNEL_GAUSSIAN_ML   model=1 "Multilayer" as rbfsetalgomultilayer(model, radius, layers, lambda)
+ *       (src/SOP_FaceDeform.cpp:346-348) lays it out, in dense form   params {R [, layers [, lambda]]}
+ *       -- the term's polynomial is fitted to the deltas first, by least squares, and removed
+ *       (ALGLIB's order; the kinds above solve it together with the weights); then layer
+ *       l = 0 .. layers-1 fits what is left with exp(-d2/R_l^2), R_l = R / 2^l, on every centre:
+ *       (Phi_l + lambda I) w_l = r_l,  r_{l+1} = r_l - Phi_l w_l.  The solved model is M * layers
+ *       Gaussian records (fd_model_centres).  1 <= layers <= 8; defaults 4 and 0.1 as the SOP's.
+ *       Not bit-parity with ALGLIB's truncated-Gaussian LSQR fit (absent here): parity with this
+ *       dense statement, pinned by tests/golden/ml_golden.npz. */
 enum {
     FD_KERNEL_GAUSSIAN = 0,
     FD_KERNEL_GAUSSIAN_QNN = 1,
     FD_KERNEL_THIN_PLATE = 2,
     FD_KERNEL_BIHARMONIC = 3,
-    FD_KERNEL_CUBIC = 4
+    FD_KERNEL_CUBIC = 4,
+    FD_KERNEL_GAUSSIAN_ML = 5
 };
 
 /* Same integers as ALGLIB_TERM_LINEAR/CONST/ZERO, src/SOP_FaceDeform.hpp:16-18. */
@@ -189,9 +199,12 @@ int64_t fd_mesh_size(const fd_ctx *ctx);
 int fd_deform_mesh(fd_ctx *ctx, float *P_out, float *falloff_out, float radius2, float falloffrate);
 
 /* ---- model access -----------------------------------------------------------
- * W is (M+4) x 3 fp64 row-major: M RBF weights, the constant row, the x,y,z
- * linear rows (zero when the term lacks them).  radii (may be NULL) gets M
- * Gaussian radii.  For tests and for RCCL-free replication. */
+ * W is (C+4) x 3 fp64 row-major: C RBF weights, the constant row, the x,y,z
+ * linear rows (zero when the term lacks them).  radii (may be NULL) gets C
+ * Gaussian radii.  C = fd_model_centres(ctx): the control points M, or M * layers
+ * for FD_KERNEL_GAUSSIAN_ML (layer-major: record l*M + j is centre j in layer l).
+ * For tests and for RCCL-free replication. */
+int fd_model_centres(const fd_ctx *ctx);
 int fd_get_weights(fd_ctx *ctx, double *W, double *radii);
 
 /* Solved model as one relocatable blob (header + centres + radii + weights):

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _DEFAULT_SO = os.path.join(_HERE, "libfd_oracle.so")
 
-KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC = range(5)
+KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC, KERNEL_GAUSSIAN_ML = range(6)
 TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
 
 _f32p = C.POINTER(C.c_float)
@@ -96,6 +96,46 @@ class Oracle:
         rc = self.lib.fdo_build(_ptr(table, _f64p), M, kind, _ptr(params, _f64p) if params.size else None,
                                 params.size, term, _ptr(W, _f64p), _ptr(radii, _f64p), C.byref(tt))
         return rc, tt.value, W, radii[:M]
+
+    # -- A4 model = 1: alglib::rbfsetalgomultilayer(model, radius, layers, lambda), reference
+    #    src/SOP_FaceDeform.cpp:346-348, in the dense form include/facedeform_hip.h states for
+    #    FD_KERNEL_GAUSSIAN_ML (ALGLIB itself is absent: parity unpinned against it; this restatement
+    #    is pinned by tests/golden/ml_golden.npz, written with SciPy's RBFInterpolator per layer).
+    #    numpy fp64 throughout: the term's polynomial by least squares first (LAPACK gelsd), then
+    #    (Phi_l + lambda I) w_l = r_l per layer with r_{l+1} = r_l - Phi_l w_l.
+    #    Returns tt, the expanded table (layer-major: row l*M + j = centre j), W ((M*L + 4) x 3), radii (M*L):
+    #    what eval() / deform() take with kind = KERNEL_GAUSSIAN_QNN (per-record radii).
+    def build_multilayer(self, table, radius, layers, lam, term=TERM_LINEAR):
+        table = np.ascontiguousarray(table, np.float64)
+        M = table.shape[0]
+        c, f = table[:, :3], table[:, 3:6].copy()
+        T = (4, 1, 0)[term]
+        aff = np.zeros((4, 3))
+        if T:
+            Pm = np.hstack([np.ones((M, 1)), c])[:, :T]
+            sol, *_ = np.linalg.lstsq(Pm, f, rcond=None)
+            aff[:T] = sol
+            f = f - Pm @ sol
+        d2 = ((c[:, None, :] - c[None, :, :]) ** 2).sum(-1)
+        if M > 1 and (d2 + np.eye(M) == 0.0).any():
+            return -5, None, None, None
+        W = np.zeros((M * layers + 4, 3))
+        radii = np.zeros(M * layers)
+        r = f
+        for l in range(layers):
+            R = radius / 2.0 ** l
+            Phi = np.exp(-d2 / (R * R))
+            try:
+                w = np.linalg.solve(Phi + lam * np.eye(M), r)
+            except np.linalg.LinAlgError:
+                return -4, None, None, None
+            W[l * M:(l + 1) * M] = w
+            radii[l * M:(l + 1) * M] = R
+            r = r - Phi @ w
+        W[M * layers:] = aff
+        if not np.isfinite(W).all():
+            return -4, None, None, None
+        return 1, np.tile(table, (layers, 1)), W, radii
 
     # -- A8
     def eval(self, table, kind, radii, W, x):
