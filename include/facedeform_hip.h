@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 2
+#define FD_ABI_VERSION 3   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres (additions only) */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {

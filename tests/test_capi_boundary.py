@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(hip_lib):
 
 
 def test_abi_version(hip_lib):
-    assert hip_lib.fd_abi_version() == 2   # 2: fdsop_geo grew the morph-space inputs
+    assert hip_lib.fd_abi_version() == 3   # 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres
 
 
 def test_struct_layouts_match_header():
