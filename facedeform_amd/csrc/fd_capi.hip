@@ -18,6 +18,8 @@ struct fd_ctx {
     int eval_precision = FD_EVAL_FP32;
     int eval_variant = 0;
     int solver = FD_SOLVER_AUTO;
+    bool prefer_lu = false;          // the Cholesky path lost definiteness on this rig: LU until kernel, term or M change
+    bool last_spd = false;           // the build in flight / last finished took the Cholesky path
 
     // model configuration
     int M = 0, kind = FD_KERNEL_GAUSSIAN_QNN, term = FD_TERM_LINEAR, nparams = 0;
@@ -390,6 +392,7 @@ static int set_points_common(fd_ctx *ctx, const float *rest, const float *delta,
     FD_HIP(ctx, hipMemcpyAsync(ctx->d_rest, rest, sizeof(float) * 3 * (size_t)M, k, cur_stream(ctx)));
     FD_HIP(ctx, hipMemcpyAsync(ctx->d_delta, delta, sizeof(float) * 3 * (size_t)M, k, cur_stream(ctx)));
     if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));  // caller may reuse its arrays
+    if (M != ctx->M) ctx->prefer_lu = false;
     ctx->M = M;
     ctx->points_set = true;
     ctx->built = false;
@@ -411,7 +414,7 @@ static int set_deltas_common(fd_ctx *ctx, const float *delta, int M, bool on_dev
                      "fd_set_kernel / fd_set_term / fd_import_model discard it)", M);
         return FD_E_NOT_BUILT;
     }
-    if (!use_spd(ctx) && round_up(order_of(ctx), 32) > 2048) {
+    if (!ctx->last_spd && round_up(order_of(ctx), 32) > 2048) {
         set_err(ctx, "fd_set_deltas: supported up to order 2048 (M = %d here); use fd_set_points", M);
         return FD_E_INVALID;
     }
@@ -471,6 +474,7 @@ int fd_set_kernel(fd_ctx *ctx, int kind, const double *params, int nparams)
     ctx->kind = kind;
     ctx->nparams = nparams;
     memcpy(ctx->params, p, sizeof(p));
+    ctx->prefer_lu = false;
     ctx->built = false;
     ctx->build_pending = false;
     ctx->have_factor = false;
@@ -484,6 +488,7 @@ int fd_set_term(fd_ctx *ctx, int term)
     if (term < FD_TERM_LINEAR || term > FD_TERM_ZERO) { set_err(ctx, "fd_set_term: bad term %d", term); return FD_E_INVALID; }
     if (term == ctx->term) return FD_OK;
     ctx->term = term;
+    ctx->prefer_lu = false;
     ctx->built = false;
     ctx->build_pending = false;
     ctx->have_factor = false;
@@ -501,7 +506,7 @@ static double ctx_lambda(const fd_ctx *ctx)
 static bool use_spd(const fd_ctx *ctx)
 {
     static const char *env = getenv("FD_SOLVER");
-    if ((env && strcmp(env, "lu") == 0) || ctx->solver == FD_SOLVER_LU) return false;
+    if ((env && strcmp(env, "lu") == 0) || ctx->solver == FD_SOLVER_LU || ctx->prefer_lu) return false;
     if (ctx->kind == FD_KERNEL_GAUSSIAN_ML) return false;          // its own pipeline (launch_build_ml)
     return spd_applicable(ctx->kind, ctx->term, ctx_lambda(ctx), ctx->M);
 }
@@ -546,9 +551,10 @@ int fd_build_async(fd_ctx *ctx)
     if (ctx->deltas_only && ctx->have_factor) {
         // fd_set_deltas: right-hand sides only, through the factorisation of the last full build
         b.group_panels = ctx->factor_grouped ? 1 : 0;
+        b.spd = ctx->last_spd ? 1 : 0;                // the path that left the factorisation (a batch may have overruled this context's own choice)
         hipStream_t st = cur_stream(ctx);
         fd_ctx::GraphKey rkey{};
-        rkey.M = ctx->M; rkey.kind = ctx->kind; rkey.term = ctx->term | (b.group_panels << 8); rkey.nparams = ctx->nparams;
+        rkey.M = ctx->M; rkey.kind = ctx->kind; rkey.term = ctx->term | (b.group_panels << 8) | (b.spd << 9); rkey.nparams = ctx->nparams;
         memcpy(rkey.params, ctx->params, sizeof(rkey.params));
         rkey.A = ctx->d_A; rkey.rest = ctx->d_rest; rkey.rec32 = ctx->d_rec32;
         if (ctx->use_graph && (!ctx->resolve_exec || memcmp(&rkey, &ctx->resolve_key, sizeof(rkey)) != 0)) {
@@ -572,6 +578,7 @@ int fd_build_async(fd_ctx *ctx)
         FD_HIP(ctx, hipEventRecord(ctx->ev1, st));
         ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
         ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
+        ctx->last_spd = b.spd != 0;
         ctx->build_pending = true;
         ctx->built = false;
         ctx->have_report = false;
@@ -587,7 +594,7 @@ int fd_build_async(fd_ctx *ctx)
         FD_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, sizeof(double) * (size_t)ctx->cap_npad * cols, cur_stream(ctx)));
     }
     fd_ctx::GraphKey key{};
-    key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term; key.nparams = ctx->nparams;
+    key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term | (b.spd << 9); key.nparams = ctx->nparams;
     memcpy(key.params, ctx->params, sizeof(key.params));
     key.A = ctx->d_A; key.rest = ctx->d_rest; key.rec32 = ctx->d_rec32;
     if (ctx->use_graph && (!ctx->build_exec || memcmp(&key, &ctx->graph_key, sizeof(key)) != 0)) {
@@ -622,6 +629,7 @@ int fd_build_async(fd_ctx *ctx)
     ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
     ctx->have_factor = b.ml_layers == 0;     // the multilayer model keeps no single factorisation to reuse
+    ctx->last_spd = b.spd != 0;
     ctx->factor_grouped = false;
     ctx->deltas_only = false;
     ctx->build_pending = true;
@@ -655,6 +663,17 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
         ctx->have_report = true;
         ctx->build_pending = false;
         ctx->built = r.terminationtype == 1;
+        // The Cholesky pivot of two nearly coincident centres is the SQUARE of what partial
+        // pivoting sees (1e-12 vs 2e-7 of the largest at 1e-7 apart), and a wide fixed-radius
+        // Gaussian loses definiteness to rounding before the LU gives up.  Nothing that the LU
+        // accepts may fail here: build again with it, and keep it for this rig.
+        if (r.terminationtype == -4 && ctx->last_spd && ctx->points_set) {
+            ctx->prefer_lu = true;
+            ctx->have_factor = false;
+            ctx->deltas_only = false;
+            if ((rc = fd_build_async(ctx))) return rc;
+            return fd_build_result(ctx, report);
+        }
     }
     if (!ctx->have_report) { set_err(ctx, "fd_build_result: no build has been enqueued"); return FD_E_NOT_BUILT; }
     if (report) *report = ctx->report;
@@ -1232,6 +1251,8 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     fill_build_buffers(c0, bb);
     bb.d_slots = b->d_slots;
     bb.nbatch = b->n;
+    for (int i = 0; i < b->n; ++i)
+        if (!use_spd(b->ctxs[i])) bb.spd = 0;        // one context that fell back to the LU takes the batch with it
     static const bool no_groups = getenv("FD_NO_PANEL_PAIRS") != nullptr;
     bb.group_panels = (b->n >= 4 && !no_groups && !getenv("FD_LOOKAHEAD")) ? 1 : 0;
     if (make_lookahead(&b->lu_stream, b->lu_events)) {
@@ -1240,7 +1261,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     }
 
     fd_batch::Key key{};
-    key.M = c0->M; key.kind = c0->kind; key.term = c0->term; key.nparams = c0->nparams;
+    key.M = c0->M; key.kind = c0->kind; key.term = c0->term | (bb.spd << 9); key.nparams = c0->nparams;
     memcpy(key.params, c0->params, sizeof(key.params));
     if (b->use_graph && (!b->exec || memcmp(&key, &b->key, sizeof(key)) != 0)) {
         if (b->exec) { (void)hipGraphExecDestroy(b->exec); b->exec = nullptr; }
@@ -1281,6 +1302,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         c->tev0 = b->ev0; c->tev_mid = b->ev_mid; c->tev1 = b->ev1;
         c->have_factor = bb.ml_layers == 0;   // a batched build leaves a factorisation fd_set_deltas can reuse (not the multilayer model)
         c->factor_grouped = bb.group_panels != 0;
+        c->last_spd = bb.spd != 0;
         c->deltas_only = false;
         c->build_pending = true;
         c->built = false;

@@ -82,7 +82,10 @@ enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
  * with a constant or linear term, the fixed-radius Gaussian with any term; lambda >= 0, M >= 16)
  * the polynomial constraints are eliminated with Householder reflectors and the projected kernel
  * block is Cholesky-factorised -- no pivot search; everything else (QNN radii make Phi
- * non-symmetric) goes through LU with partial pivoting.  LU forces the latter everywhere.  Both
+ * non-symmetric) goes through LU with partial pivoting.  LU forces the latter everywhere.  A
+ * system on which the Cholesky loses definiteness to rounding (centres one fp32 step apart, a
+ * fixed-radius Gaussian wider than the rig) is rebuilt with the LU before anything is reported,
+ * and the context keeps the LU until its kernel, term or M change: nothing the LU accepts fails.  Both
  * are fp64 direct solves of the same system: their weights agree to rounding (~1e-12 relative
  * on the benchmark rigs), far inside the parity tolerance. */
 enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1 };

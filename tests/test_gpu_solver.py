@@ -164,3 +164,52 @@ def test_resolve_and_batches_on_the_cholesky_path(hip_lib):
     b.close()
     for e in es:
         e.close()
+
+
+def test_nothing_the_lu_accepts_fails_on_the_cholesky_path(hip_lib, oracle):
+    """Two centres one fp32 step apart under the cubic kernel, and a fixed-radius Gaussian wider
+    than the rig: the Cholesky pivot falls under the threshold (it is the square of what partial
+    pivoting sees), the engine rebuilds with the LU and keeps it for the rig -- same weights as
+    FD_SOLVER_LU, bit for bit, also through fd_set_deltas and in a batch."""
+    M = 300
+    rest = synth.control_points(M, "head")
+    near = rest.copy(); near[17] = near[200] + np.float32(1e-7) * np.array([1, 0.5, -0.3], np.float32)
+    cases = [(capi.KERNEL_CUBIC, [], capi.TERM_LINEAR, near), (capi.KERNEL_GAUSSIAN, [1.2], capi.TERM_ZERO, rest)]
+    d0 = synth.smooth_deltas(rest, 0).astype(np.float32)
+    d1 = synth.smooth_deltas(rest, 1).astype(np.float32)
+    for kind, params, term, pts in cases:
+        auto = _engine(kind, params, term, pts, d0, capi.SOLVER_AUTO)
+        lu = _engine(kind, params, term, pts, d0, capi.SOLVER_LU)
+        ra, rl = auto.build(), lu.build()
+        assert ra.terminationtype == 1 and rl.terminationtype == 1
+        assert np.array_equal(auto.get_weights()[0], lu.get_weights()[0]), kind
+        auto.set_deltas(d1); lu.set_deltas(d1)                       # the stored factorisation is the LU's
+        assert auto.build().terminationtype == 1 and lu.build().terminationtype == 1
+        assert np.array_equal(auto.get_weights()[0], lu.get_weights()[0])
+        auto.set_points(pts, d0)                                       # sticky: no second failed attempt
+        assert auto.build().terminationtype == 1
+        auto.set_term(capi.TERM_CONST if term != capi.TERM_CONST else capi.TERM_LINEAR)   # a new system: the choice is made afresh
+        auto.set_term(term)
+        assert auto.build().terminationtype == 1
+        auto.close(); lu.close()
+    # in a batch: the context that falls back is rebuilt alone; its neighbours keep their results
+    dev = torch.device("cuda:0")
+    es = [capi.Engine() for _ in range(3)]
+    for e in es:
+        e.set_kernel(capi.KERNEL_CUBIC); e.set_term(capi.TERM_LINEAR)
+    pts = [rest, near, rest]
+    d_pts = [torch.from_numpy(p).to(dev) for p in pts]
+    d_del = [torch.from_numpy(synth.smooth_deltas(rest, f).astype(np.float32)).to(dev) for f in range(3)]
+    b = capi.Batch(es)
+    b.set_points_dev([t.data_ptr() for t in d_pts], [t.data_ptr() for t in d_del], M)
+    b.build_async()
+    assert all(r.terminationtype == 1 for r in b.build_result())
+    for f, e in enumerate(es):
+        ref = _engine(capi.KERNEL_CUBIC, [], capi.TERM_LINEAR, pts[f], synth.smooth_deltas(rest, f).astype(np.float32),
+                      capi.SOLVER_LU if f == 1 else capi.SOLVER_AUTO)
+        ref.build()
+        assert np.array_equal(ref.get_weights()[0], e.get_weights()[0]), f
+        ref.close()
+    b.close()
+    for e in es:
+        e.close()
