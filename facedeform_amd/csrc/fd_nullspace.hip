@@ -509,10 +509,6 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_first(const Bat
 }
 
 // ---- Cholesky: rows below the diagonal block ---------------------------------------------------
-// X L11^T = A21, one row per thread, L11 and the reciprocals of its diagonal from the side store.
-// Workgroups 0 .. nslab-1 take 256 matrix rows each (and mirror their result into the upper
-// triangle); workgroup nslab takes the three right-hand-side rows, which live transposed in the
-// RHS columns of A.  fd_set_deltas launches that last workgroup alone.
 // x <- x L11^-T in registers.  Right-looking: x_k is final once columns 0 .. k-1 have been applied;
 // its update of the columns to the right is 31-k independent fmas (a dot-product form would be one
 // dependent chain per element, and there is one wave per SIMD to hide it).  sL[k][c] = L11[c][k].
@@ -536,6 +532,11 @@ __device__ __forceinline__ void solve_row(double (&x)[kNB], const double (*sL)[k
     }
 }
 
+// X L11^T = A21, one row per thread, L11 and the reciprocals of its diagonal from the side store.
+// Workgroups 0 .. nslab-1 take 256 matrix rows each (and mirror their result into the upper
+// triangle); workgroup nslab takes the three right-hand-side rows, which live transposed in the
+// RHS columns of A, and inverts L11 with its second wave.  fd_set_deltas launches that last
+// workgroup alone.
 __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_solve(const BatchSlot *tab, int M, int lda, int npad, int npc, int k0, int nslab,
                                                                        int with_inverse)
 {
