@@ -56,6 +56,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNB = 32;                 // Cholesky block width
 constexpr int kSlab = 256;              // rows per workgroup of the panel's triangular solve
+constexpr int kStepSlab = 192;          // ... in the fused step kernel: three waves of rows, the fourth factorises
 
 // small block of the solver state, after V, W and B21 (each M x 4)
 constexpr int kTau = 0;                 // tau[4]
@@ -379,17 +380,16 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double &root, double &inv)
 
 constexpr int kLdsRow = kNB + 2;          // even: rows stay 16-byte aligned for ds_read_b128
 
-// The 32 x 32 block at (kb, kb): optionally its share of the trailing update of step kprev first
-// (C -= Lr Lr^T with Lr = rows kb .. kb+31 of that step's panel), then the factorisation by wave 0
-// -- rows in registers, columns right-looking, multipliers broadcast through LDS -- then L11 to
-// the side store (what the triangular solves read), into A below the diagonal, and mirrored above
-// it as the U = L^T the back-substitution kernels read.  256 threads, all of them must call.
-__device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda, int n1, int kb, int kprev,
-                                             double (*sC)[kLdsRow], double (*sR)[kLdsRow], double *sInv)
+// The 32 x 32 diagonal block at (kb, kb) goes through three stages, all on LDS copies:
+//   block_load_update  all 256 threads: the block and, after step kprev, its share of that step's
+//                      trailing update (C -= Lr Lr^T with Lr = rows kb .. kb+31 of that panel);
+//   factor_wave        one wave: rows in registers, columns right-looking, multipliers broadcast
+//                      through an LDS line;
+//   block_store        L11 to the side store (what the triangular solves and fd_set_deltas read),
+//                      and into A mirrored above the diagonal.
+__device__ __forceinline__ void block_load_update(gcdouble *A, int lda, int kb, int kprev, double (*sC)[kLdsRow],
+                                                  double (*sR)[kLdsRow])
 {
-    gdouble *A = as_global(s.A);
-    DevModel FD_GLOBAL *model = as_global(s.model);
-    __shared__ __attribute__((aligned(16))) double sCol[kNB];
     const int tid = threadIdx.x;
     for (int e = tid; e < kNB * kNB; e += 256) {
         const int r = e & 31, c = e >> 5;
@@ -416,87 +416,108 @@ __device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda,
         }
         __syncthreads();
     }
-    if (tid < 64) {
-        // Row i of the block lives in lanes i and i + 32: the lower half keeps the even columns,
-        // the upper half the odd ones (16 doubles each).  Column j, once scaled, goes through a
-        // 32-double LDS line ordered by row parity, so each half fetches the multipliers of ITS
-        // columns with 16-byte broadcast reads; one v_readlane pair per column (the diagonal) is
-        // all that is left on the scalar path.  (Broadcasting every multiplier with v_readlane
-        // cost three instructions and a hazard stall per fma: 4000 instructions per block.)
-        const int i = tid & 31, h = tid >> 5;
-        double a[kNB / 2];
+}
+
+// wave 0 only (tid < 64); `stats`: this workgroup reports pivots, progress and failure
+__device__ __forceinline__ void factor_wave(DevModel FD_GLOBAL *model, int n1, int kb, double (*sC)[kLdsRow], double *sInv,
+                                            double *sCol, bool stats)
+{
+    const int tid = threadIdx.x;
+    // Row i of the block lives in lanes i and i + 32: the lower half keeps the even columns,
+    // the upper half the odd ones (16 doubles each).  Column j, once scaled, goes through a
+    // 32-double LDS line ordered by row parity, so each half fetches the multipliers of ITS
+    // columns with 16-byte broadcast reads; one v_readlane pair per column (the diagonal) is
+    // all that is left on the scalar path.  (Broadcasting every multiplier with v_readlane
+    // cost three instructions and a hazard stall per fma: 4000 instructions per block.)
+    const int i = tid & 31, h = tid >> 5;
+    double a[kNB / 2];
 #pragma unroll
-        for (int kk = 0; kk < kNB / 2; ++kk) a[kk] = sC[i][2 * kk + h];
-        const double *colp = sCol + 16 * h;                   // L[2 kk + h][j] at colp[kk]
-        double *mine = sCol + 16 * (i & 1) + (i >> 1);        // L[i][j]
-        const double amax = __longlong_as_double((long long)model->amax_bits);
-        const double tiny = (double)n1 * kEps * amax;
-        double pmin = INFINITY, pmax = 0.0, myinv = 0.0;
-        bool singular = false;
-        // The diagonal of the NEXT column is formed ahead of the LDS round trip from two
-        // v_readlanes (its own old value and the multiplier l_{j+1,j}): the square-root chain of
-        // column j+1 then runs while column j's multipliers travel through LDS.  It is the same
-        // fma the owning lane performs on its register copy, so both hold the same bits.
-        double d = readlane_f64(a[0], 0);
+    for (int kk = 0; kk < kNB / 2; ++kk) a[kk] = sC[i][2 * kk + h];
+    const double *colp = sCol + 16 * h;                   // L[2 kk + h][j] at colp[kk]
+    double *mine = sCol + 16 * (i & 1) + (i >> 1);        // L[i][j]
+    const double amax = __longlong_as_double((long long)model->amax_bits);
+    const double tiny = (double)n1 * kEps * amax;
+    double pmin = INFINITY, pmax = 0.0, myinv = 0.0;
+    bool singular = false;
+    // The diagonal of the NEXT column is formed ahead of the LDS round trip from two
+    // v_readlanes (its own old value and the multiplier l_{j+1,j}): the square-root chain of
+    // column j+1 then runs while column j's multipliers travel through LDS.  It is the same
+    // fma the owning lane performs on its register copy, so both hold the same bits.
+    double d = readlane_f64(a[0], 0);
 #pragma unroll
-        for (int j = 0; j < kNB; ++j) {
-            const int hj = j & 1, jj = j >> 1;
-            const bool ok = d > tiny;            // false for NaN and for a lost definiteness
-            if (kb + j < n1) {
-                if (!ok) singular = true;
-                const double ad = fabs(d);
-                pmin = ad < pmin ? ad : pmin;
-                pmax = ad > pmax ? ad : pmax;
-            }
-            double root, inv;
-            sqrt_rsqrt(ok ? d : 1.0, root, inv);
-            if (!ok) inv = 0.0;
-            // lanes talk through the LDS line: to the compiler a store by one lane and a load by
-            // another are unrelated, so the order is pinned on both sides (no instructions: the
-            // wave executes its LDS operations in program order)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (h == hj) {
-                const double l = i == j ? root : a[jj] * inv;
-                a[jj] = l;
-                *mine = l;
-                if (i == j) myinv = inv;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (j + 1 < kNB) {
-                const int hn = (j + 1) & 1, jn = (j + 1) >> 1;
-                const double lnext = readlane_f64(a[jj], j + 1 + 32 * hj);       // l_{j+1,j}
-                const double dold = readlane_f64(a[jn], j + 1 + 32 * hn);         // a_{j+1,j+1} before this column
-                d = fma(-lnext, lnext, dold);
-            }
-            const double lij = *mine;
-            if (hj == 0 && h == 1) a[jj] = fma(-lij, colp[jj], a[jj]);   // column j + 1 sits in the other half
-#pragma unroll
-            for (int kk = jj + 1; kk < kNB / 2; ++kk) a[kk] = fma(-lij, colp[kk], a[kk]);
+    for (int j = 0; j < kNB; ++j) {
+        const int hj = j & 1, jj = j >> 1;
+        const bool ok = d > tiny;            // false for NaN and for a lost definiteness
+        if (kb + j < n1) {
+            if (!ok) singular = true;
+            const double ad = fabs(d);
+            pmin = ad < pmin ? ad : pmin;
+            pmax = ad > pmax ? ad : pmax;
         }
+        double root, inv;
+        sqrt_rsqrt(ok ? d : 1.0, root, inv);
+        if (!ok) inv = 0.0;
+        // lanes talk through the LDS line: to the compiler a store by one lane and a load by
+        // another are unrelated, so the order is pinned on both sides (no instructions: the
+        // wave executes its LDS operations in program order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (h == hj) {
+            const double l = i == j ? root : a[jj] * inv;
+            a[jj] = l;
+            *mine = l;
+            if (i == j) myinv = inv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (j + 1 < kNB) {
+            const int hn = (j + 1) & 1, jn = (j + 1) >> 1;
+            const double lnext = readlane_f64(a[jj], j + 1 + 32 * hj);       // l_{j+1,j}
+            const double dold = readlane_f64(a[jn], j + 1 + 32 * hn);         // a_{j+1,j+1} before this column
+            d = fma(-lnext, lnext, dold);
+        }
+        const double lij = *mine;
+        if (hj == 0 && h == 1) a[jj] = fma(-lij, colp[jj], a[jj]);   // column j + 1 sits in the other half
 #pragma unroll
-        for (int kk = 0; kk < kNB / 2; ++kk) sC[i][2 * kk + h] = a[kk];
-        if (h == (i & 1)) sInv[i] = myinv;
-        if (tid == 0) {
-            model->iterations = kb + kNB < n1 ? kb + kNB : n1;
-            if (singular) model->sing_flag = 1;
-            if (pmax > 0.0 || pmin < INFINITY) {
-                atomicMin((unsigned long long *)&model->pivmin_bits, (unsigned long long)__double_as_longlong(pmin));
-                atomicMax((unsigned long long *)&model->pivmax_bits, (unsigned long long)__double_as_longlong(pmax));
-            }
+        for (int kk = jj + 1; kk < kNB / 2; ++kk) a[kk] = fma(-lij, colp[kk], a[kk]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kNB / 2; ++kk) sC[i][2 * kk + h] = a[kk];
+    if (h == (i & 1)) sInv[i] = myinv;
+    if (stats && tid == 0) {
+        model->iterations = kb + kNB < n1 ? kb + kNB : n1;
+        if (singular) model->sing_flag = 1;
+        if (pmax > 0.0 || pmin < INFINITY) {
+            atomicMin((unsigned long long *)&model->pivmin_bits, (unsigned long long)__double_as_longlong(pmin));
+            atomicMax((unsigned long long *)&model->pivmax_bits, (unsigned long long)__double_as_longlong(pmax));
         }
     }
-    __syncthreads();
+}
+
+__device__ __forceinline__ void block_store(const BatchSlot &s, int M, int lda, int kb, const double (*sC)[kLdsRow],
+                                            const double *sInv, bool into_A)
+{
+    gdouble *A = as_global(s.A);
     gdouble *Ld = ld_block(s.ns, M, kb);
+    const int tid = threadIdx.x;
     for (int e = tid; e < kNB * kNB; e += 256) {
         const int r = e & 31, c = e >> 5;
         const double l = r >= c ? sC[r][c] : sC[c][r];
         Ld[e] = r >= c ? l : 0.0;
-        A[(size_t)(kb + c) * lda + kb + r] = l;
+        if (into_A) A[(size_t)(kb + c) * lda + kb + r] = l;
     }
     if (tid < kNB) Ld[kNB * kNB + tid] = sInv[tid];
+}
+
+__device__ __forceinline__ void factor_block(const BatchSlot &s, int M, int lda, int n1, int kb, int kprev,
+                                             double (*sC)[kLdsRow], double (*sR)[kLdsRow], double *sInv)
+{
+    __shared__ __attribute__((aligned(16))) double sCol[kNB];
+    block_load_update(as_global(s.A), lda, kb, kprev, sC, sR);
+    if (threadIdx.x < 64) factor_wave(as_global(s.model), n1, kb, sC, sInv, sCol, true);
+    __syncthreads();
+    block_store(s, M, lda, kb, sC, sInv, true);
 }
 
 // the first diagonal block has no trailing update before it
@@ -509,6 +530,17 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_first(const Bat
 }
 
 // ---- Cholesky: rows below the diagonal block ---------------------------------------------------
+// Element `byte_off` of a wave-uniform column: the pointer is pinned into SGPRs so that the access
+// is scalar base + one 32-bit lane offset.  Left alone, the compiler folds 32 such columns into 32
+// per-lane 64-bit addresses and keeps them all alive between the loads and the stores.
+__device__ __forceinline__ gdouble *pinned_column(gdouble *col, unsigned byte_off)
+{
+    const unsigned long long p = (unsigned long long)col;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+    return (gdouble *)((char FD_GLOBAL *)(((unsigned long long)hi << 32) | lo) + byte_off);
+}
+
 // x <- x L11^-T in registers.  Right-looking: x_k is final once columns 0 .. k-1 have been applied;
 // its update of the columns to the right is 31-k independent fmas (a dot-product form would be one
 // dependent chain per element, and there is one wave per SIMD to hide it).  sL[k][c] = L11[c][k].
@@ -760,6 +792,183 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_trail(const Bat
     }
 }
 
+// ---- Cholesky: one fused step --------------------------------------------------------------------
+// Panel k0 is solved; this kernel does everything up to and including the solve of panel
+// kb = k0 + 32 -- one launch per 32 columns instead of two, and the factor never leaves LDS:
+//   panel workgroups (blockIdx.x < npanel; 192 rows each, the last one the right-hand sides):
+//     - the diagonal block (kb, kb) with panel k0's update applied, in LDS, EVERY workgroup for
+//       itself: the redundant factorisations run side by side, nobody waits for anybody;
+//     - wave 0 factorises it while waves 1..3 apply panel k0 to the workgroup's own rows of
+//       columns kb .. kb+31 (one A operand serves both 16-column blocks);
+//     - then X L11^T = A21 on those rows, L11 read from LDS.  The right-hand-side workgroup also
+//       files L11 in the side store and inverts it (for fd_set_deltas and the back-substitution);
+//   the other workgroups: the trailing update of the columns from kb + 32 on, as k_chol_trail.
+// Nothing here waits on a flag: every dependency is inside one workgroup or across the launch.
+__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const BatchSlot *tab, int M, int lda, int npad, int npc, int n1,
+                                                                      int k0, int nchunk, int npanel)
+{
+    const BatchSlot &slot = tab[blockIdx.z];
+    gdouble *A = as_global(slot.A);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int kb = k0 + kNB;
+    constexpr int S = kNB / 4;
+    __builtin_amdgcn_s_setprio(3);
+
+    if ((int)blockIdx.x >= npanel) {
+        // trailing update of column block cb >= 2 (columns kb + 32 ..)
+        const int cbid = (int)blockIdx.x - npanel;
+        const int cb = 2 + cbid / nchunk, chunk = cbid % nchunk;
+        const int c0 = kb + cb * 16;
+        double u[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) u[s] = -A[(size_t)(k0 + g + 4 * s) * lda + c0 + c];
+        const int mtiles = (npc - c0) / 16;               // index mtiles = RHS tile
+        const int stride = 4 * nchunk;
+        for (int t0 = chunk * 4 + wave; t0 <= mtiles; t0 += 2 * stride) {
+            const int t1 = t0 + stride;
+            const bool two = t1 <= mtiles;
+            gdouble *cp[2];
+            size_t rs[2];
+            double av[2][S];
+            double4_t acc[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int t = q == 0 ? t0 : (two ? t1 : t0);
+                if (t < mtiles) {
+                    const int r0 = c0 + t * 16;
+                    cp[q] = A + (size_t)(c0 + c) * lda + r0 + g;
+                    rs[q] = 4;
+                    gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) av[q][s] = aptr[(size_t)(4 * s) * lda];
+                } else {
+                    cp[q] = A + (size_t)(npad + g) * lda + c0 + c;
+                    rs[q] = (size_t)4 * lda;
+                    gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) av[q][s] = aptr[4 * s];
+                }
+                acc[q][0] = cp[q][0]; acc[q][1] = cp[q][rs[q]]; acc[q][2] = cp[q][2 * rs[q]]; acc[q][3] = cp[q][3 * rs[q]];
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][s], u[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][s], u[s], acc[1], 0, 0, 0);
+            }
+            cp[0][0] = acc[0][0]; cp[0][rs[0]] = acc[0][1]; cp[0][2 * rs[0]] = acc[0][2]; cp[0][3 * rs[0]] = acc[0][3];
+            if (two) { cp[1][0] = acc[1][0]; cp[1][rs[1]] = acc[1][1]; cp[1][2 * rs[1]] = acc[1][2]; cp[1][3 * rs[1]] = acc[1][3]; }
+        }
+        return;
+    }
+
+    // ---- panel workgroup: wave 0 factorises; waves 1..3 own 64 rows each -- they apply panel k0 to
+    // them, fetch them back into registers (no workgroup barrier in between: a wave reads what it
+    // wrote) and solve them once L11 is there
+    __shared__ __attribute__((aligned(16))) double sC[kNB][kLdsRow];
+    __shared__ __attribute__((aligned(16))) double sR[kNB][kLdsRow];
+    __shared__ __attribute__((aligned(16))) double sCol[kNB];
+    __shared__ double sInv[kNB];
+    const bool rhs = (int)blockIdx.x == npanel - 1;
+    const int slab0 = kb + kNB + (int)blockIdx.x * kStepSlab;   // first row of a matrix slab
+    block_load_update(A, lda, kb, k0, sC, sR);
+    __syncthreads();                          // sR (the rows of panel k0) is free from here on
+
+    double x[kNB];
+    bool active = false, invert = false;
+    const int unit = tid - 128;               // RHS workgroup, third wave: row `unit` of the identity
+    const int grow = slab0 + (tid - 64);      // matrix slab: waves 1..3 <-> rows slab0 .. slab0 + 191
+    if (wave == 0) {
+        factor_wave(as_global(slot.model), n1, kb, sC, sInv, sCol, rhs);
+        // L11^T for the solves: column k of L11 contiguous, zeros above the diagonal
+        const int i = tid & 31, h = tid >> 5;
+#pragma unroll
+        for (int kk = 0; kk < kNB / 2; ++kk) { const int k = 2 * kk + h; sR[k][i] = i >= k ? sC[i][k] : 0.0; }
+    } else {
+        double u0[S], u1[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            u0[s] = -A[(size_t)(k0 + g + 4 * s) * lda + kb + c];
+            u1[s] = -A[(size_t)(k0 + g + 4 * s) * lda + kb + 16 + c];
+        }
+        const int wrow0 = slab0 + (wave - 1) * 64;             // my wave's first row
+        const int ntr = rhs ? (wave == 1 ? 1 : 0) : ((npc - wrow0 < 64 ? (npc - wrow0 > 0 ? npc - wrow0 : 0) : 64) / 16);
+        for (int rt = 0; rt < ntr; ++rt) {
+            gdouble *cp0, *cp1;
+            size_t rs;
+            double av[S];
+            if (!rhs) {
+                const int r0 = wrow0 + rt * 16;
+                cp0 = A + (size_t)(kb + c) * lda + r0 + g;
+                cp1 = cp0 + (size_t)16 * lda;
+                rs = 4;
+                gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
+#pragma unroll
+                for (int s = 0; s < S; ++s) av[s] = aptr[(size_t)(4 * s) * lda];
+            } else {
+                cp0 = A + (size_t)(npad + g) * lda + kb + c;
+                cp1 = cp0 + 16;
+                rs = (size_t)4 * lda;
+                gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
+#pragma unroll
+                for (int s = 0; s < S; ++s) av[s] = aptr[4 * s];
+            }
+            double4_t acc0, acc1;
+            acc0[0] = cp0[0]; acc0[1] = cp0[rs]; acc0[2] = cp0[2 * rs]; acc0[3] = cp0[3 * rs];
+            acc1[0] = cp1[0]; acc1[1] = cp1[rs]; acc1[2] = cp1[2 * rs]; acc1[3] = cp1[3 * rs];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], u0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], u1[s], acc1, 0, 0, 0);
+            }
+            cp0[0] = acc0[0]; cp0[rs] = acc0[1]; cp0[2 * rs] = acc0[2]; cp0[3 * rs] = acc0[3];
+            cp1[0] = acc1[0]; cp1[rs] = acc1[1]; cp1[2 * rs] = acc1[2]; cp1[3 * rs] = acc1[3];
+        }
+        // my wave's rows are complete in memory: other lanes of this wave wrote them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (!rhs) {
+            active = grow < npc;
+            if (active) {
+#pragma unroll
+                for (int cc = 0; cc < kNB; ++cc) x[cc] = *pinned_column(A + (size_t)(kb + cc) * lda, 8u * (unsigned)grow);
+            }
+        } else if (wave == 1) {
+            active = lane < 3;
+            gcdouble *rowp = A + (size_t)(npad + (active ? lane : 0)) * lda + kb;
+#pragma unroll
+            for (int cc = 0; cc < kNB; ++cc) x[cc] = rowp[cc];
+        } else if (wave == 2) {
+            invert = unit >= 0 && unit < kNB;
+#pragma unroll
+            for (int cc = 0; cc < kNB; ++cc) x[cc] = cc == unit ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();                          // L11 (sC), L11^T (sR) and 1 / diag (sInv) are in LDS
+    if (rhs) block_store(slot, M, lda, kb, sC, sInv, false);
+    if (!active && !invert) return;
+    solve_row(x, sR, sInv);
+    if (invert) {
+        gdouble *inv = ld_block(slot.ns, M, kb) + kLdInv;
+#pragma unroll
+        for (int cc = 0; cc < kNB; ++cc) inv[cc * kNB + unit] = x[cc];
+        return;
+    }
+    if (rhs) {
+        gdouble *rowp = A + (size_t)(npad + lane) * lda + kb;
+#pragma unroll
+        for (int cc = 0; cc < kNB; ++cc) rowp[cc] = x[cc];
+        return;
+    }
+#pragma unroll
+    for (int cc = 0; cc < kNB; ++cc) *pinned_column(A + (size_t)(kb + cc) * lda, 8u * (unsigned)grow) = x[cc];
+    gdouble *up = A + (size_t)grow * lda + kb;             // mirrored: U[kb+cc][grow] = L[grow][kb+cc]
+#pragma unroll
+    for (int cc = 0; cc < kNB; ++cc) up[cc] = x[cc];
+}
+
 // ---- recover a and w ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ns_recover(const BatchSlot *tab, int M, int T, int npad)
 {
@@ -918,19 +1127,32 @@ __global__ void k_ml_finish(const BatchSlot *tab, int M, int T, int L)
 void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, int rhs_only)
 {
     const unsigned nb = (unsigned)b.nbatch;
+    static const bool unfused = getenv("FD_CHOL_UNFUSED") != nullptr;      // A/B: two launches per step
     if (!rhs_only) hipLaunchKernelGGL(k_chol_first, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, n1);
     for (int k0 = 0; k0 < npc; k0 += kNB) {
         const int below = npc - k0 - kNB;
-        const int nslab = rhs_only ? 0 : (below + kSlab - 1) / kSlab;
-        hipLaunchKernelGGL(k_chol_solve, dim3(nslab + 1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
-                           k0, nslab, rhs_only ? 0 : 1);
-        if (below > 0) {
-            const int ncb = below / 16;
+        if (rhs_only || unfused || k0 == 0) {
+            const int nslab = rhs_only ? 0 : (below + kSlab - 1) / kSlab;
+            hipLaunchKernelGGL(k_chol_solve, dim3(nslab + 1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
+                               k0, nslab, rhs_only ? 0 : 1);
+        }
+        if (below <= 0) break;
+        const int ncb = below / 16;
+        if (rhs_only || unfused) {
             // enough workgroups to cover the device while the trailing matrix is large
             int nchunk = rhs_only ? 1 : (ncb + 15) / 16;
             nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
             hipLaunchKernelGGL(k_chol_trail, dim3(ncb * nchunk + (rhs_only ? 0 : 1), 1, nb), dim3(256), 0, stream, b.d_slots,
                                b.M, b.lda, b.npad, npc, n1, k0, nchunk, rhs_only);
+        } else {
+            // fused: this launch also factorises block k0 + 32 and solves its panel
+            const int below_next = below - kNB;
+            const int npanel = (below_next + kStepSlab - 1) / kStepSlab + 1;
+            int nchunk = (ncb + 15) / 16;
+            nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
+            const int nreg = ncb > 2 ? (ncb - 2) * nchunk : 0;
+            hipLaunchKernelGGL(k_chol_step, dim3(npanel + nreg, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
+                               n1, k0, nchunk, npanel);
         }
     }
 }
