@@ -761,7 +761,7 @@ __device__ __forceinline__ double block_max(double v, double *scratch, int tid)
 
 // one 128-VGPR slot: the kernel runs beside the evaluation of earlier frames (fd_nullspace.hip, FD_FIT_BESIDE_EVAL)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_pack(const BatchSlot *tab, int npad, int M, int Mpad, int T, int kind,
-                                              int from_w)
+                                              int from_w, int layers)
 {
     const BatchSlot &slot = tab[blockIdx.z];
     const double *X = from_w ? nullptr : slot.X;
@@ -841,8 +841,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 m[5 * c + 4] += w[c] * cc2;
             }
         }
-        rec32[j] = r32;
-        rec64[j] = r64;
+        // multilayer model: W is layer-major (record l * Mc + c), the evaluation wants the layers of
+        // a centre side by side (c * layers + l) so that they can share its distances
+        int jo = j;
+        if (layers > 1 && j < M) { const int Mc = M / layers; jo = (j % Mc) * layers + j / Mc; }
+        rec32[jo] = r32;
+        rec64[jo] = r64;
     }
 #pragma unroll
     for (int q = 0; q < 15; ++q) m[q] = block_sum(m[q], s_red, tid);
@@ -1206,23 +1210,23 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
 hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream)
 {
     const unsigned nb = (unsigned)b.nbatch;
-    hipLaunchKernelGGL(k_pack, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.npad, b.M, b.Mpad, b.T, b.kind, 0);
+    hipLaunchKernelGGL(k_pack, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.npad, b.M, b.Mpad, b.T, b.kind, 0, 0);
     if (b.kind == FD_KERNEL_THIN_PLATE)
         hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16, 1, nb), dim3(64), 0, stream, b.d_slots, b.Mpad);
     return hipGetLastError();
 }
 
-hipError_t launch_pack_records(const BuildBuffers &b, hipStream_t stream, int records, int kind, int mode)
+hipError_t launch_pack_records(const BuildBuffers &b, hipStream_t stream, int records, int kind, int mode, int layers)
 {
     hipLaunchKernelGGL(k_pack, dim3(1, 1, (unsigned)b.nbatch), dim3(256), 0, stream, b.d_slots, b.npad, records,
-                       round_up(records, kRecPad), b.T, kind, mode);
+                       round_up(records, kRecPad), b.T, kind, mode, layers);
     return hipGetLastError();
 }
 
-hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream)
+hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream, int layers)
 {
     const unsigned nb = (unsigned)b.nbatch;
-    hipLaunchKernelGGL(k_pack, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.npad, b.M, b.Mpad, b.T, b.kind, 1);
+    hipLaunchKernelGGL(k_pack, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.npad, b.M, b.Mpad, b.T, b.kind, 1, layers);
     if (b.kind == FD_KERNEL_THIN_PLATE)
         hipLaunchKernelGGL(k_pack_tiles, dim3(b.Mpad / 16, 1, nb), dim3(64), 0, stream, b.d_slots, b.Mpad);
     return hipGetLastError();

@@ -18,6 +18,7 @@ struct fd_ctx {
     int eval_precision = FD_EVAL_FP32;
     int eval_variant = 0;
     int solver = FD_SOLVER_AUTO;
+    int imported_layers = 0;         // a multilayer model that came in through fd_import_model
     bool prefer_lu = false;          // the Cholesky path lost definiteness on this rig: LU until kernel, term or M change
     bool last_spd = false;           // the build in flight / last finished took the Cholesky path
 
@@ -175,6 +176,8 @@ static int ml_layers(const fd_ctx *ctx) { return ctx->kind == FD_KERNEL_GAUSSIAN
 // Gaussian records of the solved model, and the kernel the evaluation sees
 static int model_centres(const fd_ctx *ctx) { return ctx->kind == FD_KERNEL_GAUSSIAN_ML ? ctx->M * ml_layers(ctx) : ctx->M; }
 static int eval_kind(const fd_ctx *ctx) { return ctx->kind == FD_KERNEL_GAUSSIAN_ML ? FD_KERNEL_GAUSSIAN_QNN : ctx->kind; }
+// layers per centre in the evaluation records (built here or imported); 0 = a flat model
+static int record_layers(const fd_ctx *ctx) { return ctx->kind == FD_KERNEL_GAUSSIAN_ML ? ml_layers(ctx) : ctx->imported_layers; }
 
 // the solved model's arrays: one entry per Gaussian record (= per centre, times the layers of the
 // multilayer model).  Everything in them is produced by a build or an import, so growing them loses nothing.
@@ -474,6 +477,7 @@ int fd_set_kernel(fd_ctx *ctx, int kind, const double *params, int nparams)
     ctx->kind = kind;
     ctx->nparams = nparams;
     memcpy(ctx->params, p, sizeof(p));
+    ctx->imported_layers = 0;
     ctx->prefer_lu = false;
     ctx->built = false;
     ctx->build_pending = false;
@@ -539,6 +543,7 @@ int fd_build_async(fd_ctx *ctx)
 {
     if (!ctx) return FD_E_INVALID;
     if (!ctx->points_set) { set_err(ctx, "fd_build: fd_set_points has not been called"); return FD_E_INVALID; }
+    ctx->imported_layers = 0;        // whatever was imported is about to be replaced
     int rc = use_device(ctx);
     if (rc) return rc;
     const int npad = round_up(order_of(ctx), 32);
@@ -721,7 +726,7 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
     a.dist2 = d_dist2; a.falloff_out = d_falloff_out;
     a.tu = d_tu; a.tv = d_tv; a.nrm = d_nrm;
     a.radius2 = radius2; a.falloffrate = falloffrate;
-    a.M = model_centres(ctx); a.Mpad = round_up(a.M, kRecPad); a.kind = eval_kind(ctx);
+    a.M = model_centres(ctx); a.Mpad = round_up(a.M, kRecPad); a.kind = eval_kind(ctx); a.layers = record_layers(ctx);
     a.rec32 = ctx->d_rec32; a.rec64 = ctx->d_rec64; a.tiles = ctx->d_tiles; a.tiles16 = ctx->d_tiles16;
     a.model = ctx->d_model;
     a.precision = ctx->eval_precision;
@@ -1057,6 +1062,7 @@ int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device)
     h->magic = kModelMagic;
     h->M = M; h->kind = eval_kind(ctx); h->term = ctx->term; h->nparams = ctx->nparams;
     h->terminationtype = 1;
+    h->layers = record_layers(ctx);
     memcpy(h->params, ctx->params, sizeof(h->params));
     char *p = (char *)buf;
     const hipMemcpyKind kh = on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
@@ -1086,13 +1092,15 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
         memcpy(&h, buf, sizeof(h));
     }
     if (h.magic != kModelMagic || h.M <= 0 || h.M > kMaxOrder * kMaxLayers || h.kind < 0 || h.kind > FD_KERNEL_CUBIC ||
-        h.term < 0 || h.term > 2 || h.terminationtype != 1 || bytes < model_bytes_for(h.M)) {
+        h.term < 0 || h.term > 2 || h.terminationtype != 1 || bytes < model_bytes_for(h.M) ||
+        h.layers < 0 || h.layers > kMaxLayers || (h.layers > 1 && h.M % h.layers != 0)) {
         set_err(ctx, "fd_import_model: not a valid model blob");
         return FD_E_INVALID;
     }
     const int M = h.M;
     if ((rc = ensure_model_capacity(ctx, M))) return rc;
     ctx->M = M; ctx->kind = h.kind; ctx->term = h.term; ctx->nparams = h.nparams;
+    ctx->imported_layers = h.layers > 1 ? h.layers : 0;
     memcpy(ctx->params, h.params, sizeof(h.params));
     const char *p = (const char *)buf + sizeof(ModelHeader);
     const hipMemcpyKind kd = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1104,7 +1112,7 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     if ((rc = sync_slot(ctx))) return rc;
     BuildBuffers b;
     fill_build_buffers(ctx, b);
-    FD_HIP(ctx, launch_pack_from_weights(b, cur_stream(ctx)));
+    FD_HIP(ctx, launch_pack_from_weights(b, cur_stream(ctx), ctx->imported_layers));
     ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
     if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     ctx->have_factor = false;
@@ -1218,6 +1226,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];
         if (!c->points_set) { batch_err(b, "fd_batch_build: context %d has no control points", i); return FD_E_INVALID; }
+        c->imported_layers = 0;
         if (c->M != c0->M || c->kind != c0->kind || c->term != c0->term || c->nparams != c0->nparams ||
             memcmp(c->params, c0->params, sizeof(c->params)) != 0) {
             batch_err(b, "fd_batch_build: context %d differs from context 0 in M, kernel, parameters or term", i);
@@ -1353,7 +1362,7 @@ int fd_batch_deform_dev(fd_batch *b, void *hip_stream, int64_t N, const float *c
         a.dist2 = d_dist2 ? d_dist2[i] : nullptr; a.falloff_out = d_falloff_out ? d_falloff_out[i] : nullptr;
         a.tu = tu; a.tv = tv; a.nrm = nr;
         a.radius2 = radius2; a.falloffrate = falloffrate;
-        a.M = model_centres(c); a.Mpad = round_up(a.M, kRecPad); a.kind = eval_kind(c);
+        a.M = model_centres(c); a.Mpad = round_up(a.M, kRecPad); a.kind = eval_kind(c); a.layers = record_layers(c);
         a.rec32 = c->d_rec32; a.rec64 = c->d_rec64; a.tiles = c->d_tiles; a.tiles16 = c->d_tiles16;
         a.model = c->d_model;
         a.precision = c->eval_precision;

@@ -233,7 +233,7 @@ __device__ __forceinline__ f32x2 phi32(f32x2 d2, float s)
 }
 
 // V vertices per lane in Q = V / W registers; vertex v sits in register v / W, component v % W
-template <int KIND, int V, bool USE_LDS, typename LaneT>
+template <int KIND, int V, bool USE_LDS, typename LaneT, int SHARE = 1>
 __device__ __forceinline__ void deform32_body(const EvalParams &p)
 {
     using L = Lanes<LaneT>;
@@ -358,7 +358,46 @@ __device__ __forceinline__ void deform32_body(const EvalParams &p)
                 for (int q = 0; q < Q; ++q) az[q] = vfma(t[q], L::splat(wz), az[q]);
             }
         };
+        // Multilayer Gaussian model (records centre-major: the SHARE layers of one centre are
+        // consecutive): the squared distances of a centre are formed once and every layer takes
+        // its own exponent of them -- 3 + 4 SHARE issue slots per centre instead of 7 SHARE.
+        LaneT sd2[Q];
+        auto consume2 = [&](const Ctr g0, const Ctr g1, bool new_centre) {
+            if (new_centre) {
+                LaneT dx[Q], dy[Q], dz[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) dx[q] = px[q] - g0.cx;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) dy[q] = py[q] - g0.cy;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) dz[q] = pz[q] - g0.cz;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) sd2[q] = vfma(dx[q], dx[q], bias);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) sd2[q] = vfma(dy[q], dy[q], sd2[q]);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) sd2[q] = vfma(dz[q], dz[q], sd2[q]);
+            }
+            LaneT t0[Q], t1[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) t0[q] = phi32<KIND>(sd2[q], g0.s);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) t1[q] = phi32<KIND>(sd2[q], g1.s);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) ax[q] = vfma(t0[q], L::splat(g0.wx), ax[q]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) ay[q] = vfma(t0[q], L::splat(g0.wy), ay[q]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) az[q] = vfma(t0[q], L::splat(g0.wz), az[q]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) ax[q] = vfma(t1[q], L::splat(g1.wx), ax[q]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) ay[q] = vfma(t1[q], L::splat(g1.wy), ay[q]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) az[q] = vfma(t1[q], L::splat(g1.wz), az[q]);
+        };
         static_assert(kGroup == 2 && kRecPad % 8 == 0, "four stages of two records per iteration");
+        static_assert(SHARE == 1 || SHARE == 2 || SHARE == 4 || SHARE == 8, "layers that share a centre's distances");
         // Four stages per iteration; each requests the next pair of records before it consumes
         // the current pair.  Scalar loads return out of order, so every wait on them is
         // lgkmcnt(0): the wait for the pair about to be consumed comes BEFORE the next request,
@@ -367,18 +406,19 @@ __device__ __forceinline__ void deform32_body(const EvalParams &p)
         // before the data lands (seen in the ISA: an in-flight destination reused as an address
         // -> memory fault).  hipcc sinks only the loop-carried request to the latch, so three
         // of the four stages overlap their fetch with arithmetic.
-#define FD_STAGE(N0, N1, JJ, C0, C1)                                          \
+#define FD_STAGE(N0, N1, JJ, C0, C1, ST)                                      \
         if constexpr (!USE_LDS) __builtin_amdgcn_s_waitcnt(0xc07f);           \
         N0 = fetch(JJ); N1 = fetch((JJ) + 1);                                 \
         __builtin_amdgcn_sched_barrier(0);                                    \
-        consume1(C0); consume1(C1);
+        if constexpr (SHARE == 1) { consume1(C0); consume1(C1); }             \
+        else consume2(C0, C1, (2 * (ST)) % SHARE == 0);
         Ctr a0 = fetch(0), a1 = fetch(1), b0, b1, c0, c1, d0, d1;
         for (int j = 0; j < p.Mpad; j += 8) {
-            FD_STAGE(b0, b1, j + 2, a0, a1)
-            FD_STAGE(c0, c1, j + 4, b0, b1)
-            FD_STAGE(d0, d1, j + 6, c0, c1)
+            FD_STAGE(b0, b1, j + 2, a0, a1, 0)
+            FD_STAGE(c0, c1, j + 4, b0, b1, 1)
+            FD_STAGE(d0, d1, j + 6, c0, c1, 2)
             const int jn = (j + 8 < p.Mpad) ? j + 8 : j;   // the last pass re-reads its own records
-            FD_STAGE(a0, a1, jn, d0, d1)
+            FD_STAGE(a0, a1, jn, d0, d1, 3)
             if (((j + 8) & (kChunk - 1)) == 0 || j + 8 >= p.Mpad) flush();
         }
 #undef FD_STAGE
@@ -400,10 +440,10 @@ __device__ __forceinline__ void deform32_body(const EvalParams &p)
     }
 }
 
-template <int KIND, int V, bool USE_LDS, typename LaneT>
+template <int KIND, int V, bool USE_LDS, typename LaneT, int SHARE = 1>
 __global__ __launch_bounds__(kBlock) void k_deform32(const EvalParams p)
 {
-    deform32_body<KIND, V, USE_LDS, LaneT>(p);
+    deform32_body<KIND, V, USE_LDS, LaneT, SHARE>(p);
 }
 
 // several frames in one launch (the default variant only: packed lanes, scalar-loaded records, V = 4)
@@ -793,6 +833,24 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
             return hipGetLastError();
         } else {
             variant = kDefaultVariant;   // the matrix-pipe path exists for thin-plate only
+        }
+    }
+    if constexpr (KIND == FD_KERNEL_GAUSSIAN) {
+        // multilayer model, default kernel: the layers of a centre share its distances (the
+        // records come centre-major from k_pack, layers a multiple of the share)
+        if (a.variant <= 0 && a.layers >= 2 && a.layers % 2 == 0) {
+            const int64_t per = (int64_t)kBlock * 4;
+            const unsigned grid = (unsigned)((a.N + per - 1) / per);
+            const unsigned share = (grid + kNumCU - 1) / kNumCU;
+            const bool bal = getenv("FD_NO_BALANCE") == nullptr;
+            const size_t dyn = (bal && share >= 3 && share <= 8) ? (((160u * 1024u) / share) & ~1023u) : 0;
+            if (a.layers % 8 == 0)
+                hipLaunchKernelGGL((k_deform32<KIND, 4, false, f32x2, 8>), dim3(grid), dim3(kBlock), dyn, stream, p);
+            else if (a.layers % 4 == 0)
+                hipLaunchKernelGGL((k_deform32<KIND, 4, false, f32x2, 4>), dim3(grid), dim3(kBlock), dyn, stream, p);
+            else
+                hipLaunchKernelGGL((k_deform32<KIND, 4, false, f32x2, 2>), dim3(grid), dim3(kBlock), dyn, stream, p);
+            return hipGetLastError();
         }
     }
     const size_t lds_bytes = (size_t)a.Mpad * sizeof(Rec32);

@@ -82,7 +82,8 @@ struct ModelHeader {
     uint32_t magic;        // 'FDM1'
     int32_t M, kind, term, nparams;
     int32_t terminationtype;
-    int32_t reserved[2];
+    int32_t layers;        // multilayer Gaussian model: records per centre (the blob's arrays are layer-major); 0 otherwise
+    int32_t reserved;
     double params[4];
 };
 constexpr uint32_t kModelMagic = 0x314D4446u;
@@ -154,13 +155,13 @@ hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const Point
 hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
 hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 hipError_t launch_pack(const BuildBuffers &b, hipStream_t stream);
-hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream);
+hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream, int layers = 0);
 // pieces of the LU pipeline the null-space path reuses: the kernel block alone (order M, identity
 // padding to npad_a) and back-substitution with the upper triangle over rows [0, rows)
 hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a, int radii_off = 0);
 // k_pack over `records` centres whose weights are already in W (mode 1: imported model, status from
 // the values alone; mode 2: built here, the factorisation's flags count too)
-hipError_t launch_pack_records(const BuildBuffers &b, hipStream_t stream, int records, int kind, int mode);
+hipError_t launch_pack_records(const BuildBuffers &b, hipStream_t stream, int records, int kind, int mode, int layers);
 hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int rows);
 hipError_t launch_prepare_rhs(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 hipError_t launch_backsub_update(const BuildBuffers &b, hipStream_t stream, int row_lo, int w);
@@ -187,6 +188,7 @@ struct DeformArgs {
     const MfmaTileH *tiles16;
     const DevModel *model;
     int precision, variant;
+    int layers;            // multilayer Gaussian model: records are centre-major, `layers` per centre; 0 otherwise
 };
 hipError_t launch_deform(const DeformArgs &a, hipStream_t stream);
 hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream);

@@ -1241,7 +1241,7 @@ hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t
                            l + 1 == L ? 1 : 0, b.lambda);
     }
     hipLaunchKernelGGL(k_ml_finish, dim3(1, 1, nb), dim3(64), 0, stream, b.d_slots, M, T, L);
-    return launch_pack_records(b, stream, M * L, FD_KERNEL_GAUSSIAN_QNN, 2);
+    return launch_pack_records(b, stream, M * L, FD_KERNEL_GAUSSIAN_QNN, 2, L);
 }
 
 // fd_set_deltas: new right-hand sides through the stored reflectors and Cholesky factor
