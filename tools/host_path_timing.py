@@ -69,3 +69,16 @@ for f in range(10):
 ts = sorted(ts[2:])
 print(f"fdsop_cook, page-locked arrays, rest rig AND mesh unchanged from cook to cook (the animated-shot case): median {ts[len(ts)//2]*1e3:.3f} ms; severity {res.severity}")
 
+# the SOP's own two models at its default parameters (model = 0: QNN q = 1, z = 5; model = 1: multilayer
+# radius 1, 4 layers, lambda 0.1), page-locked arrays, everything new every cook
+for label, settings in (("model = 0 (QNN radii, the SOP's default; pivoted LU + Gaussian kernel)", {"model": "0"}),
+                        ("model = 1 (multilayer, 4 layers; 4 Cholesky solves + shared-distance Gaussian kernel)", {"model": "1"})):
+    n2 = FaceDeformSOP()
+    for k, v in settings.items():
+        n2.set(k, v)
+    ts = []
+    for f in range(8):
+        t0 = time.perf_counter(); res = n2.cook(pin_in, rest, synth.deformed_rig(rest, f), out_P=pin_out, out_falloff=pin_fall, want_Cd=False); ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[2:])
+    print(f"fdsop_cook, page-locked arrays, {label}: median {ts[len(ts)//2]*1e3:.3f} ms; severity {res.severity}; {res.infos}")
+    n2.close()
