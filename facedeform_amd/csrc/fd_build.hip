@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda,
 // rows above it with as many workgroups as there are rows (one workgroup walking all 2080 rows
 // per 32-column step took 2.4 ms at M = 2048).
 template <int T>
-__global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda, int npad, int row_lo, int row_hi)
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_backsub_all(const BatchSlot *tab, int lda, int npad, int row_lo, int row_hi)
 {
     double *A = tab[blockIdx.z].A;
     double *X = tab[blockIdx.z].X;
@@ -640,7 +640,10 @@ __global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda
         }
         // my first row's segment of U for the update below (does not depend on x); only the
         // small-system variant has the registers to hold it across the solve
-        constexpr bool kPrefetch = T <= 256;
+        // (no prefetch of the U row across the triangle any more: together with the triangle's own
+        // row it needs more than the 128 VGPRs of one evaluation-wave slot, and a kernel that does
+        // waits for two of them to retire when it runs beside an evaluation -- fd_nullspace.hip)
+        constexpr bool kPrefetch = false;
         const int i0 = row_lo + tid;
         double uik[32];
         if (kPrefetch && i0 < b0) {
@@ -688,6 +691,7 @@ __global__ __launch_bounds__(T) void k_backsub_all(const BatchSlot *tab, int lda
                 a0 = fma(uik[k], s_x[k][0], a0);
                 a1 = fma(uik[k], s_x[k][1], a1);
                 a2 = fma(uik[k], s_x[k][2], a2);
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // or all 96 LDS reads are hoisted and the U row spills
             }
             const int li = i - row_lo;
             s_y[li] -= a0; s_y[w + li] -= a1; s_y[2 * w + li] -= a2;
