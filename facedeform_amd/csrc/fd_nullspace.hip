@@ -872,7 +872,8 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
     __shared__ double sInv[kNB];
     const bool rhs = (int)blockIdx.x == npanel - 1;
     const int slab0 = kb + kNB + (int)blockIdx.x * kStepSlab;   // first row of a matrix slab
-    block_load_update(A, lda, kb, k0, sC, sR);
+    const bool first = k0 < 0;                // the first block: no panel before it, nothing to apply
+    block_load_update(A, lda, kb, first ? -1 : k0, sC, sR);
     __syncthreads();                          // sR (the rows of panel k0) is free from here on
 
     double x[kNB];
@@ -889,11 +890,11 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
         double u0[S], u1[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            u0[s] = -A[(size_t)(k0 + g + 4 * s) * lda + kb + c];
-            u1[s] = -A[(size_t)(k0 + g + 4 * s) * lda + kb + 16 + c];
+            u0[s] = first ? 0.0 : -A[(size_t)(k0 + g + 4 * s) * lda + kb + c];
+            u1[s] = first ? 0.0 : -A[(size_t)(k0 + g + 4 * s) * lda + kb + 16 + c];
         }
         const int wrow0 = slab0 + (wave - 1) * 64;             // my wave's first row
-        const int ntr = rhs ? (wave == 1 ? 1 : 0) : ((npc - wrow0 < 64 ? (npc - wrow0 > 0 ? npc - wrow0 : 0) : 64) / 16);
+        const int ntr = first ? 0 : (rhs ? (wave == 1 ? 1 : 0) : ((npc - wrow0 < 64 ? (npc - wrow0 > 0 ? npc - wrow0 : 0) : 64) / 16));
         for (int rt = 0; rt < ntr; ++rt) {
             gdouble *cp0, *cp1;
             size_t rs;
@@ -1128,10 +1129,16 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
 {
     const unsigned nb = (unsigned)b.nbatch;
     static const bool unfused = getenv("FD_CHOL_UNFUSED") != nullptr;      // A/B: two launches per step
-    if (!rhs_only) hipLaunchKernelGGL(k_chol_first, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, n1);
+    if (!rhs_only && unfused) hipLaunchKernelGGL(k_chol_first, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, n1);
+    if (!rhs_only && !unfused) {
+        // block 0: the step kernel with no panel before it (factorise, solve the rows below, nothing else)
+        const int npanel = (npc - kNB + kStepSlab - 1) / kStepSlab + 1;
+        hipLaunchKernelGGL(k_chol_step, dim3(npanel, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc, n1,
+                           -kNB, 1, npanel);
+    }
     for (int k0 = 0; k0 < npc; k0 += kNB) {
         const int below = npc - k0 - kNB;
-        if (rhs_only || unfused || k0 == 0) {
+        if (rhs_only || unfused) {
             const int nslab = rhs_only ? 0 : (below + kSlab - 1) / kSlab;
             hipLaunchKernelGGL(k_chol_solve, dim3(nslab + 1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
                                k0, nslab, rhs_only ? 0 : 1);
