@@ -484,7 +484,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{desc}, thin-plate kernel, linear term, {args.precision} evaluation, "
-                            "fp64 dense solve rebuilt every step (assemble + LU + evaluate), one frame per step",
+                            "fp64 dense solve rebuilt every step (assemble + direct solve + evaluate), one frame per step",
                 "n_verts": n_verts, "n_ctrl": n_ctrl,
                 "frames_per_batched_build": B, "frames_per_evaluation_launch": frames_per_launch,
                 "lanes_per_gpu": n_lanes,
