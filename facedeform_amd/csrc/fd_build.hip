@@ -561,13 +561,17 @@ __global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda,
         const int r0 = rbase + tile * 16;
         const bool two = tile + 4 < ntiles;
         const int r1 = two ? r0 + 64 : r0;
-        double *cptr0 = A + (size_t)(c0 + c) * lda + r0 + g;
-        double *cptr1 = A + (size_t)(c0 + c) * lda + r1 + g;
+        // accumulator transposed (the update U12 as the MFMA's A operand, L21 as its B operand):
+        // a lane then owns ONE row and four columns of the tile, and every load / store covers 16
+        // consecutive rows of a column (128 B) instead of 4 rows of 16 columns
+        const size_t cs = (size_t)4 * lda;
+        double *cptr0 = A + (size_t)(c0 + g) * lda + r0 + c;
+        double *cptr1 = A + (size_t)(c0 + g) * lda + r1 + c;
         const double *aptr0 = A + (size_t)(k0 + g) * lda + r0 + c;
         const double *aptr1 = A + (size_t)(k0 + g) * lda + r1 + c;
         double4_t acc0, acc1;
-        acc0[0] = cptr0[0]; acc0[1] = cptr0[4]; acc0[2] = cptr0[8]; acc0[3] = cptr0[12];
-        acc1[0] = cptr1[0]; acc1[1] = cptr1[4]; acc1[2] = cptr1[8]; acc1[3] = cptr1[12];
+        acc0[0] = cptr0[0]; acc0[1] = cptr0[cs]; acc0[2] = cptr0[2 * cs]; acc0[3] = cptr0[3 * cs];
+        acc1[0] = cptr1[0]; acc1[1] = cptr1[cs]; acc1[2] = cptr1[2 * cs]; acc1[3] = cptr1[3 * cs];
         const bool ok0 = r0 + c >= rfirst, ok1 = r1 + c >= rfirst;
         double av0[S], av1[S];
 #pragma unroll
@@ -579,16 +583,16 @@ __global__ __launch_bounds__(256) void k_lu_trail(const BatchSlot *tab, int lda,
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[s], u[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[s], u[s], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u[s], av0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u[s], av1[s], acc1, 0, 0, 0);
         }
+        if (ok0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r0 + g + 4 * r >= rfirst) cptr0[4 * r] = acc0[r];
-        if (two) {
+            for (int r = 0; r < 4; ++r) cptr0[r * cs] = acc0[r];
+        }
+        if (two && ok1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r1 + g + 4 * r >= rfirst) cptr1[4 * r] = acc1[r];
+            for (int r = 0; r < 4; ++r) cptr1[r * cs] = acc1[r];
         }
     }
 }

@@ -768,14 +768,14 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_trail(const Bat
             const int t = q == 0 ? t0 : (two ? t1 : t0);
             if (t < mtiles) {
                 const int r0 = c0 + t * 16;
-                cp[q] = A + (size_t)(c0 + c) * lda + r0 + g;
-                rs[q] = 4;
+                cp[q] = A + (size_t)(c0 + g) * lda + r0 + c;      // transposed accumulator: 16 consecutive rows per load
+                rs[q] = (size_t)4 * lda;
                 gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
 #pragma unroll
                 for (int s = 0; s < S; ++s) av[q][s] = aptr[(size_t)(4 * s) * lda];
             } else {
-                cp[q] = A + (size_t)(npad + g) * lda + c0 + c;
-                rs[q] = (size_t)4 * lda;
+                cp[q] = A + (size_t)(npad + c) * lda + c0 + g;
+                rs[q] = 4;
                 gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
 #pragma unroll
                 for (int s = 0; s < S; ++s) av[q][s] = aptr[4 * s];
@@ -784,8 +784,8 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_trail(const Bat
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][s], u[s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][s], u[s], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[s], av[0][s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[s], av[1][s], acc[1], 0, 0, 0);
         }
         cp[0][0] = acc[0][0]; cp[0][rs[0]] = acc[0][1]; cp[0][2 * rs[0]] = acc[0][2]; cp[0][3 * rs[0]] = acc[0][3];
         if (two) { cp[1][0] = acc[1][0]; cp[1][rs[1]] = acc[1][1]; cp[1][2 * rs[1]] = acc[1][2]; cp[1][3 * rs[1]] = acc[1][3]; }
@@ -838,14 +838,14 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
                 const int t = q == 0 ? t0 : (two ? t1 : t0);
                 if (t < mtiles) {
                     const int r0 = c0 + t * 16;
-                    cp[q] = A + (size_t)(c0 + c) * lda + r0 + g;
-                    rs[q] = 4;
+                    cp[q] = A + (size_t)(c0 + g) * lda + r0 + c;      // transposed accumulator: 16 consecutive rows per load
+                    rs[q] = (size_t)4 * lda;
                     gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
 #pragma unroll
                     for (int s = 0; s < S; ++s) av[q][s] = aptr[(size_t)(4 * s) * lda];
                 } else {
-                    cp[q] = A + (size_t)(npad + g) * lda + c0 + c;
-                    rs[q] = (size_t)4 * lda;
+                    cp[q] = A + (size_t)(npad + c) * lda + c0 + g;
+                    rs[q] = 4;
                     gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
 #pragma unroll
                     for (int s = 0; s < S; ++s) av[q][s] = aptr[4 * s];
@@ -854,8 +854,8 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
             }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][s], u[s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][s], u[s], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[s], av[0][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[s], av[1][s], acc[1], 0, 0, 0);
             }
             cp[0][0] = acc[0][0]; cp[0][rs[0]] = acc[0][1]; cp[0][2 * rs[0]] = acc[0][2]; cp[0][3 * rs[0]] = acc[0][3];
             if (two) { cp[1][0] = acc[1][0]; cp[1][rs[1]] = acc[1][1]; cp[1][2 * rs[1]] = acc[1][2]; cp[1][3 * rs[1]] = acc[1][3]; }
@@ -901,16 +901,16 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
             double av[S];
             if (!rhs) {
                 const int r0 = wrow0 + rt * 16;
-                cp0 = A + (size_t)(kb + c) * lda + r0 + g;
+                cp0 = A + (size_t)(kb + g) * lda + r0 + c;
                 cp1 = cp0 + (size_t)16 * lda;
-                rs = 4;
+                rs = (size_t)4 * lda;
                 gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
 #pragma unroll
                 for (int s = 0; s < S; ++s) av[s] = aptr[(size_t)(4 * s) * lda];
             } else {
-                cp0 = A + (size_t)(npad + g) * lda + kb + c;
+                cp0 = A + (size_t)(npad + c) * lda + kb + g;
                 cp1 = cp0 + 16;
-                rs = (size_t)4 * lda;
+                rs = 4;
                 gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
 #pragma unroll
                 for (int s = 0; s < S; ++s) av[s] = aptr[4 * s];
@@ -920,8 +920,8 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
             acc1[0] = cp1[0]; acc1[1] = cp1[rs]; acc1[2] = cp1[2 * rs]; acc1[3] = cp1[3 * rs];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], u0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], u1[s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0[s], av[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[s], av[s], acc1, 0, 0, 0);
             }
             cp0[0] = acc0[0]; cp0[rs] = acc0[1]; cp0[2 * rs] = acc0[2]; cp0[3 * rs] = acc0[3];
             cp1[0] = acc1[0]; cp1[rs] = acc1[1]; cp1[2 * rs] = acc1[2]; cp1[3 * rs] = acc1[3];
