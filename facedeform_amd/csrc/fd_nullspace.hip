@@ -817,48 +817,60 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
     __builtin_amdgcn_s_setprio(3);
 
     if ((int)blockIdx.x >= npanel) {
-        // trailing update of column block cb >= 2 (columns kb + 32 ..)
+        // Trailing update of a PAIR of 16-column blocks (32 columns from kb + 32 on) in 32 x 32
+        // macro tiles: two A operands (16 rows each) against two B operands give four MFMA chains,
+        // so every operand byte loaded is used twice and a wave has 16 KB in flight.  The last
+        // "tile" of a column pair is the right-hand sides (16 rows, of which three live).
         const int cbid = (int)blockIdx.x - npanel;
-        const int cb = 2 + cbid / nchunk, chunk = cbid % nchunk;
-        const int c0 = kb + cb * 16;
-        double u[S];
+        const int cpair = 1 + cbid / nchunk, chunk = cbid % nchunk;
+        const int c0 = kb + 32 * cpair;
+        double u0[S], u1[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) u[s] = -A[(size_t)(k0 + g + 4 * s) * lda + c0 + c];
-        const int mtiles = (npc - c0) / 16;               // index mtiles = RHS tile
-        const int stride = 4 * nchunk;
-        for (int t0 = chunk * 4 + wave; t0 <= mtiles; t0 += 2 * stride) {
-            const int t1 = t0 + stride;
-            const bool two = t1 <= mtiles;
-            gdouble *cp[2];
-            size_t rs[2];
-            double av[2][S];
-            double4_t acc[2];
+        for (int s = 0; s < S; ++s) {
+            u0[s] = -A[(size_t)(k0 + g + 4 * s) * lda + c0 + c];
+            u1[s] = -A[(size_t)(k0 + g + 4 * s) * lda + c0 + 16 + c];
+        }
+        const int mt = (npc - c0) / 32;                   // macro tiles of this column pair; index mt = RHS
+        const size_t cs = (size_t)4 * lda;
+        for (int t = chunk * 4 + wave; t <= mt; t += 4 * nchunk) {
+            if (t < mt) {
+                const int r0 = c0 + 32 * t;
+                gdouble *p00 = A + (size_t)(c0 + g) * lda + r0 + c;      // rows r0.., columns c0.. (accumulator transposed)
+                gdouble *p01 = p00 + (size_t)16 * lda;                    // columns c0 + 16..
+                gdouble *p10 = p00 + 16, *p11 = p01 + 16;                 // rows r0 + 16..
+                gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
+                double av0[S], av1[S];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int t = q == 0 ? t0 : (two ? t1 : t0);
-                if (t < mtiles) {
-                    const int r0 = c0 + t * 16;
-                    cp[q] = A + (size_t)(c0 + g) * lda + r0 + c;      // transposed accumulator: 16 consecutive rows per load
-                    rs[q] = (size_t)4 * lda;
-                    gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
+                for (int s = 0; s < S; ++s) { av0[s] = aptr[(size_t)(4 * s) * lda]; av1[s] = aptr[(size_t)(4 * s) * lda + 16]; }
+                double4_t a00, a01, a10, a11;
 #pragma unroll
-                    for (int s = 0; s < S; ++s) av[q][s] = aptr[(size_t)(4 * s) * lda];
-                } else {
-                    cp[q] = A + (size_t)(npad + c) * lda + c0 + g;
-                    rs[q] = 4;
-                    gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
+                for (int r = 0; r < 4; ++r) { a00[r] = p00[r * cs]; a01[r] = p01[r * cs]; a10[r] = p10[r * cs]; a11[r] = p11[r * cs]; }
 #pragma unroll
-                    for (int s = 0; s < S; ++s) av[q][s] = aptr[4 * s];
+                for (int s = 0; s < S; ++s) {
+                    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0[s], av0[s], a00, 0, 0, 0);
+                    a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[s], av0[s], a01, 0, 0, 0);
+                    a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0[s], av1[s], a10, 0, 0, 0);
+                    a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[s], av1[s], a11, 0, 0, 0);
                 }
-                acc[q][0] = cp[q][0]; acc[q][1] = cp[q][rs[q]]; acc[q][2] = cp[q][2 * rs[q]]; acc[q][3] = cp[q][3 * rs[q]];
-            }
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[s], av[0][s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[s], av[1][s], acc[1], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) { p00[r * cs] = a00[r]; p01[r * cs] = a01[r]; p10[r * cs] = a10[r]; p11[r * cs] = a11[r]; }
+            } else {
+                gdouble *p0 = A + (size_t)(npad + c) * lda + c0 + g, *p1 = p0 + 16;
+                gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
+                double av[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) av[s] = aptr[4 * s];
+                double4_t a0, a1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a0[r] = p0[4 * r]; a1[r] = p1[4 * r]; }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0[s], av[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[s], av[s], a1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p0[4 * r] = a0[r]; p1[4 * r] = a1[r]; }
             }
-            cp[0][0] = acc[0][0]; cp[0][rs[0]] = acc[0][1]; cp[0][2 * rs[0]] = acc[0][2]; cp[0][3 * rs[0]] = acc[0][3];
-            if (two) { cp[1][0] = acc[1][0]; cp[1][rs[1]] = acc[1][1]; cp[1][2 * rs[1]] = acc[1][2]; cp[1][3 * rs[1]] = acc[1][3]; }
         }
         return;
     }
@@ -1155,9 +1167,10 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
             // fused: this launch also factorises block k0 + 32 and solves its panel
             const int below_next = below - kNB;
             const int npanel = (below_next + kStepSlab - 1) / kStepSlab + 1;
-            int nchunk = (ncb + 15) / 16;
+            // macro tiles per column pair: up to (ncb / 2 - 1); four waves per workgroup, about two tiles each
+            int nchunk = (ncb / 2 + 7) / 8;
             nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
-            const int nreg = ncb > 2 ? (ncb - 2) * nchunk : 0;
+            const int nreg = ncb > 2 ? (ncb / 2 - 1) * nchunk : 0;
             hipLaunchKernelGGL(k_chol_step, dim3(npanel + nreg, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
                                n1, k0, nchunk, npanel);
         }
