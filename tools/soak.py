@@ -28,6 +28,10 @@ def main():
             es[1].set_deltas(synth.smooth_deltas(rest, 5).astype(np.float32)); es[1].build()
             es[2].mesh_set(P); out = np.empty_like(P); es[2].deform_mesh(out)
             es[3].capture_dist2(P[:1000], np.zeros((3, 9), np.float32), 1.0)
+            if it % 4 == 0:      # the multilayer model (record arrays grow), the LU path, an exported blob
+                ml = capi.Engine(); ml.set_kernel(capi.KERNEL_GAUSSIAN_ML, [0.8, 2 + it % 5, 0.1]); ml.set_term(0)
+                ml.set_points(rest, synth.smooth_deltas(rest, 1).astype(np.float32)); ml.build()
+                r2 = capi.Engine(solver=capi.SOLVER_LU); r2.import_model(ml.export_model()); r2.deform(P[:5000]); r2.close(); ml.close()
             b.close()
             for e in es: e.close()
             if it % 10 == 0:
