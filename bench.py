@@ -65,6 +65,8 @@ def parse_args():
                     help="evaluations per HIP event pair (a pair costs ~4-5 us of stream time, spread over the run)")
     ap.add_argument("--eval-launch", choices=["batched", "single"], default="batched",
                     help="evaluate the frames of a group with one launch (fd_batch_deform_dev) or one launch per frame")
+    ap.add_argument("--c5-solve", choices=["broadcast", "redundant"], default="broadcast",
+                    help="config c5: rank 0 solves and broadcasts the models (default), or every rank solves them itself")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
                     help="evaluations on one stream for all lanes (default) or on each lane's build stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,6 +127,8 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
     lo, hi = fdist.vertex_range(n_verts, rank, world)
     n_mine = hi - lo
     B = max(1, min(args.inflight, 8))                 # frames per group (10M-vertex frames are large)
+    # the alternative to one broadcast is every rank solving the (tiny) system itself
+    redundant = args.c5_solve == "redundant"
     n_lanes = 2
     P_host = synth.head_mesh(n_verts)
     rest_host = synth.control_points(n_ctrl, mesh_kind)
@@ -162,14 +166,14 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
         frames = [(first + k) % N_FRAMES for k in range(B)]
         with torch.cuda.stream(stream):
             if e: e[0].record(stream)
-            if rank == 0:
+            if rank == 0 or redundant:
                 batch.set_points_dev([d_rest.data_ptr()] * B, [d_deltas.data_ptr() + f * delta_stride for f in frames], n_ctrl)
                 batch.build_async(stream.cuda_stream)
-                if world > 1:
+                if world > 1 and not redundant:
                     for k, eng in enumerate(engines):
                         eng.export_model_dev(blob[k].data_ptr(), nbytes)      # waits for the build status
             if e: e[1].record(stream)
-            if world > 1:
+            if world > 1 and not redundant:
                 if rehearse:                                            # gloo: through host memory
                     if rank == 0:
                         ln["blob_host"].copy_(blob, non_blocking=False)
@@ -218,11 +222,14 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc + ", thin-plate kernel, linear term, models rebuilt on rank 0 every step "
-                                   f"({B} per batched build), one broadcast per {B} frames", "n_verts": n_verts,
+            "config": {"workload": desc + ", thin-plate kernel, linear term, models rebuilt " +
+                                   ("on every rank every step " if redundant else "on rank 0 every step ") +
+                                   f"({B} per batched build)" + ("" if redundant else f", one broadcast per {B} frames"),
+                       "n_verts": n_verts,
                        "n_ctrl": n_ctrl, "verts_on_rank0": n_mine, "model_blob_bytes": nbytes,
                        "frames_per_group": B, "frames_cooked": frames_done,
-                       "parallelism": f"vertex ranges over {world} GPU(s), 1 broadcast per {B} frames, {n_lanes} lanes"},
+                       "parallelism": (f"vertex ranges over {world} GPU(s), every rank solves the models itself, {n_lanes} lanes" if redundant else
+                                       f"vertex ranges over {world} GPU(s), 1 broadcast per {B} frames, {n_lanes} lanes")},
             "roofline": {"bound": "mfma", "kernel": "k_deform32_tps_mfma_batch" if B > 1 else "k_deform32_tps_mfma",
                          "achieved": tf, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
