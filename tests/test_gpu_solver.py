@@ -213,3 +213,23 @@ def test_nothing_the_lu_accepts_fails_on_the_cholesky_path(hip_lib, oracle):
     b.close()
     for e in es:
         e.close()
+
+
+def test_every_block_shape_of_the_fused_step(hip_lib):
+    """A sweep over M walks every relation between the 32-column blocks, the 192-row slabs of the
+    step kernel, the 64-row waves inside them and the padding (one block only, one slab exactly,
+    a slab plus one row, pivot rows straddling a block boundary ...), thin-plate + linear term and
+    a Gaussian without projection; the LU is the reference."""
+    sizes = list(range(16, 140, 5)) + [191, 192, 193, 196, 197, 223, 224, 225, 228, 229, 255, 256, 257, 260, 261, 287, 288, 289, 292, 293, 420, 452, 453]
+    for kind, params, term in ((capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR), (capi.KERNEL_GAUSSIAN, [0.2, 1e-3], capi.TERM_ZERO)):
+        for M in sizes:
+            rest = synth.control_points(M, "head")
+            delta = synth.smooth_deltas(rest, 1).astype(np.float32)
+            W = []
+            for solver in (capi.SOLVER_AUTO, capi.SOLVER_LU):
+                e = _engine(kind, params, term, rest, delta, solver)
+                rep = e.build()
+                assert rep.terminationtype == 1, (kind, M, solver)
+                W.append(e.get_weights()[0])
+                e.close()
+            assert np.abs(W[0] - W[1]).max() <= 1e-8 * np.abs(W[1]).max(), (kind, M)
