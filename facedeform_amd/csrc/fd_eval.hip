@@ -934,7 +934,8 @@ hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream)
     bool same = n > 1 && n <= kMaxBatch;
     for (int i = 0; i < n && same; ++i)
         same = a[i].precision == FD_EVAL_FP32 && a[i].variant <= 0 && a[i].N == a[0].N && a[i].N > 0 &&
-               a[i].Mpad == a[0].Mpad && a[i].kind == a[0].kind;
+               a[i].Mpad == a[0].Mpad && a[i].kind == a[0].kind &&
+               !(a[i].layers >= 2 && a[i].layers % 2 == 0);     // shared-distance multilayer kernel: single launches (same bits as fd_deform)
     static const bool bf16_tiles = getenv("FD_MFMA_BF16") != nullptr;
     bool mfma = same && a[0].kind == FD_KERNEL_THIN_PLATE && a[0].Mpad >= 64 && !bf16_tiles;
     for (int i = 0; i < n && mfma; ++i) mfma = a[i].tiles16 != nullptr;

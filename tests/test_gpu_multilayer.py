@@ -111,7 +111,7 @@ def test_boundary_behaviour(hip_lib):
 
 
 def test_batched_builds_match_single_builds_bitwise(hip_lib):
-    M, L = 120, 3
+    M, L = 120, 4
     rest = synth.control_points(M, "head")
     dev = torch.device("cuda:0")
     d_rest = torch.from_numpy(rest).to(dev)
@@ -131,6 +131,17 @@ def test_batched_builds_match_single_builds_bitwise(hip_lib):
         s.set_points(rest, synth.smooth_deltas(rest, f).astype(np.float32)); s.build()
         assert np.array_equal(s.get_weights()[0], e.get_weights()[0]), f
         s.close()
+    # one batched evaluation call gives every context what its own fd_deform_dev gives, bit for bit
+    # (the multilayer contexts are launched one by one there: their kernel shares distances per centre)
+    N = 4096
+    d_P = torch.from_numpy(synth.head_mesh(N)).to(dev)
+    outs = [torch.empty_like(d_P) for _ in es]
+    b.deform_dev(N, [d_P.data_ptr()] * 4, [o.data_ptr() for o in outs])
+    torch.cuda.synchronize()
+    for e, o in zip(es, outs):
+        single = torch.empty_like(d_P)
+        e.deform_dev(N, d_P.data_ptr(), single.data_ptr()); e.synchronize()
+        assert torch.equal(single, o)
     b.close()
     for e in es:
         e.close()
