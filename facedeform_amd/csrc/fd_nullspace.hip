@@ -885,8 +885,34 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
     const bool rhs = (int)blockIdx.x == npanel - 1;
     const int slab0 = kb + kNB + (int)blockIdx.x * kStepSlab;   // first row of a matrix slab
     const bool first = k0 < 0;                // the first block: no panel before it, nothing to apply
-    block_load_update(A, lda, kb, first ? -1 : k0, sC, sR);
-    __syncthreads();                          // sR (the rows of panel k0) is free from here on
+    // operands of the next panel's two 16-column blocks: rows kb.. / kb+16.. of panel k0, negated
+    double u0[S], u1[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        u0[s] = first ? 0.0 : -A[(size_t)(k0 + g + 4 * s) * lda + kb + c];
+        u1[s] = first ? 0.0 : -A[(size_t)(k0 + g + 4 * s) * lda + kb + 16 + c];
+    }
+    // the diagonal block (kb, kb) with panel k0 applied, into LDS: its three lower 16 x 16 tiles by
+    // waves 1..3, one MFMA chain each -- the row operand of a tile is the (negated) column operand
+    // of its row half, so nothing else has to be loaded; wave 0 clears the tile above the diagonal
+    if (wave == 0) {
+        for (int e = lane; e < 256; e += 64) sC[e & 15][16 + (e >> 4)] = 0.0;
+    } else {
+        const int ta = wave == 1 ? 0 : 1, tb = wave == 3 ? 1 : 0;          // tile (row half, column half)
+        gcdouble *cp = A + (size_t)(kb + 16 * tb + g) * lda + kb + 16 * ta + c;   // transposed accumulator
+        const size_t cs = (size_t)4 * lda;
+        double4_t acc;
+        acc[0] = cp[0]; acc[1] = cp[cs]; acc[2] = cp[2 * cs]; acc[3] = cp[3 * cs];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const double colop = tb ? u1[s] : u0[s];
+            const double rowop = -(ta ? u1[s] : u0[s]);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(colop, rowop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sC[16 * ta + c][16 * tb + g + 4 * r] = acc[r];
+    }
+    __syncthreads();
 
     double x[kNB];
     bool active = false, invert = false;
@@ -899,12 +925,6 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
 #pragma unroll
         for (int kk = 0; kk < kNB / 2; ++kk) { const int k = 2 * kk + h; sR[k][i] = i >= k ? sC[i][k] : 0.0; }
     } else {
-        double u0[S], u1[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            u0[s] = first ? 0.0 : -A[(size_t)(k0 + g + 4 * s) * lda + kb + c];
-            u1[s] = first ? 0.0 : -A[(size_t)(k0 + g + 4 * s) * lda + kb + 16 + c];
-        }
         const int wrow0 = slab0 + (wave - 1) * 64;             // my wave's first row
         const int ntr = first ? 0 : (rhs ? (wave == 1 ? 1 : 0) : ((npc - wrow0 < 64 ? (npc - wrow0 > 0 ? npc - wrow0 : 0) : 64) / 16));
         for (int rt = 0; rt < ntr; ++rt) {
