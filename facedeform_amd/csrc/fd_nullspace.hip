@@ -98,11 +98,13 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double *scratch /* [
     for (int q = 0; q < N; ++q) v[q] = (scratch[q] + scratch[N + q]) + (scratch[2 * N + q] + scratch[3 * N + q]);
 }
 
+__device__ __forceinline__ void ns_rhs_body(const BatchSlot &s, int M, int T, int npad, int lda, double *s_red);
+
 // ---- reflectors ----------------------------------------------------------------------
 // LAPACK dlarfg turned upside down: reflector k acts on rows 0 .. M-1-k and leaves its beta in
 // row M-1-k, so the null-space block comes FIRST in the rotated system and the Cholesky starts
 // at row 0 on tile boundaries.
-__global__ __launch_bounds__(256) void k_ns_reflectors(const BatchSlot *tab, int M, int T)
+__global__ __launch_bounds__(256) void k_ns_reflectors(const BatchSlot *tab, int M, int T, int npad, int lda, int with_rhs)
 {
     const BatchSlot &s = tab[blockIdx.z];
     gcdouble *centres = as_global(s.centres);
@@ -187,17 +189,20 @@ __global__ __launch_bounds__(256) void k_ns_reflectors(const BatchSlot *tab, int
         for (int k = T; k < 4; ++k) small[kTau + k] = 0.0;
         if (singular) s.model->sing_flag = 1;
     }
+    if (with_rhs) {
+        __threadfence_block();
+        __syncthreads();                      // tau is in memory
+        ns_rhs_body(s, M, T, npad, lda, s_red);
+    }
 }
 
 // f <- Q^T f = H_{T-1} .. H_0 f in the right-hand-side columns; the pivot rows' values go aside
 // (they belong to the polynomial equations) and read as zero padding afterwards.
-__global__ __launch_bounds__(256) void k_ns_rhs(const BatchSlot *tab, int M, int T, int npad, int lda)
+__device__ __forceinline__ void ns_rhs_body(const BatchSlot &s, int M, int T, int npad, int lda, double *s_red /* [12] */)
 {
-    const BatchSlot &s = tab[blockIdx.z];
     gcdouble *V = as_global(s.ns);
     gdouble *small = as_global(s.ns) + (size_t)12 * M;
     gdouble *f0 = as_global(s.A) + (size_t)npad * lda, *f1 = f0 + lda, *f2 = f1 + lda;
-    __shared__ double s_red[4 * 3];
     const int tid = threadIdx.x;
     for (int k = 0; k < T; ++k) {
         const int piv = M - 1 - k;
@@ -219,6 +224,14 @@ __global__ __launch_bounds__(256) void k_ns_rhs(const BatchSlot *tab, int M, int
         small[kG + 3 * tid] = f0[piv]; small[kG + 3 * tid + 1] = f1[piv]; small[kG + 3 * tid + 2] = f2[piv];
         f0[piv] = 0.0; f1[piv] = 0.0; f2[piv] = 0.0;
     }
+}
+
+// on its own for fd_set_deltas (the reflectors are there already); the full build runs it at the
+// end of k_ns_reflectors -- same code, same bits
+__global__ __launch_bounds__(256) void k_ns_rhs(const BatchSlot *tab, int M, int T, int npad, int lda)
+{
+    __shared__ double s_red[4 * 3];
+    ns_rhs_body(tab[blockIdx.z], M, T, npad, lda, s_red);
 }
 
 // ---- Y = K V ---------------------------------------------------------------------------
@@ -1240,8 +1253,7 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
     const int M = b.M, T = b.T;
     const int n1 = M - T, npc = round_up(n1, kNB), npa = round_up(M, 32);
     if (T > 0) {
-        hipLaunchKernelGGL(k_ns_reflectors, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T);
-        hipLaunchKernelGGL(k_ns_rhs, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
+        hipLaunchKernelGGL(k_ns_reflectors, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda, 1);
     }
     hipError_t e = launch_assemble_block(b, stream, npa);
     if (e != hipSuccess) return e;
@@ -1266,7 +1278,7 @@ hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t
     const int M = b.M, T = b.T, L = b.ml_layers;
     const int npc = round_up(M, kNB);
     if (T > 0) {
-        hipLaunchKernelGGL(k_ns_reflectors, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T);
+        hipLaunchKernelGGL(k_ns_reflectors, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda, 0);
         hipLaunchKernelGGL(k_ml_affine, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
     }
     hipLaunchKernelGGL(k_ml_setup, dim3((M * L + 255) / 256, 1, nb), dim3(256), 0, stream, b.d_slots, M, L, b.gauss_R);
