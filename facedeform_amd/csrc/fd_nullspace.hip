@@ -21,8 +21,8 @@
 //   k_ns_reflectors   one workgroup: Householder vectors V (M x T), tau, R, the compact-WY factor
 //   k_ns_rhs          one workgroup: f <- Q^T f in the right-hand-side columns of A
 //   k_assemble        (fd_build.hip) K into A, full square
-//   k_ns_kv           Y = K V
-//   k_ns_w            W = Y Tm - (1/2) V (Tm^T V^T Y Tm), so that B = K - V W^T - W V^T
+//   k_ns_kv           Y = K V, then (its last workgroup) W = Y Tm - (1/2) V (Tm^T V^T Y Tm),
+//                     so that B = K - V W^T - W V^T
 //   k_ns_rotate       lower triangle of B11 in place, B21 aside, identity padding to npc
 //   per 32 columns:   k_chol_solve (the rows below the diagonal block and the right-hand sides:
 //                     X L11^T = A21, one row per thread) and k_chol_trail (A22 -= L21 L21^T,
@@ -64,6 +64,7 @@ constexpr int kR = 4;                   // R[k][c], row k = pivot row M-1-k
 constexpr int kTm = 20;                 // compact WY: Q = I - V Tm V^T, upper triangular
 constexpr int kG = 36;                  // (Q^T f) in the pivot rows: g[k][c]
 constexpr int kAff = 48;                // multilayer model: least-squares polynomial a[k][c]
+constexpr int kTicket = 60;             // k_ns_kv's workgroups take a number here; the last one finishes W (an unsigned, zeroed by k_ns_reflectors)
 constexpr int kSmall = 64;
 // after the small block: the factorised diagonal blocks, one per 32 columns -- L11 column-major
 // (32 x 32, zeros above the diagonal) followed by the reciprocals of its diagonal: what the
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256) void k_ns_reflectors(const BatchSlot *tab, int
         for (int a = 0; a < 4; ++a)
             for (int b = 0; b < 4; ++b) small[kTm + 4 * a + b] = Tm[a][b];
         for (int k = T; k < 4; ++k) small[kTau + k] = 0.0;
+        *(unsigned FD_GLOBAL *)(small + kTicket) = 0u;
         if (singular) s.model->sing_flag = 1;
     }
     if (with_rhs) {
@@ -234,59 +236,10 @@ __global__ __launch_bounds__(256) void k_ns_rhs(const BatchSlot *tab, int M, int
     ns_rhs_body(tab[blockIdx.z], M, T, npad, lda, s_red);
 }
 
-// ---- Y = K V ---------------------------------------------------------------------------
-// 64 rows per workgroup, one row per lane (consecutive lanes walk a column of A: coalesced); the
-// four waves split the columns, each with its slice of V in LDS, and their partial sums are added
-// in a fixed order
-__global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int lda)
-{
-    const BatchSlot &s = tab[blockIdx.z];
-    gcdouble *A = as_global(s.A), *V = as_global(s.ns);
-    gdouble *Y = as_global(s.ns) + (size_t)4 * M;
-    __shared__ __attribute__((aligned(16))) double s_v[4][64][4];
-    __shared__ double s_part[4][64][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    const int ic = i < M ? i : M - 1;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const int per = ((M + 3) / 4 + 63) & ~63;          // columns per wave, a multiple of the LDS slice
-    const int jlo = wave * per, jhi = jlo + per < M ? jlo + per : M;
-    for (int j0 = jlo; j0 < jhi; j0 += 64) {
-        {
-            const int j = j0 + lane;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) s_v[wave][lane][t] = j < jhi ? V[4 * (size_t)j + t] : 0.0;   // my wave's slice only
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-        for (int q0 = 0; q0 < 64; q0 += 8) {
-            double a[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int j = j0 + q0 + q < M ? j0 + q0 + q : M - 1; a[q] = A[(size_t)j * lda + ic]; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = fma(a[q], s_v[wave][q0 + q][t], acc[t]);     // zero beyond jhi
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) s_part[wave][lane][t] = acc[t];
-    __syncthreads();
-    if (wave == 0 && i < M) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            Y[4 * (size_t)i + t] = (s_part[0][lane][t] + s_part[1][lane][t]) + (s_part[2][lane][t] + s_part[3][lane][t]);
-    }
-}
-
 // ---- W = Y Tm - (1/2) V G,  G = Tm^T (V^T Y) Tm ---------------------------------------------
-__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_ns_w(const BatchSlot *tab, int M)
+// (256 threads; runs in the last workgroup of k_ns_kv to finish)
+__device__ __forceinline__ void ns_w_body(const BatchSlot &s, int M)
 {
-    const BatchSlot &s = tab[blockIdx.z];
     gcdouble *V = as_global(s.ns), *small = V + (size_t)12 * M;
     gdouble *Y = as_global(s.ns) + (size_t)4 * M;          // becomes W
     __shared__ double s_red[4 * 16];
@@ -337,6 +290,65 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_ns_w(const BatchSlot
 #pragma unroll
         for (int t = 0; t < 4; ++t) Y[4 * (size_t)i + t] = w[t];
     }
+}
+
+// ---- Y = K V ---------------------------------------------------------------------------
+// 64 rows per workgroup, one row per lane (consecutive lanes walk a column of A: coalesced); the
+// four waves split the columns, each with its slice of V in LDS, and their partial sums are added
+// in a fixed order
+__global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int lda)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *A = as_global(s.A), *V = as_global(s.ns);
+    gdouble *Y = as_global(s.ns) + (size_t)4 * M;
+    __shared__ __attribute__((aligned(16))) double s_v[4][64][4];
+    __shared__ double s_part[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int ic = i < M ? i : M - 1;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int per = ((M + 3) / 4 + 63) & ~63;          // columns per wave, a multiple of the LDS slice
+    const int jlo = wave * per, jhi = jlo + per < M ? jlo + per : M;
+    for (int j0 = jlo; j0 < jhi; j0 += 64) {
+        {
+            const int j = j0 + lane;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s_v[wave][lane][t] = j < jhi ? V[4 * (size_t)j + t] : 0.0;   // my wave's slice only
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+        for (int q0 = 0; q0 < 64; q0 += 8) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int j = j0 + q0 + q < M ? j0 + q0 + q : M - 1; a[q] = A[(size_t)j * lda + ic]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = fma(a[q], s_v[wave][q0 + q][t], acc[t]);     // zero beyond jhi
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s_part[wave][lane][t] = acc[t];
+    __syncthreads();
+    if (wave == 0 && i < M) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            Y[4 * (size_t)i + t] = (s_part[0][lane][t] + s_part[1][lane][t]) + (s_part[2][lane][t] + s_part[3][lane][t]);
+    }
+    // the last workgroup to get here turns Y into W (it needs all of Y: V^T Y is a sum over every
+    // row).  Which workgroup that is does not matter to the result.
+    __shared__ unsigned s_ticket;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd((unsigned *)(s.ns + (size_t)12 * M + kTicket), 1u);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    __threadfence();
+    ns_w_body(s, M);
 }
 
 // ---- B = K - V W^T - W V^T, lower triangle of the leading n1 x n1 block in place ----------------
@@ -655,13 +667,78 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_solve(const Bat
     for (int c = 0; c < kNB; ++c) rowp[c] = x[c];
 }
 
+// ---- recover a and w ------------------------------------------------------------------------------
+__device__ __forceinline__ void ns_recover_body(const BatchSlot &s, int M, int T, int npad, double *s_red /* [48] */)
+{
+    gcdouble *V = as_global(s.ns), *B21 = V + (size_t)8 * M, *small = V + (size_t)12 * M;
+    gdouble *X = as_global(s.X);
+    const int tid = threadIdx.x;
+    const int n1 = M - T;
+
+    // (B21 y)[k][c]
+    double q[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) q[e] = 0.0;
+    for (int j = tid; j < n1; j += 256) {
+        const double y0 = X[j], y1 = X[(size_t)npad + j], y2 = X[2 * (size_t)npad + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double b = B21[4 * (size_t)j + k];
+            q[3 * k] = fma(b, y0, q[3 * k]); q[3 * k + 1] = fma(b, y1, q[3 * k + 1]); q[3 * k + 2] = fma(b, y2, q[3 * k + 2]);
+        }
+    }
+    block_sum_n<12>(q, s_red, tid);
+    // R a = g - B21 y, row k of R sits in pivot row M-1-k and is upper triangular in (k, c)
+    double a[4][3];
+    for (int k = T - 1; k >= 0; --k)
+        for (int c = 0; c < 3; ++c) {
+            double v = small[kG + 3 * k + c] - q[3 * k + c];
+            for (int cc = k + 1; cc < T; ++cc) v = fma(-small[kR + 4 * k + cc], a[cc][c], v);
+            a[k][c] = v / small[kR + 4 * k + k];
+        }
+    // w = Q [y; 0] = H_0 .. H_{T-1} [y; 0]
+    for (int i = n1 + tid; i < npad; i += 256) { X[i] = 0.0; X[(size_t)npad + i] = 0.0; X[2 * (size_t)npad + i] = 0.0; }
+    __syncthreads();
+    for (int k = T - 1; k >= 0; --k) {
+        const int piv = M - 1 - k;
+        const double tau = small[kTau + k];
+        double d[3] = {0.0, 0.0, 0.0};
+        for (int i = tid; i <= piv; i += 256) {
+            const double v = V[4 * (size_t)i + k];
+            d[0] = fma(v, X[i], d[0]); d[1] = fma(v, X[(size_t)npad + i], d[1]); d[2] = fma(v, X[2 * (size_t)npad + i], d[2]);
+        }
+        block_sum_n<3>(d, s_red, tid);
+        for (int i = tid; i <= piv; i += 256) {
+            const double v = V[4 * (size_t)i + k];
+            X[i] = fma(-tau * d[0], v, X[i]);
+            X[(size_t)npad + i] = fma(-tau * d[1], v, X[(size_t)npad + i]);
+            X[2 * (size_t)npad + i] = fma(-tau * d[2], v, X[2 * (size_t)npad + i]);
+        }
+        __syncthreads();
+    }
+    if (tid < 3 * T) {
+        const int k = tid / 3, c = tid % 3;
+        X[(size_t)c * npad + M + k] = a[k][c];
+    }
+    // the report counts eliminated unknowns: n1 by the Cholesky, T constraints by the reflectors,
+    // T coefficients through R
+    if (tid == 0 && s.model->iterations >= n1) s.model->iterations = M + T;
+}
+
+__global__ __launch_bounds__(256) void k_ns_recover(const BatchSlot *tab, int M, int T, int npad)
+{
+    __shared__ double s_red[4 * 12];
+    ns_recover_body(tab[blockIdx.z], M, T, npad, s_red);
+}
+
 // ---- back-substitution with the inverted diagonal blocks ----------------------------------------------
 // L^T y = z over the rows [row_lo, row_hi), bottom up, one workgroup: z of the range lives in LDS;
 // per 32-row block y_b = inverse(L_bb)^T z_b is 96 dot products instead of a 32-step dependent
 // chain, then the rows above in the range take the block's contribution (the mirrored U = L^T, one
 // row per thread, coalesced).  Ranges above 512 rows are chained with k_backsub_update as in the
 // LU path.  Same role and data layout as fd_build.hip's k_backsub_all.
-__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_backsub_inv(const BatchSlot *tab, int M, int lda, int npad, int row_lo, int row_hi)
+__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_backsub_inv(const BatchSlot *tab, int M, int lda, int npad, int row_lo, int row_hi,
+                                                                        int recover_T)
 {
     const BatchSlot &s = tab[blockIdx.z];
     gcdouble *A = as_global(s.A);
@@ -731,6 +808,11 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_backsub_inv(const Ba
     }
     __syncthreads();
     for (int e = tid; e < 3 * w; e += 256) X[(size_t)(e / w) * npad + row_lo + e % w] = s_y[e];
+    if (recover_T >= 0) {                     // whole system in one call: the polynomial and w = Q [y; 0] right away
+        __threadfence_block();
+        __syncthreads();
+        ns_recover_body(s, M, recover_T, npad, &s_li[0][0][0]);
+    }
 }
 
 // ---- Cholesky: trailing update ---------------------------------------------------------------
@@ -1015,66 +1097,6 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
     for (int cc = 0; cc < kNB; ++cc) up[cc] = x[cc];
 }
 
-// ---- recover a and w ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ns_recover(const BatchSlot *tab, int M, int T, int npad)
-{
-    const BatchSlot &s = tab[blockIdx.z];
-    gcdouble *V = as_global(s.ns), *B21 = V + (size_t)8 * M, *small = V + (size_t)12 * M;
-    gdouble *X = as_global(s.X);
-    __shared__ double s_red[4 * 12];
-    const int tid = threadIdx.x;
-    const int n1 = M - T;
-
-    // (B21 y)[k][c]
-    double q[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) q[e] = 0.0;
-    for (int j = tid; j < n1; j += 256) {
-        const double y0 = X[j], y1 = X[(size_t)npad + j], y2 = X[2 * (size_t)npad + j];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double b = B21[4 * (size_t)j + k];
-            q[3 * k] = fma(b, y0, q[3 * k]); q[3 * k + 1] = fma(b, y1, q[3 * k + 1]); q[3 * k + 2] = fma(b, y2, q[3 * k + 2]);
-        }
-    }
-    block_sum_n<12>(q, s_red, tid);
-    // R a = g - B21 y, row k of R sits in pivot row M-1-k and is upper triangular in (k, c)
-    double a[4][3];
-    for (int k = T - 1; k >= 0; --k)
-        for (int c = 0; c < 3; ++c) {
-            double v = small[kG + 3 * k + c] - q[3 * k + c];
-            for (int cc = k + 1; cc < T; ++cc) v = fma(-small[kR + 4 * k + cc], a[cc][c], v);
-            a[k][c] = v / small[kR + 4 * k + k];
-        }
-    // w = Q [y; 0] = H_0 .. H_{T-1} [y; 0]
-    for (int i = n1 + tid; i < npad; i += 256) { X[i] = 0.0; X[(size_t)npad + i] = 0.0; X[2 * (size_t)npad + i] = 0.0; }
-    __syncthreads();
-    for (int k = T - 1; k >= 0; --k) {
-        const int piv = M - 1 - k;
-        const double tau = small[kTau + k];
-        double d[3] = {0.0, 0.0, 0.0};
-        for (int i = tid; i <= piv; i += 256) {
-            const double v = V[4 * (size_t)i + k];
-            d[0] = fma(v, X[i], d[0]); d[1] = fma(v, X[(size_t)npad + i], d[1]); d[2] = fma(v, X[2 * (size_t)npad + i], d[2]);
-        }
-        block_sum_n<3>(d, s_red, tid);
-        for (int i = tid; i <= piv; i += 256) {
-            const double v = V[4 * (size_t)i + k];
-            X[i] = fma(-tau * d[0], v, X[i]);
-            X[(size_t)npad + i] = fma(-tau * d[1], v, X[(size_t)npad + i]);
-            X[2 * (size_t)npad + i] = fma(-tau * d[2], v, X[2 * (size_t)npad + i]);
-        }
-        __syncthreads();
-    }
-    if (tid < 3 * T) {
-        const int k = tid / 3, c = tid % 3;
-        X[(size_t)c * npad + M + k] = a[k][c];
-    }
-    // the report counts eliminated unknowns: n1 by the Cholesky, T constraints by the reflectors,
-    // T coefficients through R
-    if (tid == 0 && s.model->iterations >= n1) s.model->iterations = M + T;
-}
-
 // ---- multilayer Gaussian model (FD_KERNEL_GAUSSIAN_ML) ---------------------------------------------
 // The SOP's model = 1, alglib::rbfsetalgomultilayer(model, radius, layers, lambda)
 // (reference src/SOP_FaceDeform.cpp:346-348), in dense form: the term's polynomial is fitted to
@@ -1211,24 +1233,27 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
 }
 
 // L^T y = z over rows [0, rows): one call up to 512 rows, 256-row ranges chained above that
-hipError_t launch_backsub_spd(const BuildBuffers &b, hipStream_t stream, int rows)
+// recover_T >= 0: also recover the polynomial and w (k_ns_recover's work) -- inside the same launch
+// when the system is one range, as a launch of its own otherwise; -1: back-substitution only
+hipError_t launch_backsub_spd(const BuildBuffers &b, hipStream_t stream, int rows, int recover_T)
 {
     const unsigned nb = (unsigned)b.nbatch;
     if (rows <= 512) {
         hipLaunchKernelGGL(k_backsub_inv, dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)rows, stream, b.d_slots,
-                           b.M, b.lda, b.npad, 0, rows);
+                           b.M, b.lda, b.npad, 0, rows, recover_T);
         return hipGetLastError();
     }
     constexpr int W = 256;
     for (int hi = rows; hi > 0; hi -= W) {
         const int lo = hi > W ? hi - W : 0;
         hipLaunchKernelGGL(k_backsub_inv, dim3(1, 1, nb), dim3(256), sizeof(double) * 3 * (size_t)(hi - lo), stream,
-                           b.d_slots, b.M, b.lda, b.npad, lo, hi);
+                           b.d_slots, b.M, b.lda, b.npad, lo, hi, -1);
         if (lo > 0) {
             hipError_t e = launch_backsub_update(b, stream, lo, hi - lo);
             if (e != hipSuccess) return e;
         }
     }
+    if (recover_T >= 0) hipLaunchKernelGGL(k_ns_recover, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, recover_T, b.npad);
     return hipGetLastError();
 }
 
@@ -1259,15 +1284,13 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
     if (e != hipSuccess) return e;
     if (T > 0) {
         hipLaunchKernelGGL(k_ns_kv, dim3((M + 63) / 64, 1, nb), dim3(256), 0, stream, b.d_slots, M, b.lda);
-        hipLaunchKernelGGL(k_ns_w, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M);
         const unsigned g = (unsigned)((npc > M ? npc : M) + 31) / 32;
         hipLaunchKernelGGL(k_ns_rotate, dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, T, npc, b.lda);
     }
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     launch_factor(b, stream, npc, n1, 0);
-    e = launch_backsub_spd(b, stream, npc);
+    e = launch_backsub_spd(b, stream, npc, T);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ns_recover, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad);
     return launch_pack(b, stream);
 }
 
@@ -1287,7 +1310,7 @@ hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t
         hipError_t e = launch_assemble_block(b, stream, npc, l * M);
         if (e != hipSuccess) return e;
         launch_factor(b, stream, npc, M, 0);
-        e = launch_backsub_spd(b, stream, npc);
+        e = launch_backsub_spd(b, stream, npc, -1);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_ml_layer, dim3((M + 255) / 256, 1, nb), dim3(256), 0, stream, b.d_slots, M, b.npad, b.lda, l,
                            l + 1 == L ? 1 : 0, b.lambda);
@@ -1306,9 +1329,8 @@ hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const P
     if (e != hipSuccess) return e;
     if (T > 0) hipLaunchKernelGGL(k_ns_rhs, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
     launch_factor(b, stream, npc, n1, 1);
-    e = launch_backsub_spd(b, stream, npc);
+    e = launch_backsub_spd(b, stream, npc, T);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ns_recover, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad);
     return launch_pack(b, stream);
 }
 
