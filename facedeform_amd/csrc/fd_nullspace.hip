@@ -916,15 +916,24 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
         // macro tiles: two A operands (16 rows each) against two B operands give four MFMA chains,
         // so every operand byte loaded is used twice and a wave has 16 KB in flight.  The last
         // "tile" of a column pair is the right-hand sides (16 rows, of which three live).
+        //
+        // Rank 64 every other step: an even step (k0 / 32 even) touches only the column pair that
+        // becomes the next panel but one; the odd step after it applies BOTH panels, k0 - 32 and
+        // k0, to everything beyond in one pass -- each C tile of the bulk is read and written
+        // once per 64 columns instead of once per 32.  (The next panel's own columns get every
+        // panel on time from the panel workgroups.)  The B operands of both panels wait in LDS.
         const int cbid = (int)blockIdx.x - npanel;
         const int cpair = 1 + cbid / nchunk, chunk = cbid % nchunk;
         const int c0 = kb + 32 * cpair;
-        double u0[S], u1[S];
+        const int depth = ((k0 >> 5) & 1) ? 2 : 1;
+        __shared__ double sU[2][2][S][64];
+        if (wave < 2 * depth) {
+            const int pp = wave >> 1, hh = wave & 1;
+            const int kp = k0 - 32 * (depth - 1 - pp);
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            u0[s] = -A[(size_t)(k0 + g + 4 * s) * lda + c0 + c];
-            u1[s] = -A[(size_t)(k0 + g + 4 * s) * lda + c0 + 16 + c];
+            for (int s = 0; s < S; ++s) sU[pp][hh][s][lane] = -A[(size_t)(kp + g + 4 * s) * lda + c0 + 16 * hh + c];
         }
+        __syncthreads();
         const int mt = (npc - c0) / 32;                   // macro tiles of this column pair; index mt = RHS
         const size_t cs = (size_t)4 * lda;
         for (int t = chunk * 4 + wave; t <= mt; t += 4 * nchunk) {
@@ -933,35 +942,42 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
                 gdouble *p00 = A + (size_t)(c0 + g) * lda + r0 + c;      // rows r0.., columns c0.. (accumulator transposed)
                 gdouble *p01 = p00 + (size_t)16 * lda;                    // columns c0 + 16..
                 gdouble *p10 = p00 + 16, *p11 = p01 + 16;                 // rows r0 + 16..
-                gcdouble *aptr = A + (size_t)(k0 + g) * lda + r0 + c;
-                double av0[S], av1[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) { av0[s] = aptr[(size_t)(4 * s) * lda]; av1[s] = aptr[(size_t)(4 * s) * lda + 16]; }
                 double4_t a00, a01, a10, a11;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { a00[r] = p00[r * cs]; a01[r] = p01[r * cs]; a10[r] = p10[r * cs]; a11[r] = p11[r * cs]; }
+                for (int pp = 0; pp < depth; ++pp) {
+                    const int kp = k0 - 32 * (depth - 1 - pp);
+                    gcdouble *aptr = A + (size_t)(kp + g) * lda + r0 + c;
+                    double av0[S], av1[S];
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0[s], av0[s], a00, 0, 0, 0);
-                    a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[s], av0[s], a01, 0, 0, 0);
-                    a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0[s], av1[s], a10, 0, 0, 0);
-                    a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[s], av1[s], a11, 0, 0, 0);
+                    for (int s = 0; s < S; ++s) { av0[s] = aptr[(size_t)(4 * s) * lda]; av1[s] = aptr[(size_t)(4 * s) * lda + 16]; }
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const double ua = sU[pp][0][s][lane], ub = sU[pp][1][s][lane];
+                        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua, av0[s], a00, 0, 0, 0);
+                        a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(ub, av0[s], a01, 0, 0, 0);
+                        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua, av1[s], a10, 0, 0, 0);
+                        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(ub, av1[s], a11, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { p00[r * cs] = a00[r]; p01[r * cs] = a01[r]; p10[r * cs] = a10[r]; p11[r * cs] = a11[r]; }
             } else {
                 gdouble *p0 = A + (size_t)(npad + c) * lda + c0 + g, *p1 = p0 + 16;
-                gcdouble *aptr = A + (size_t)(npad + c) * lda + k0 + g;
-                double av[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) av[s] = aptr[4 * s];
                 double4_t a0, a1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { a0[r] = p0[4 * r]; a1[r] = p1[4 * r]; }
+                for (int pp = 0; pp < depth; ++pp) {
+                    const int kp = k0 - 32 * (depth - 1 - pp);
+                    gcdouble *aptr = A + (size_t)(npad + c) * lda + kp + g;
+                    double av[S];
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0[s], av[s], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[s], av[s], a1, 0, 0, 0);
+                    for (int s = 0; s < S; ++s) av[s] = aptr[4 * s];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[pp][0][s][lane], av[s], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[pp][1][s][lane], av[s], a1, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { p0[4 * r] = a0[r]; p1[4 * r] = a1[r]; }
@@ -1225,7 +1241,9 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
             // macro tiles per column pair: up to (ncb / 2 - 1); four waves per workgroup, about two tiles each
             int nchunk = (ncb / 2 + 7) / 8;
             nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
-            const int nreg = ncb > 2 ? (ncb / 2 - 1) * nchunk : 0;
+            // even steps touch one column pair only, odd steps everything beyond the next panel at rank 64
+            const bool even = ((k0 >> 5) & 1) == 0;
+            const int nreg = ncb > 2 ? (even ? nchunk : (ncb / 2 - 1) * nchunk) : 0;
             hipLaunchKernelGGL(k_chol_step, dim3(npanel + nreg, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
                                n1, k0, nchunk, npanel);
         }
