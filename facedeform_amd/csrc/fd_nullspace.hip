@@ -56,6 +56,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNB = 32;                 // Cholesky block width
 constexpr int kSlab = 256;              // rows per workgroup of the panel's triangular solve
+constexpr int kBulk = 4;                 // fused step: the bulk of the trailing matrix is updated every kBulk steps
 constexpr int kStepSlab = 192;          // ... in the fused step kernel: three waves of rows, the fourth factorises
 
 // small block of the solver state, after V, W and B21 (each M x 4)
@@ -917,18 +918,20 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
         // so every operand byte loaded is used twice and a wave has 16 KB in flight.  The last
         // "tile" of a column pair is the right-hand sides (16 rows, of which three live).
         //
-        // Rank 64 every other step: an even step (k0 / 32 even) touches only the column pair that
-        // becomes the next panel but one; the odd step after it applies BOTH panels, k0 - 32 and
-        // k0, to everything beyond in one pass -- each C tile of the bulk is read and written
-        // once per 64 columns instead of once per 32.  (The next panel's own columns get every
-        // panel on time from the panel workgroups.)  The B operands of both panels wait in LDS.
+        // Deep updates: only every kBulk-th step touches the bulk of the trailing matrix, with all
+        // kBulk panels since the last time in one pass (rank 128: each C tile is read and written
+        // once per 128 columns instead of once per 32); the steps in between bring just the column
+        // pair that becomes the next panel but one up to date, with the panels pending for it.
+        // (The next panel's own columns get every panel on time from the panel workgroups.)  The
+        // B operands of all pending panels wait in LDS.
         const int cbid = (int)blockIdx.x - npanel;
         const int cpair = 1 + cbid / nchunk, chunk = cbid % nchunk;
         const int c0 = kb + 32 * cpair;
-        const int depth = ((k0 >> 5) & 1) ? 2 : 1;
-        __shared__ double sU[2][2][S][64];
-        if (wave < 2 * depth) {
-            const int pp = wave >> 1, hh = wave & 1;
+        // panels pending for these columns: all since the last bulk step (kBulk = 4 steps apart)
+        const int depth = ((k0 >> 5) % kBulk) + 1;
+        __shared__ double sU[kBulk][2][S][64];
+        for (int q = wave; q < 2 * depth; q += 4) {
+            const int pp = q >> 1, hh = q & 1;
             const int kp = k0 - 32 * (depth - 1 - pp);
 #pragma unroll
             for (int s = 0; s < S; ++s) sU[pp][hh][s][lane] = -A[(size_t)(kp + g + 4 * s) * lda + c0 + 16 * hh + c];
@@ -1241,9 +1244,9 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
             // macro tiles per column pair: up to (ncb / 2 - 1); four waves per workgroup, about two tiles each
             int nchunk = (ncb / 2 + 7) / 8;
             nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
-            // even steps touch one column pair only, odd steps everything beyond the next panel at rank 64
-            const bool even = ((k0 >> 5) & 1) == 0;
-            const int nreg = ncb > 2 ? (even ? nchunk : (ncb / 2 - 1) * nchunk) : 0;
+            // bulk steps update everything beyond the next panel, the others one column pair
+            const bool bulk = ((k0 >> 5) % kBulk) == kBulk - 1;
+            const int nreg = ncb > 2 ? (bulk ? (ncb / 2 - 1) * nchunk : nchunk) : 0;
             hipLaunchKernelGGL(k_chol_step, dim3(npanel + nreg, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
                                n1, k0, nchunk, npanel);
         }
