@@ -56,7 +56,8 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNB = 32;                 // Cholesky block width
 constexpr int kSlab = 256;              // rows per workgroup of the panel's triangular solve
-constexpr int kBulk = 4;                 // fused step: the bulk of the trailing matrix is updated every kBulk steps
+constexpr int kBulk = 4;                 // fused step, large systems: the bulk of the trailing matrix is updated every kBulk steps
+constexpr size_t kStepPanelLds = sizeof(double) * (2 * 32 * 34 + 2 * 32);   // diagonal block + its transpose + two 32-vectors
 constexpr int kStepSlab = 192;          // ... in the fused step kernel: three waves of rows, the fourth factorises
 
 // small block of the solver state, after V, W and B21 (each M x 4)
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_trail(const Bat
 //   the other workgroups: the trailing update of the columns from kb + 32 on, as k_chol_trail.
 // Nothing here waits on a flag: every dependency is inside one workgroup or across the launch.
 __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const BatchSlot *tab, int M, int lda, int npad, int npc, int n1,
-                                                                      int k0, int nchunk, int npanel)
+                                                                      int k0, int nchunk, int npanel, int bulk_every)
 {
     const BatchSlot &slot = tab[blockIdx.z];
     gdouble *A = as_global(slot.A);
@@ -911,6 +912,11 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
     const int kb = k0 + kNB;
     constexpr int S = kNB / 4;
     __builtin_amdgcn_s_setprio(3);
+    // One dynamic LDS block, used either way round: the panel workgroups keep the diagonal block in
+    // it, the others the B operands of their pending panels (8 KB per panel).  Small systems
+    // (bulk_every = 1) then need no more LDS than the panel work -- a build that runs beside an
+    // evaluation has to find its LDS between that kernel's workgroups as well as its registers.
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
 
     if ((int)blockIdx.x >= npanel) {
         // Trailing update of a PAIR of 16-column blocks (32 columns from kb + 32 on) in 32 x 32
@@ -927,9 +933,9 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
         const int cbid = (int)blockIdx.x - npanel;
         const int cpair = 1 + cbid / nchunk, chunk = cbid % nchunk;
         const int c0 = kb + 32 * cpair;
-        // panels pending for these columns: all since the last bulk step (kBulk = 4 steps apart)
-        const int depth = ((k0 >> 5) % kBulk) + 1;
-        __shared__ double sU[kBulk][2][S][64];
+        // panels pending for these columns: all since the last bulk step (bulk_every steps apart)
+        const int depth = ((k0 >> 5) % bulk_every) + 1;
+        double (*sU)[2][S][64] = reinterpret_cast<double (*)[2][S][64]>(dyn_lds);
         for (int q = wave; q < 2 * depth; q += 4) {
             const int pp = q >> 1, hh = q & 1;
             const int kp = k0 - 32 * (depth - 1 - pp);
@@ -992,10 +998,10 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
     // ---- panel workgroup: wave 0 factorises; waves 1..3 own 64 rows each -- they apply panel k0 to
     // them, fetch them back into registers (no workgroup barrier in between: a wave reads what it
     // wrote) and solve them once L11 is there
-    __shared__ __attribute__((aligned(16))) double sC[kNB][kLdsRow];
-    __shared__ __attribute__((aligned(16))) double sR[kNB][kLdsRow];
-    __shared__ __attribute__((aligned(16))) double sCol[kNB];
-    __shared__ double sInv[kNB];
+    double (*sC)[kLdsRow] = reinterpret_cast<double (*)[kLdsRow]>(dyn_lds);
+    double (*sR)[kLdsRow] = reinterpret_cast<double (*)[kLdsRow]>(dyn_lds + kNB * kLdsRow);
+    double *sCol = dyn_lds + 2 * kNB * kLdsRow;
+    double *sInv = sCol + kNB;
     const bool rhs = (int)blockIdx.x == npanel - 1;
     const int slab0 = kb + kNB + (int)blockIdx.x * kStepSlab;   // first row of a matrix slab
     const bool first = k0 < 0;                // the first block: no panel before it, nothing to apply
@@ -1219,8 +1225,8 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
     if (!rhs_only && !unfused) {
         // block 0: the step kernel with no panel before it (factorise, solve the rows below, nothing else)
         const int npanel = (npc - kNB + kStepSlab - 1) / kStepSlab + 1;
-        hipLaunchKernelGGL(k_chol_step, dim3(npanel, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc, n1,
-                           -kNB, 1, npanel);
+        hipLaunchKernelGGL(k_chol_step, dim3(npanel, 1, nb), dim3(256), kStepPanelLds, stream, b.d_slots, b.M, b.lda, b.npad,
+                           npc, n1, -kNB, 1, npanel, 1);
     }
     for (int k0 = 0; k0 < npc; k0 += kNB) {
         const int below = npc - k0 - kNB;
@@ -1245,10 +1251,14 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
             int nchunk = (ncb / 2 + 7) / 8;
             nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
             // bulk steps update everything beyond the next panel, the others one column pair
-            const bool bulk = ((k0 >> 5) % kBulk) == kBulk - 1;
+            // deferring the bulk pays where the trailing matrix is large; a small system updates
+            // everything every step and keeps its LDS footprint at the panel work's
+            const int bulk_every = npc > 512 ? kBulk : 1;
+            const bool bulk = ((k0 >> 5) % bulk_every) == bulk_every - 1;
             const int nreg = ncb > 2 ? (bulk ? (ncb / 2 - 1) * nchunk : nchunk) : 0;
-            hipLaunchKernelGGL(k_chol_step, dim3(npanel + nreg, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, b.npad, npc,
-                               n1, k0, nchunk, npanel);
+            const size_t lds = (size_t)bulk_every * 8192 > kStepPanelLds ? (size_t)bulk_every * 8192 : kStepPanelLds;
+            hipLaunchKernelGGL(k_chol_step, dim3(npanel + nreg, 1, nb), dim3(256), lds, stream, b.d_slots, b.M, b.lda, b.npad, npc,
+                               n1, k0, nchunk, npanel, bulk_every);
         }
     }
 }
