@@ -18,23 +18,29 @@
 // 2052); here only the 32 x 32 diagonal block is sequential, the rows below it are independent.
 //
 // Pipeline (every kernel indexes the batch table with blockIdx.z, like the LU kernels):
-//   k_ns_reflectors   one workgroup: Householder vectors V (M x T), tau, R, the compact-WY factor
-//   k_ns_rhs          one workgroup: f <- Q^T f in the right-hand-side columns of A
+//   k_ns_reflectors   one workgroup: Householder vectors V (M x T), tau, R, the compact-WY factor;
+//                     then f <- Q^T f in the right-hand-side columns of A (k_ns_rhs on its own
+//                     for fd_set_deltas)
 //   k_assemble        (fd_build.hip) K into A, full square
 //   k_ns_kv           Y = K V, then (its last workgroup) W = Y Tm - (1/2) V (Tm^T V^T Y Tm),
 //                     so that B = K - V W^T - W V^T
 //   k_ns_rotate       lower triangle of B11 in place, B21 aside, identity padding to npc
-//   per 32 columns:   k_chol_solve (the rows below the diagonal block and the right-hand sides:
-//                     X L11^T = A21, one row per thread) and k_chol_trail (A22 -= L21 L21^T,
-//                     lower triangle, v_mfma_f64_16x16x4_f64) whose last workgroup updates and
-//                     factorises the NEXT diagonal block (one wave, rows in registers) beside the
-//                     others -- the sequential part is off the critical path.
+//   k_chol_step       ONE launch per 32 columns.  Panel workgroups: the next diagonal block with
+//                     the current panel applied (MFMA, into LDS), factorised by one wave in every
+//                     workgroup for itself, while the other waves apply the current panel to
+//                     their rows of the next panel; then X L11^T = A21, one row per thread.  The
+//                     other workgroups: A22 -= L21 L21^T on the lower triangle in 32 x 32 macro
+//                     tiles of v_mfma_f64_16x16x4_f64 -- above order 512 only every fourth step,
+//                     at rank 128, with the steps in between keeping one column pair current.
 //                     The right-hand sides ride along as three extra rows, so the forward solve
-//                     costs nothing; L^T is mirrored into the upper triangle as it is produced,
-//   k_backsub_inv     L^T y = z with the inverted diagonal blocks (a by-product of k_chol_solve's
-//                     otherwise idle right-hand-side workgroup); k_backsub_update (fd_build.hip)
-//                     chains 256-row ranges above order 512
-//   k_ns_recover      a from R, w = Q [y; 0], into X in the layout k_pack expects.
+//                     costs nothing; L^T is mirrored into the upper triangle as it is produced.
+//                     (k_chol_first / k_chol_solve / k_chol_trail: the unfused pieces, used by
+//                     fd_set_deltas and by FD_CHOL_UNFUSED.)
+//   k_backsub_inv     L^T y = z with the inverted diagonal blocks (a by-product of an otherwise
+//                     idle wave of the right-hand-side workgroup), then -- one-range systems --
+//                     a from R and w = Q [y; 0] into X in the layout k_pack expects
+//                     (k_ns_recover on its own above order 512, after the chained ranges and
+//                     fd_build.hip's k_backsub_update).
 //
 // fd_set_deltas (launch_resolve_spd) sends new right-hand sides through the same kernels with the
 // matrix work switched off: identical operands in identical order, bit-identical weights.
@@ -56,7 +62,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNB = 32;                 // Cholesky block width
 constexpr int kSlab = 256;              // rows per workgroup of the panel's triangular solve
-constexpr int kBulk = 4;                 // fused step, large systems: the bulk of the trailing matrix is updated every kBulk steps
+constexpr int kBulk = 4;                // fused step, large systems: the bulk of the trailing matrix is updated every kBulk steps
 constexpr size_t kStepPanelLds = sizeof(double) * (2 * 32 * 34 + 2 * 32);   // diagonal block + its transpose + two 32-vectors
 constexpr int kStepSlab = 192;          // ... in the fused step kernel: three waves of rows, the fourth factorises
 
