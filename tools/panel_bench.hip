@@ -1,6 +1,7 @@
 // panel_bench.hip -- diagnostic: where does one LU panel (32 columns) spend its cycles?
 // Includes the product kernels with FD_PANEL_STAMPS; prints per-phase shader cycles per column.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include tools/panel_bench.hip -o tools/panel_bench
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include tools/panel_bench.hip facedeform_amd/csrc/fd_nullspace.hip -o tools/panel_bench
+//        (fd_build.hip dispatches to the null-space solver, so its translation unit comes along)
 #define FD_PANEL_STAMPS 1
 #include "../facedeform_amd/csrc/fd_build.hip"
 #include <cstdio>
