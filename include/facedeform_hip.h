@@ -85,7 +85,10 @@ enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
  * non-symmetric) goes through LU with partial pivoting.  LU forces the latter everywhere.  A
  * system on which the Cholesky loses definiteness to rounding (centres one fp32 step apart, a
  * fixed-radius Gaussian wider than the rig) is rebuilt with the LU before anything is reported,
- * and the context keeps the LU until its kernel, term or M change: nothing the LU accepts fails.  Both
+ * and the context keeps the LU until its kernel, term or M change: nothing the LU accepts fails.
+ * (The rebuild happens where the status is read -- fd_build, fd_build_result, fd_batch_build_result;
+ * a pipeline that enqueues builds and evaluations without ever collecting a result evaluates such
+ * a rig as a failed model, i.e. passes the mesh through, until it does.)  Both
  * are fp64 direct solves of the same system: their weights agree to rounding (~1e-12 relative
  * on the benchmark rigs), far inside the parity tolerance. */
 enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1 };
