@@ -52,8 +52,8 @@ N_FRAMES = 64
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--variant", type=int, default=0, help="evaluation kernel variant (0 = auto)")
     ap.add_argument("--precision", choices=["fp32", "fp64"], default="fp32")
