@@ -124,3 +124,16 @@ def test_cook_without_gpu_reports_engine_error(hip_lib):
     res = node.cook(mesh, rest, rest + 0.1)
     assert res.severity == capi.FDSOP_ERROR
     assert any("GPU deformation engine" in e for e in res.errors)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path or nothing: on a box without a GPU it must stop with a
+    message, not fall back to the oracle (only its cpu_baseline leg may touch oracle/)."""
+    import subprocess, sys, os, torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "no GPU visible" in (r.stderr + r.stdout)
