@@ -115,25 +115,26 @@ def cpu_baseline(cfg_name, P, rest, deform, max_pairs):
     }
 
 
-def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev, rehearse):
+def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev, rehearse, ranks):
     """BASELINE config 5: ONE mesh, contiguous page-aligned vertex ranges per rank.  Frames are
     cooked in groups: rank 0 assembles + solves the group's models with ONE batched build and
     exports them into one device buffer, ONE broadcast per group (RCCL over xGMI with the nccl
     backend), every rank imports the models and evaluates its own vertex range for all frames of
     the group with one launch.  Two lanes alternate, so rank 0's next build overlaps the current
-    evaluations.  The mesh is resident on every rank; only ~28 KB per frame move.  Strong scaling."""
+    evaluations.  The mesh is resident on every rank; only ~28 KB per frame move.  Strong scaling.
+    Both of SURVEY 8(e)'s alternatives are timed, one after the other: the broadcast, and every
+    rank solving the (small) systems itself with no collective on the data path."""
     from facedeform_amd import dist as fdist
     n_verts, n_ctrl, mesh_kind, desc = CONFIGS["c5"]
     lo, hi = fdist.vertex_range(n_verts, rank, world)
     n_mine = hi - lo
     B = max(1, min(args.inflight, 8))                 # frames per group (10M-vertex frames are large)
-    # SURVEY 8(e): the alternative to one broadcast is every rank solving the (tiny) system itself
-    redundant = args.c5_solve == "redundant"
     n_lanes = 2
     P_host = synth.head_mesh(n_verts)
     rest_host = synth.control_points(n_ctrl, mesh_kind)
     deltas_host = np.stack([synth.smooth_deltas(rest_host, f) for f in range(N_FRAMES)])
     d_P = torch.from_numpy(P_host[lo:hi]).to(dev)
+    del P_host
     d_rest = torch.from_numpy(rest_host).to(dev)
     d_deltas = torch.from_numpy(deltas_host).to(dev)
     delta_stride = n_ctrl * 3 * 4
@@ -157,39 +158,6 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
                       "out": [torch.empty_like(d_P) for _ in range(B)],
                       "fall": [torch.zeros(max(n_mine, 1), device=dev, dtype=torch.float32) for _ in range(B)]})
     n_groups = (args.steps + B - 1) // B
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_groups)]
-
-    def group(g, first, e=None):
-        """Frames first .. first + B - 1 (always a full group: the last one may cook spare frames)."""
-        ln = lanes[g % n_lanes]
-        stream, engines, batch, blob = ln["stream"], ln["engines"], ln["batch"], ln["blob"]
-        frames = [(first + k) % N_FRAMES for k in range(B)]
-        with torch.cuda.stream(stream):
-            if e: e[0].record(stream)
-            if rank == 0 or redundant:
-                batch.set_points_dev([d_rest.data_ptr()] * B, [d_deltas.data_ptr() + f * delta_stride for f in frames], n_ctrl)
-                batch.build_async(stream.cuda_stream)
-                if world > 1 and not redundant:
-                    for k, eng in enumerate(engines):
-                        eng.export_model_dev(blob[k].data_ptr(), nbytes)      # waits for the build status
-            if e: e[1].record(stream)
-            if world > 1 and not redundant:
-                if rehearse:                                            # gloo: through host memory
-                    if rank == 0:
-                        ln["blob_host"].copy_(blob, non_blocking=False)
-                    dist.broadcast(ln["blob_host"], src=0)
-                    if rank != 0:
-                        blob.copy_(ln["blob_host"], non_blocking=False)
-                else:
-                    dist.broadcast(blob, src=0)
-                if rank != 0:
-                    for k, eng in enumerate(engines):
-                        eng.import_model_dev(blob[k].data_ptr(), nbytes, n_ctrl)
-            if e: e[2].record(stream)
-            if n_mine > 0:
-                batch.deform_dev(n_mine, [d_P.data_ptr()] * B, [o.data_ptr() for o in ln["out"]],
-                                 d_falloff=[f.data_ptr() for f in ln["fall"]], stream_ptr=stream.cuda_stream)
-            if e: e[3].record(stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -197,32 +165,77 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
             dist.barrier()
             torch.cuda.synchronize()
 
-    for g in range((args.warmup + B - 1) // B + n_lanes):
-        group(g, g * B)
-    sync_all()
-    t0 = time.perf_counter()
-    for g in range(n_groups):
-        group(g, g * B, ev[g])
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    def one_mode(redundant):
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_groups)]
+
+        def group(g, first, e=None):
+            """Frames first .. first + B - 1 (always a full group: the last one may cook spare frames)."""
+            ln = lanes[g % n_lanes]
+            stream, engines, batch, blob = ln["stream"], ln["engines"], ln["batch"], ln["blob"]
+            frames = [(first + k) % N_FRAMES for k in range(B)]
+            with torch.cuda.stream(stream):
+                if e: e[0].record(stream)
+                if rank == 0 or redundant:
+                    batch.set_points_dev([d_rest.data_ptr()] * B, [d_deltas.data_ptr() + f * delta_stride for f in frames], n_ctrl)
+                    batch.build_async(stream.cuda_stream)
+                    if world > 1 and not redundant:
+                        for k, eng in enumerate(engines):
+                            eng.export_model_dev(blob[k].data_ptr(), nbytes)      # waits for the build status
+                if e: e[1].record(stream)
+                if world > 1 and not redundant:
+                    if rehearse:                                            # gloo: through host memory
+                        if rank == 0:
+                            ln["blob_host"].copy_(blob, non_blocking=False)
+                        dist.broadcast(ln["blob_host"], src=0)
+                        if rank != 0:
+                            blob.copy_(ln["blob_host"], non_blocking=False)
+                    else:
+                        dist.broadcast(blob, src=0)
+                    if rank != 0:
+                        for k, eng in enumerate(engines):
+                            eng.import_model_dev(blob[k].data_ptr(), nbytes, n_ctrl)
+                if e: e[2].record(stream)
+                if n_mine > 0:
+                    batch.deform_dev(n_mine, [d_P.data_ptr()] * B, [o.data_ptr() for o in ln["out"]],
+                                     d_falloff=[f.data_ptr() for f in ln["fall"]], stream_ptr=stream.cuda_stream)
+                if e: e[3].record(stream)
+
+        if redundant and rank != 0:
+            for ln in lanes:                       # contexts that only imported so far get control points of their own
+                for eng in ln["engines"]:
+                    eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr(), n_ctrl)
+        for g in range((args.warmup + B - 1) // B + n_lanes):
+            group(g, g * B)
+        sync_all()
+        t0 = time.perf_counter()
+        for g in range(n_groups):
+            group(g, g * B, ev[g])
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return {"elapsed": float(t.item()),
+                "build_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
+                "bcast_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in ev])),
+                "eval_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))}
+
+    order = ["broadcast", "redundant"] if args.c5_solve == "broadcast" else ["redundant", "broadcast"]
+    res = {m: one_mode(m == "redundant") for m in order}
+    main_r, alt_r = res[order[0]], res[order[1]]
+    redundant = order[0] == "redundant"
     frames_done = n_groups * B                    # >= args.steps; the surplus is work done, not credited
     if rank == 0:
-        build_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        bcast_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-        eval_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
         flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_mine * B
-        tf = flops / (eval_ms * 1e-3) / 1e12
+        tf = flops / (main_r["eval_ms"] * 1e-3) / 1e12
+        mv = lambda r: args.steps * n_verts / r["elapsed"] / 1e6
         print(json.dumps({
             "metric": "deformed Mverts/sec, one 10M-vert mesh at 512 ctrl pts split across the GPUs",
-            "value": args.steps * n_verts / elapsed / 1e6, "unit": "Mverts/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "value": mv(main_r), "unit": "Mverts/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc + ", thin-plate kernel, linear term, models rebuilt " +
+            "config": {"workload": desc + ", thin-plate kernel, linear term, d2 on fp16x2-split MFMA with fp32 accumulation, models rebuilt " +
                                    ("on every rank every step " if redundant else "on rank 0 every step ") +
                                    f"({B} per batched build)" + ("" if redundant else f", one broadcast per {B} frames"),
                        "n_verts": n_verts,
@@ -230,11 +243,17 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
                        "frames_per_group": B, "frames_cooked": frames_done,
                        "parallelism": (f"vertex ranges over {world} GPU(s), every rank solves the models itself, {n_lanes} lanes" if redundant else
                                        f"vertex ranges over {world} GPU(s), 1 broadcast per {B} frames, {n_lanes} lanes")},
-            "roofline": {"bound": "mfma", "kernel": "k_deform32_tps_mfma_batch" if B > 1 else "k_deform32_tps_mfma",
+            "ranks": ranks,
+            "roofline": {"bound": "valu_fp32", "kernel": "k_deform32_tps_mfma_batch" if B > 1 else "k_deform32_tps_mfma",
                          "achieved": tf, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
-                         "flops_per_launch": flops, "avg_launch_ms": eval_ms, "frames_per_launch": B},
-            "phases_ms": {"build_group_rank0": build_ms, "broadcast_and_import": bcast_ms, "evaluate_group": eval_ms},
+                         "flops_per_launch": flops, "avg_launch_ms": main_r["eval_ms"], "frames_per_launch": B},
+            "phases_ms": {"build_group_rank0": main_r["build_ms"], "broadcast_and_import": main_r["bcast_ms"],
+                          "evaluate_group": main_r["eval_ms"]},
+            # the other way of getting the model to every rank, same run, same sizes
+            "alternative": {"c5_solve": order[1], "value": mv(alt_r), "ms_per_step": alt_r["elapsed"] / args.steps * 1e3,
+                            "phases_ms": {"build_group": alt_r["build_ms"], "broadcast_and_import": alt_r["bcast_ms"],
+                                          "evaluate_group": alt_r["eval_ms"]}},
         }), flush=True)
     torch.cuda.synchronize()
     for ln in lanes:
@@ -246,8 +265,65 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
         dist.destroy_process_group()
 
 
+def rank_report(torch, dist, rank, world, local_rank, rehearse):
+    """Who ran: the process group's size as torch.distributed reports it and every rank's device, so
+    that a reader of the JSON line sees N ranks on N GPUs rather than taking n_gpus on trust."""
+    props = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": rank, "local_device": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+            "pid": os.getpid()}
+    everyone = [mine]
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+    return {"world_size": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else None),
+            "collective_library": ("gloo (FD_BENCH_REHEARSE)" if rehearse else "RCCL (torch.distributed nccl backend)") if world > 1 else None,
+            "launcher": os.environ.get("FD_BENCH_LAUNCHER", "external" if "RANK" in os.environ else "none"),
+            "devices": everyone}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves,
+    as a CHILD process (`python -m torch.distributed.run`, one rank per GPU), before this process
+    has made any HIP call -- a process that has initialised the GPU must never be replaced by
+    another program.  Rank 0's JSON line and the launcher's return code are relayed."""
+    import socket
+    import subprocess
+    import torch          # importing torch and counting devices do not initialise HIP
+    rehearse = os.environ.get("FD_BENCH_REHEARSE") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not rehearse:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node; "
+                         "refusing to report a multi-GPU figure from fewer devices")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env["FD_BENCH_LAUNCHER"] = "self"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for ln in proc.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            lines.append(ln)
+        else:
+            print(ln, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    for ln in lines:
+        print(ln, flush=True)
+    if rc == 0 and not lines:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    raise SystemExit(rc)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
     from facedeform_amd import capi, synth
@@ -255,8 +331,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the engine has no CPU path)")
     # FD_BENCH_REHEARSE=1: several ranks share GPU 0 and talk over gloo -- only for rehearsing the
@@ -273,9 +349,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    ranks = rank_report(torch, dist, rank, world, local_rank, rehearse)
     n_verts, n_ctrl, mesh_kind, desc = CONFIGS[args.config]
     if args.config == "c5":
-        return run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev, rehearse)
+        return run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev, rehearse, ranks)
     P_host = synth.sphere_mesh(n_verts) if mesh_kind == "sphere" else synth.head_mesh(n_verts)
     rest_host = synth.control_points(n_ctrl, mesh_kind)
     deltas_host = np.stack([synth.smooth_deltas(rest_host, f) for f in range(N_FRAMES)])
@@ -490,8 +567,10 @@ def main():
             "dtype": "f32" if precision == capi.EVAL_FP32 else "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{desc}, thin-plate kernel, linear term, {args.precision} evaluation, "
-                            "fp64 dense solve rebuilt every step (assemble + direct solve + evaluate), one frame per step",
+                "workload": f"{desc}, thin-plate kernel, linear term, {args.precision} evaluation"
+                            + (" (squared distances on the matrix pipe from fp16 x 2 split operands, 22 bits; fp32 "
+                               "logarithm, weights and accumulation)" if (precision == capi.EVAL_FP32 and n_ctrl >= 49) else "")
+                            + ", fp64 dense solve rebuilt every step (assemble + direct solve + evaluate), one frame per step",
                 "n_verts": n_verts, "n_ctrl": n_ctrl,
                 "frames_per_batched_build": B, "frames_per_evaluation_launch": frames_per_launch,
                 "lanes_per_gpu": n_lanes,
@@ -500,9 +579,11 @@ def main():
                                "stream), no collective",
             },
             "roofline": {
-                # the evaluation kernel is compute-bound at this M (intensity ~182 flop/B vs ridge ~20):
-                # its roof is the fp32 rate, 157.3 TFLOP/s for VALU and MFMA alike on gfx950
-                "bound": "mfma",
+                # the evaluation kernel is compute-bound at this M (intensity ~182 flop/B vs ridge ~20) and
+                # its binding pipe is the fp32 VECTOR unit (logarithm + weight contraction), not the
+                # matrix pipe, which only forms the squared distances: PMC in profiles/ (VALU active
+                # ~90-100 % of busy cycles, MFMA pipe busy 13-17 %).  Roof: 157.3 TFLOP/s fp32 vector.
+                "bound": "valu_fp32",
                 "kernel": ("k_deform32_tps_mfma_batch" if frames_per_launch > 1 else "k_deform32_tps_mfma")
                           if (precision == capi.EVAL_FP32 and n_ctrl >= 49) else
                           ("k_deform32" if precision == capi.EVAL_FP32 else "k_deform64"),
@@ -515,6 +596,7 @@ def main():
                         "frac": achieved_gbs / PEAK_HBM_GBS,
                         "bytes_per_launch": BYTES_PER_VERTEX * n_verts * frames_per_launch},
             },
+            "ranks": ranks,
             "phases_ms": {"build_per_frame_batched": build_ms, "build_batch": build_group_ms,
                           "evaluate": eval_ms, "single_cook_latency": latency_ms},
             "eval_only_mverts_s": n_verts / (eval_ms * 1e-3) / 1e6,

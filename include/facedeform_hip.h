@@ -72,9 +72,15 @@ enum {
 /* Same integers as ALGLIB_TERM_LINEAR/CONST/ZERO, src/SOP_FaceDeform.hpp:16-18. */
 enum { FD_TERM_LINEAR = 0, FD_TERM_CONST = 1, FD_TERM_ZERO = 2 };
 
-/* Evaluation arithmetic.  FP32: fp32 distances and kernel, partial sums folded
- * into fp64 every 64 centres.  FP64: everything in fp64 (ill-conditioned
- * weights).  The solve is always fp64. */
+/* Evaluation arithmetic.  The solve is always fp64.
+ * FP32, thin-plate with 49 or more centres (the default kernel of BASELINE's configurations,
+ *   k_deform32_tps_mfma): the squared distances come from the matrix pipe as
+ *   |x|^2 - 2 x.c + |c|^2 on operands split into two fp16 pieces (22 significant bits, about
+ *   1.4e-6 absolute in normalised coordinates); logarithm, weights and accumulation are fp32,
+ *   partial sums folded into a second fp32 level every <= 96 terms.  No fp64 anywhere.
+ * FP32, every other kernel and small rigs (k_deform32): fp32 coordinate differences and kernel,
+ *   partial sums folded into fp64 accumulators every 64 centres.
+ * FP64: everything in fp64 (ill-conditioned weights). */
 enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
 
 /* Direct solver of the dense system.  AUTO: where the kernel is conditionally positive definite

@@ -137,3 +137,32 @@ def test_bench_refuses_to_run_without_a_gpu():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "no GPU visible" in (r.stderr + r.stdout)
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` starts its N ranks itself (a child torch.distributed.run, before any
+    HIP call).  Asked for more GPUs than the node shows it must exit non-zero with a message and no
+    result line -- never a one-GPU figure labelled N.  Runs here (0 GPUs) and on
+    a one-GPU box alike."""
+    import subprocess, sys, os, torch
+    have = torch.cuda.device_count()
+    if have >= 8:
+        pytest.skip("an 8-GPU node: nothing to refuse")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FD_BENCH_REHEARSE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(have + 1 if have else 2),
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "GPU(s) visible" in (r.stderr + r.stdout)
+    assert '"metric"' not in r.stdout
+
+
+def test_bench_rank_count_must_match_gpus_flag():
+    """Started by a launcher with a world size other than --gpus: refuse (before touching a device)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -112,8 +112,13 @@ def test_epilogue_gate_falloff_and_tangents(hip_lib, oracle):
         assert gated.any() and (~gated).any()
         assert np.array_equal(out[gated], P[gated])                 # B2: untouched
         assert np.array_equal(fall[gated], np.zeros(gated.sum(), np.float32))
-        assert np.allclose(fall, ref_fall, rtol=2e-6, atol=1e-7), rate   # powf: device vs libm
-        assert parity_ratio(out, ref, P, 3e-5) <= 1.0, rate         # fp32 tangent algebra on both sides
+        assert np.allclose(fall, ref_fall, rtol=2e-6, atol=1e-7), rate   # powf: device vs libm (measured 1.2e-7)
+        # 1e-5 of the displacement plus the rounding of P + d.  (Round 1 had 3e-5 here with no cause
+        # named.  tests/tools/tolerance_budget.py names it: the RBF displacement is within 4.3e-6
+        # and the fall-off within 1.2e-7 everywhere; what is left at the worst vertices is exactly
+        # one ulp(P) = 5.96e-8 -- P + d rounds to the neighbouring float -- on a displacement that
+        # fall-off and projection have shrunk 20-100 fold.  parity_ratio carries that ulp.)
+        assert parity_ratio(out, ref, P, TOL_FP32) <= 1.0, (rate, parity_ratio(out, ref, P, TOL_FP32))
         e.close()
 
 
@@ -277,7 +282,7 @@ def test_sop_cook_matches_oracle_and_reports_like_reference(hip_lib, oracle):
     r2 = np.float32(0.7) * np.float32(0.7)
     ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=dist2, radius2=r2,
                                   falloffrate=1.5)
-    assert parity_ratio(res.P, ref, P, 2e-5) <= 1.0
+    assert parity_ratio(res.P, ref, P, TOL_FP32) <= 1.0, parity_ratio(res.P, ref, P, TOL_FP32)   # (2e-5 in round 1: see the epilogue test)
     assert np.allclose(res.fd_falloff, ref_fall, rtol=2e-6, atol=1e-7)
     assert np.array_equal(res.Cd, np.ones_like(P))                     # :386-388
     # defaults: QNN Gaussian, linear term; no dist attribute -> warning text of :398
