@@ -45,7 +45,9 @@ class FdsopGeo(C.Structure):
                 ("nshapes", C.c_int64), ("shapes_P", C.POINTER(C.c_void_p)), ("shapes_npoints", C.POINTER(C.c_int64)),
                 ("rest", _f32p), ("rest_changed", C.c_int), ("blends_changed", C.c_int),
                 ("weights", C.POINTER(C.c_double)), ("weights_count", C.POINTER(C.c_int64)),
-                ("rig_rest_unchanged", C.c_int), ("mesh_unchanged", C.c_int)]
+                ("rig_rest_unchanged", C.c_int), ("mesh_unchanged", C.c_int),
+                ("edge_offsets", C.POINTER(C.c_int64)), ("edge_neighbours", C.POINTER(C.c_int)),
+                ("rig_ntris", C.c_int64), ("rig_tris", _f32p), ("dist2_out", _f32p)]
 
 
 # every symbol include/facedeform_hip.h declares
@@ -54,7 +56,7 @@ EXPORTS = [
     "fd_set_points_dev", "fd_set_deltas", "fd_set_deltas_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_centres", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
-    "fd_mesh_set", "fd_mesh_size", "fd_deform_mesh",
+    "fd_mesh_set", "fd_mesh_size", "fd_deform_mesh", "fd_mesh_capture", "fd_mesh_get_dist2",
     "fd_capture_dist2", "fd_capture_dist2_dev", "fd_capture_islands", "fd_capture_islands_dev",
     "fd_morph_create", "fd_morph_destroy", "fd_morph_last_error", "fd_morph_init", "fd_morph_init_dev",
     "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
@@ -115,6 +117,8 @@ def load() -> C.CDLL:
     L.fd_mesh_set.argtypes = [vp, i64, vp, vp, vp, vp, vp]; L.fd_mesh_set.restype = i32
     L.fd_mesh_size.argtypes = [vp]; L.fd_mesh_size.restype = i64
     L.fd_deform_mesh.argtypes = [vp, vp, vp, C.c_float, C.c_float]; L.fd_deform_mesh.restype = i32
+    L.fd_mesh_capture.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, C.c_float, i32, vp]; L.fd_mesh_capture.restype = i32
+    L.fd_mesh_get_dist2.argtypes = [vp, vp]; L.fd_mesh_get_dist2.restype = i32
     L.fd_capture_dist2.argtypes = [vp, i64, vp, vp, i32, vp, C.c_float, i32, vp]; L.fd_capture_dist2.restype = i32
     L.fd_capture_dist2_dev.argtypes = [vp, i64, vp, vp, i32, vp, C.c_float, i32, vp]; L.fd_capture_dist2_dev.restype = i32
     L.fd_capture_islands.argtypes = [vp, i64, vp, vp, vp, i32, vp, i32, vp]; L.fd_capture_islands.restype = i32
@@ -291,6 +295,18 @@ class Engine:
         if tangents is not None:
             tu, tv, nr = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in tangents)
         self._check(self.L.fd_mesh_set(self.ctx, P.shape[0], _np_ptr(P), _np_ptr(d2), _np_ptr(tu), _np_ptr(tv), _np_ptr(nr)))
+
+    def mesh_capture(self, offsets, neighbours, rig, max_edges, triangles, radius2, dofalloff=True, want=True):
+        """ProximityCapture on the device-resident mesh (fd_mesh_capture); returns the dist2 array if wanted."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        neighbours = np.ascontiguousarray(neighbours, np.int32)
+        rig = np.ascontiguousarray(rig, np.float32).reshape(-1, 3)
+        tri = np.ascontiguousarray(triangles, np.float32).reshape(-1, 9)
+        out = np.empty(int(self.L.fd_mesh_size(self.ctx)), np.float32) if want else None
+        self._check(self.L.fd_mesh_capture(self.ctx, _np_ptr(offsets), _np_ptr(neighbours), rig.shape[0], _np_ptr(rig),
+                                           int(max_edges), tri.shape[0], _np_ptr(tri), float(radius2), int(bool(dofalloff)),
+                                           _np_ptr(out)))
+        return out
 
     def deform_mesh(self, P_out, falloff=None, radius2=1.0, falloffrate=1.0):
         """Evaluate the cached mesh into caller-owned arrays (page-locked ones are written in place)."""

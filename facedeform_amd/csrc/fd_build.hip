@@ -127,7 +127,8 @@ __global__ void k_qnn_nearest(const BatchSlot *tab, int M, double q)
     radii[i] = M > 1 ? q * sqrt(best) : q;
 }
 
-// lower median by rank selection, then R_i = min(R_i, z * median)
+// median by rank selection -- element M / 2 of the sorted radii (the upper one for even M: ALGLIB's
+// tmp[n/2] as recalled) -- then R_i = min(R_i, z * median)
 __global__ void k_qnn_median(const BatchSlot *tab, int M)
 {
     const double *radii = tab[blockIdx.z].radii;
@@ -140,7 +141,7 @@ __global__ void k_qnn_median(const BatchSlot *tab, int M)
         const double o = radii[j];
         rank += (o < r) || (o == r && j < i);
     }
-    if (rank == (M - 1) / 2) *median_out = r;
+    if (rank == M / 2) *median_out = r;
 }
 __global__ void k_qnn_cap(const BatchSlot *tab, int M, double z)
 {
@@ -1157,33 +1158,21 @@ hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const Point
     return hipGetLastError();
 }
 
-// everything after k_prepare: radii, assembly, LU, back-substitution, packing
-hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
+// QNN radii of every model of the batch: q * nearest neighbour, capped at z * median
+hipError_t launch_qnn_radii(const BuildBuffers &b, hipStream_t stream)
 {
-    if (b.ml_layers) return launch_build_ml(b, stream, ev_mid);
-    if (b.spd) return launch_build_spd(b, stream, ev_mid);
-    const int M = b.M;
     const unsigned nb = (unsigned)b.nbatch;
-    {
-        const int threads = 256;
-        if (b.kind == FD_KERNEL_GAUSSIAN_QNN) {
-            const int mb = (M + threads - 1) / threads;
-            hipLaunchKernelGGL(k_qnn_nearest, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, M, b.qnn_q);
-            hipLaunchKernelGGL(k_qnn_median, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, M);
-            hipLaunchKernelGGL(k_qnn_cap, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, M, b.qnn_z);
-        }
-        if (b.npad <= 512) {
-            const unsigned g = (unsigned)(b.npad + 31) / 32;
-            hipLaunchKernelGGL((k_assemble<2>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
-                               b.lda, b.kind, b.T, b.lambda, 0);
-        } else {
-            const unsigned g = (unsigned)(b.npad + 63) / 64;
-            hipLaunchKernelGGL((k_assemble<4>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
-                               b.lda, b.kind, b.T, b.lambda, 0);
-        }
-    }
-    if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+    const int threads = 256, mb = (b.M + threads - 1) / threads;
+    hipLaunchKernelGGL(k_qnn_nearest, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, b.M, b.qnn_q);
+    hipLaunchKernelGGL(k_qnn_median, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, b.M);
+    hipLaunchKernelGGL(k_qnn_cap, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, b.M, b.qnn_z);
+    return hipGetLastError();
+}
 
+// the pivoted LU of the assembled order-npad system (right-hand sides in the columns npad ..) and
+// its back-substitution into X; b.n real unknowns, the rest identity padding
+hipError_t launch_lu_factor_solve(const BuildBuffers &b, hipStream_t stream)
+{
     LuStreams st{};
     st.main = stream;
     st.aux = b.aux_stream;
@@ -1210,7 +1199,30 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
     // rejoin: whatever part-B update is still running on the aux stream
     if (st.rest_pending) (void)hipStreamWaitEvent(st.main, st.ev_rest[st.last_rest], 0);
     launch_backsub(b, stream, b.npad);
-    hipError_t e = launch_pack(b, stream);
+    return hipGetLastError();
+}
+
+// everything after k_prepare: radii, assembly, LU, back-substitution, packing
+hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
+{
+    if (b.ml_layers) return launch_build_ml(b, stream, ev_mid);
+    if (b.spd) return launch_build_spd(b, stream, ev_mid);
+    if (b.kind == FD_KERNEL_GAUSSIAN_QNN) return launch_build_qnn(b, stream, ev_mid);   // polynomial first (fd_nullspace.hip)
+    const int M = b.M;
+    const unsigned nb = (unsigned)b.nbatch;
+    if (b.npad <= 512) {
+        const unsigned g = (unsigned)(b.npad + 31) / 32;
+        hipLaunchKernelGGL((k_assemble<2>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
+                           b.lda, b.kind, b.T, b.lambda, 0);
+    } else {
+        const unsigned g = (unsigned)(b.npad + 63) / 64;
+        hipLaunchKernelGGL((k_assemble<4>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
+                           b.lda, b.kind, b.T, b.lambda, 0);
+    }
+    if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+    hipError_t e = launch_lu_factor_solve(b, stream);
+    if (e != hipSuccess) return e;
+    e = launch_pack(b, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
@@ -1247,18 +1259,11 @@ hipError_t launch_pack_from_weights(const BuildBuffers &b, hipStream_t stream, i
 // as in a full build: the weights are bit-identical to rebuilding from scratch.
 // Requires every panel width to be a multiple of the 16-column block (order <= 2048), so that
 // the RHS block is exactly one of the trailing update's column blocks.
-hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
+// the right-hand-side block alone through every step of the stored LU, then back-substitution
+hipError_t launch_lu_resolve_core(const BuildBuffers &b, hipStream_t stream)
 {
-    if (b.spd) return launch_resolve_spd(b, stream, src);
-    static const PointSrc none{};
     const unsigned nb = (unsigned)b.nbatch;
     if (b.npad > 2048) return hipErrorInvalidValue;
-    {
-        const int threads = 256;
-        const int blocks = (b.npad + threads - 1) / threads;
-        hipLaunchKernelGGL(k_prepare_rhs, dim3(blocks, 1, nb), dim3(threads), 0, stream, b.d_slots, src ? *src : none,
-                           src ? 1 : 0, b.M, b.npad, b.lda);
-    }
     int k0 = 0, step = 0;
     while (k0 < b.npad) {
         const int np = group_at(b.npad, k0, b.group_panels != 0);
@@ -1283,7 +1288,19 @@ hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const Point
         ++step;
     }
     launch_backsub(b, stream, b.npad);
-    hipError_t e = launch_pack(b, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
+{
+    if (b.spd) return launch_resolve_spd(b, stream, src);
+    if (b.npad > 2048) return hipErrorInvalidValue;
+    if (b.kind == FD_KERNEL_GAUSSIAN_QNN && b.ml_layers == 0) return launch_resolve_qnn(b, stream, src);
+    hipError_t e = launch_prepare_rhs(b, stream, src);
+    if (e != hipSuccess) return e;
+    e = launch_lu_resolve_core(b, stream);
+    if (e != hipSuccess) return e;
+    e = launch_pack(b, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }

@@ -1014,6 +1014,58 @@ int fd_deform_mesh(fd_ctx *ctx, float *P_out, float *falloff_out, float radius2,
     return FD_OK;
 }
 
+// ProximityCapture on the device-resident mesh: islands, then squared distances, into m_dist2
+int fd_mesh_capture(fd_ctx *ctx, const int64_t *offsets, const int *neighbours, int M, const float *rig_xyz,
+                    int max_edges, int T, const float *tri_xyz, float radius2, int dofalloff, float *dist2_out)
+{
+    if (!ctx) return FD_E_INVALID;
+    const int64_t N = ctx->mesh_N;
+    if (N <= 0) { set_err(ctx, "fd_mesh_capture: fd_mesh_set has not been called"); return FD_E_INVALID; }
+    if (!offsets || M < 0 || T < 0 || max_edges < 0 || (M > 0 && !rig_xyz) || (T > 0 && !tri_xyz)) {
+        set_err(ctx, "fd_mesh_capture: bad sizes or NULL arrays");
+        return FD_E_INVALID;
+    }
+    const int64_t E = offsets[N];
+    if (offsets[0] != 0 || E < 0 || (E > 0 && !neighbours)) { set_err(ctx, "fd_mesh_capture: bad adjacency"); return FD_E_INVALID; }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (!ctx->m_dist2 && (rc = dev_alloc(ctx, &ctx->m_dist2, (size_t)ctx->mesh_cap))) return rc;
+    hipStream_t s = cur_stream(ctx);
+    float *d_rig = nullptr, *d_tri = nullptr;
+    int64_t *d_off = nullptr;
+    int *d_nb = nullptr;
+    unsigned char *d_mask = nullptr;
+    hipError_t e = hipMalloc((void **)&d_off, sizeof(int64_t) * (size_t)(N + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_nb, sizeof(int) * (size_t)(E > 0 ? E : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_mask, (size_t)N);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_rig, sizeof(float) * 3 * (size_t)(M > 0 ? M : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tri, sizeof(float) * 9 * (size_t)(T > 0 ? T : 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && E > 0) e = hipMemcpyAsync(d_nb, neighbours, sizeof(int) * (size_t)E, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && M > 0) e = hipMemcpyAsync(d_rig, rig_xyz, sizeof(float) * 3 * (size_t)M, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && T > 0) e = hipMemcpyAsync(d_tri, tri_xyz, sizeof(float) * 9 * (size_t)T, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_capture_islands(ctx->m_P, N, d_off, d_nb, d_rig, M, max_edges, d_mask, s);
+    if (e == hipSuccess) e = launch_capture_dist2(ctx->m_P, N, d_mask, d_tri, T, radius2, dofalloff, ctx->m_dist2, s);
+    if (e == hipSuccess && dist2_out) e = hipMemcpyAsync(dist2_out, ctx->m_dist2, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    for (void *p : {(void *)d_off, (void *)d_nb, (void *)d_mask, (void *)d_rig, (void *)d_tri}) if (p) (void)hipFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_err(ctx, "fd_mesh_capture failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    ctx->mesh_has_dist2 = true;
+    return FD_OK;
+}
+
+int fd_mesh_get_dist2(fd_ctx *ctx, float *dist2_out)
+{
+    if (!ctx || !dist2_out) return FD_E_INVALID;
+    if (ctx->mesh_N <= 0 || !ctx->mesh_has_dist2 || !ctx->m_dist2) { set_err(ctx, "fd_mesh_get_dist2: the mesh has no dist2 array"); return FD_E_INVALID; }
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    hipStream_t s = cur_stream(ctx);
+    FD_HIP(ctx, hipMemcpyAsync(dist2_out, ctx->m_dist2, sizeof(float) * (size_t)ctx->mesh_N, hipMemcpyDeviceToHost, s));
+    FD_HIP(ctx, hipStreamSynchronize(s));
+    return FD_OK;
+}
+
 static int require_built(fd_ctx *ctx, const char *who)
 {
     if (ctx->build_pending) {

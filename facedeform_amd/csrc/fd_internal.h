@@ -165,6 +165,11 @@ hipError_t launch_pack_records(const BuildBuffers &b, hipStream_t stream, int re
 hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int rows);
 hipError_t launch_prepare_rhs(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 hipError_t launch_backsub_update(const BuildBuffers &b, hipStream_t stream, int row_lo, int w);
+// the QNN model (fd_nullspace.hip launch_build_qnn) takes the LU apart: radii, then the pivoted
+// factorisation + back-substitution of whatever has been assembled, full build or right-hand sides only
+hipError_t launch_qnn_radii(const BuildBuffers &b, hipStream_t stream);
+hipError_t launch_lu_factor_solve(const BuildBuffers &b, hipStream_t stream);
+hipError_t launch_lu_resolve_core(const BuildBuffers &b, hipStream_t stream);
 
 // ---- null-space Cholesky build (fd_nullspace.hip) -----------------------------------
 // Which (kernel, term, lambda) make the projected block positive definite; M large enough to project.
@@ -174,6 +179,10 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
 hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 constexpr int kMaxLayers = 8;
 hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
+// FD_KERNEL_GAUSSIAN_QNN, the SOP's model = 0: least-squares polynomial first, then the pivoted LU
+// of the (non-symmetric) kernel block on what is left
+hipError_t launch_build_qnn(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
+hipError_t launch_resolve_qnn(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
 
 // ---- evaluation (fd_eval.hip) --------------------------------------------------
 struct DeformArgs {

@@ -1221,6 +1221,21 @@ __global__ void k_ml_finish(const BatchSlot *tab, int M, int T, int L)
     if (t == 0 && s.model->iterations >= M) s.model->iterations = M + T;      // all unknowns eliminated
 }
 
+// QNN model: the polynomial (k_ml_affine left it in the solver state) into the rows of X that
+// k_pack reads it from; a rig with fewer points than polynomial terms has no fit at all
+__global__ void k_qnn_finish(const BatchSlot *tab, int M, int T, int npad, int fit_ok)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    gcdouble *small = as_global(s.ns) + (size_t)12 * M;
+    gdouble *X = as_global(s.X);
+    const int t = threadIdx.x;
+    if (t < 3 * T) { const int k = t / 3, c = t % 3; X[(size_t)c * npad + M + k] = fit_ok ? small[kAff + 3 * k + c] : 0.0; }
+    if (t == 0) {
+        if (!fit_ok) s.model->sing_flag = 1;
+        if (s.model->iterations >= M) s.model->iterations = M + T;      // all unknowns eliminated
+    }
+}
+
 // the factorisation loop; with rhs_only the matrix is left alone and only the right-hand-side rows
 // travel through the stored factor
 void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, int rhs_only)
@@ -1354,6 +1369,57 @@ hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t
     }
     hipLaunchKernelGGL(k_ml_finish, dim3(1, 1, nb), dim3(64), 0, stream, b.d_slots, M, T, L);
     return launch_pack_records(b, stream, M * L, FD_KERNEL_GAUSSIAN_QNN, 2, L);
+}
+
+// The SOP's default model (model = 0, rbfsetalgoqnn, reference src/SOP_FaceDeform.cpp:343-345) in
+// ALGLIB's order: the term's polynomial is a least-squares fit to the deltas
+// -- through the QR of P the reflectors give, no normal equations -- and is removed; the Gaussians
+// with their per-centre radii then fit what is left, (Phi + lambda I) w = f - P a.  Phi is not
+// symmetric, so this is the pivoted LU (fd_build.hip) of the kernel block alone: order M, the
+// rest of the padded system an identity block with zero right-hand sides.
+static BuildBuffers kernel_block_only(const BuildBuffers &b)
+{
+    BuildBuffers k = b;
+    k.T = 0;
+    k.n = b.M;
+    k.term = FD_TERM_ZERO;
+    return k;
+}
+
+hipError_t launch_build_qnn(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    const int M = b.M, T = b.T;
+    const bool fit = M >= T;
+    hipError_t e = launch_qnn_radii(b, stream);
+    if (e != hipSuccess) return e;
+    if (T > 0 && fit) {
+        hipLaunchKernelGGL(k_ns_reflectors, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda, 0);
+        hipLaunchKernelGGL(k_ml_affine, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
+    }
+    const BuildBuffers k = kernel_block_only(b);
+    e = launch_assemble_block(k, stream, b.npad);
+    if (e != hipSuccess) return e;
+    if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+    e = launch_lu_factor_solve(k, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_qnn_finish, dim3(1, 1, nb), dim3(64), 0, stream, b.d_slots, M, T, b.npad, fit ? 1 : 0);
+    return launch_pack(b, stream);
+}
+
+// fd_set_deltas for the QNN model: the polynomial of the new deltas, then their remainder through the stored LU
+hipError_t launch_resolve_qnn(const BuildBuffers &b, hipStream_t stream, const PointSrc *src)
+{
+    const unsigned nb = (unsigned)b.nbatch;
+    const int M = b.M, T = b.T;
+    const bool fit = M >= T;
+    hipError_t e = launch_prepare_rhs(b, stream, src);
+    if (e != hipSuccess) return e;
+    if (T > 0 && fit) hipLaunchKernelGGL(k_ml_affine, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda);
+    e = launch_lu_resolve_core(kernel_block_only(b), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_qnn_finish, dim3(1, 1, nb), dim3(64), 0, stream, b.d_slots, M, T, b.npad, fit ? 1 : 0);
+    return launch_pack(b, stream);
 }
 
 // fd_set_deltas: new right-hand sides through the stored reflectors and Cholesky factor

@@ -8,9 +8,10 @@
 // and calls fdsop_cook; the tests drive the same entry points through ctypes.
 //
 // The morph-space pass (setupBlends :175-213, the loop at :444-482, DirectBSEdit in
-// src/dbse.cpp) runs on the device through fd_morph_*.  Out of scope here, as in
-// ProximityCapture (its product, the per-vertex dist2 array,
-// is an input).
+// src/dbse.cpp) runs on the device through fd_morph_*.  ProximityCapture (:301-322,
+// src/capture.cpp) runs on the device too, through fd_mesh_capture, when the caller hands over
+// what it needs (the mesh's edge adjacency and the rig's triangles) and no dist2 array of its
+// own; cached across cooks exactly as the reference caches m_mesh_capture.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,6 +77,9 @@ struct fdsop_node {
     fd_ctx *engine = nullptr;
     // what the engine's device-resident mesh (fd_mesh_set) was uploaded with
     bool mesh_had_dist2 = false, mesh_had_frames = false;
+    // m_mesh_capture.isInitialized() && isCaptured() (:310-311): the device-resident dist2 is the
+    // product of a capture that is still valid
+    bool captured = false;
     fd_morph *morph = nullptr;        // m_direct_blends (:SOP_FaceDeform.hpp), lives as long as the node
     int morph_device = -2;
     double fval[kNumParms][2];
@@ -300,6 +304,46 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     }
     fd_ctx *ctx = node->engine;
 
+    // :301-322 -- proximity capture, where the reference has it: before the model.  Input 0's arrays
+    // go to the device first (fd_mesh_set; skipped when the caller vouches they are the previous
+    // cook's), then -- with no dist2 array from the caller but the capture's own inputs at hand --
+    // islands and squared distances are produced there.  Re-captured on the first cook and when the
+    // rest pose or the rest rig changed; NOT when radius / maxedges / dofalloff alone changed (the
+    // FIXME at :309: kept, B12).
+    const int dofalloff_parm = (int)node->fval[find_parm("dofalloff")][0];
+    const bool want_d2 = geo->dist2 != nullptr;
+    const bool use_capture = !want_d2 && geo->edge_offsets && geo->rig_ntris >= 0 && (geo->rig_ntris == 0 || geo->rig_tris);
+    bool mesh_ready = false;
+    if (geo->npoints > 0) {
+        const bool reuse = geo->mesh_unchanged && fd_mesh_size(ctx) == geo->npoints &&
+                           node->mesh_had_dist2 == want_d2 && node->mesh_had_frames == do_tangent_disp;
+        int mrc = FD_OK;
+        if (!reuse) {
+            mrc = fd_mesh_set(ctx, geo->npoints, geo->P, geo->dist2, do_tangent_disp ? geo->tangentu : nullptr,
+                              do_tangent_disp ? geo->tangentv : nullptr, do_tangent_disp ? geo->N : nullptr);
+            node->mesh_had_dist2 = want_d2;
+            node->mesh_had_frames = do_tangent_disp;
+            node->captured = false;
+        }
+        if (mrc != FD_OK) {
+            std::string t = std::string("GPU deformation failed: ") + fd_last_error(ctx);
+            node->add(FDSOP_ERROR, t.c_str());
+            return node->severity;
+        }
+        mesh_ready = true;
+        if (!use_capture) node->captured = false;
+        if (use_capture && (!node->captured || !geo->rig_rest_unchanged)) {
+            // capture(max_edges, radius, dofalloff, falloffrate) (:317): radius^2 is the search bound
+            mrc = fd_mesh_capture(ctx, geo->edge_offsets, geo->edge_neighbours, M > 0 ? M : 0, geo->rest_P, max_edges,
+                                  (int)geo->rig_ntris, geo->rig_tris, radius * radius, dofalloff_parm, nullptr);
+            if (mrc != FD_OK) {
+                node->add(FDSOP_ERROR, "Can't capture geometry with a rig!");     // :318
+                return node->severity;
+            }
+            node->captured = true;
+        }
+    }
+
     // :342-349 -- model select; `kernel` (addition) overrides the Gaussian family.  (Set before
     // the points here: an unchanged kernel / term leaves the engine's factorisation in place, and
     // fd_set_deltas below depends on that; every failure ends in the same message as at :337-340.)
@@ -351,7 +395,7 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     if (geo->Cd)
         for (int64_t i = 0; i < geo->npoints * 3; ++i) geo->Cd[i] = 1.f;
     // :396-399
-    if (!geo->dist2)
+    if (!geo->dist2 && !(use_capture && node->captured))
         node->add(FDSOP_WARNING, "Can't find distance capture attribute. Won't apply radius nor falloff.");
     // :401 -- a fresh float attribute reads 0 until written
     if (geo->fd_falloff && geo->npoints > 0) memset(geo->fd_falloff, 0, sizeof(float) * (size_t)geo->npoints);
@@ -362,18 +406,9 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     // cook moves only its results over the host link.
     pass.armed = false;
     rc = FD_OK;
-    if (geo->npoints > 0) {
-        const bool want_d2 = geo->dist2 != nullptr;
-        const bool reuse = geo->mesh_unchanged && fd_mesh_size(ctx) == geo->npoints &&
-                           node->mesh_had_dist2 == want_d2 && node->mesh_had_frames == do_tangent_disp;
-        if (!reuse) {
-            rc = fd_mesh_set(ctx, geo->npoints, geo->P, geo->dist2, do_tangent_disp ? geo->tangentu : nullptr,
-                             do_tangent_disp ? geo->tangentv : nullptr, do_tangent_disp ? geo->N : nullptr);
-            node->mesh_had_dist2 = want_d2;
-            node->mesh_had_frames = do_tangent_disp;
-        }
-        if (rc == FD_OK) rc = fd_deform_mesh(ctx, geo->P_out, geo->fd_falloff, radius_sqrt, falloffrate);
-    }
+    if (mesh_ready) rc = fd_deform_mesh(ctx, geo->P_out, geo->fd_falloff, radius_sqrt, falloffrate);
+    if (rc == FD_OK && geo->dist2_out && use_capture && node->captured)
+        rc = fd_mesh_get_dist2(ctx, geo->dist2_out);
     if (rc != FD_OK) {
         std::string t = std::string("GPU deformation failed: ") + fd_last_error(ctx);
         node->add(FDSOP_ERROR, t.c_str());
@@ -389,7 +424,7 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
         bool weights_done = false;
         const int S = fd_morph_shape_count(node->morph);
         if (!fd_morph_is_computed(node->morph)) {
-            const int dofalloff = (int)node->fval[find_parm("dofalloff")][0];
+            const int dofalloff = dofalloff_parm;
             const int doclampweight = (int)node->fval[find_parm("doclampweight")][0];
             const float falloffradius = (float)node->fval[find_parm("falloffradius")][0];
             const float weightrange[2] = {(float)node->fval[find_parm("weightrange")][0],

@@ -23,6 +23,7 @@ class CookResult:
     fd_falloff: np.ndarray | None = None
     Cd: np.ndarray | None = None
     weights: np.ndarray | None = None              # the detail array `weights` of the morph pass
+    dist2: np.ndarray | None = None                # ProximityCapture's attribute when the cook captured on the device
 
     @property
     def errors(self):
@@ -104,7 +105,8 @@ class FaceDeformSOP:
     # -- cook
     def cook(self, mesh_P, rest_P, deform_P, dist2=None, tangentu=None, tangentv=None, N=None,
              out_P=None, out_falloff=None, want_Cd=True, shapes=None, rest=None, rest_changed=False,
-             blends_changed=False, rig_rest_unchanged=False, mesh_unchanged=False) -> CookResult:
+             blends_changed=False, rig_rest_unchanged=False, mesh_unchanged=False,
+             edge_offsets=None, edge_neighbours=None, rig_tris=None, want_dist2=False) -> CookResult:
         """out_P / out_falloff: caller-owned result arrays (e.g. page-locked ones from
         capi.host_array, as the HDK wrapper keeps them): with every mesh array page-locked the
         evaluation runs in place over the host link.  want_Cd=False leaves the Cd fill to the
@@ -144,16 +146,30 @@ class FaceDeformSOP:
         rest_attr = opt(rest, 3)
         weights = np.zeros(max(1, ns), np.float64)
         wcount = C.c_int64(0)
+        # ProximityCapture's inputs: the mesh's edge adjacency (CSR) and the rig's surface triangles
+        eo = en = tris = cap_out = None
+        if edge_offsets is not None:
+            eo = np.ascontiguousarray(edge_offsets, np.int64)
+            en = np.ascontiguousarray(edge_neighbours if edge_neighbours is not None else [], np.int32)
+            tris = np.ascontiguousarray(rig_tris if rig_tris is not None else np.zeros((0, 9)), f32).reshape(-1, 9)
+            keep.extend([eo, en, tris])
+            if want_dist2:
+                cap_out = np.full(P.shape[0], np.nan, f32)
         geo = capi.FdsopGeo(P.shape[0], ptr(P), ptr(tu), ptr(tv), ptr(nn), ptr(d2), rig_rest.shape[0],
                             deform.shape[0], ptr(rig_rest), ptr(deform), ptr(P_out), ptr(fall), ptr(Cd),
                             ns, C.cast(sh_ptrs, C.POINTER(C.c_void_p)) if ns else None,
                             C.cast(sh_counts, C.POINTER(C.c_int64)) if ns else None, ptr(rest_attr),
                             int(bool(rest_changed)), int(bool(blends_changed)),
                             weights.ctypes.data_as(C.POINTER(C.c_double)), C.pointer(wcount),
-                            int(bool(rig_rest_unchanged)), int(bool(mesh_unchanged)))
+                            int(bool(rig_rest_unchanged)), int(bool(mesh_unchanged)),
+                            None if eo is None else eo.ctypes.data_as(C.POINTER(C.c_int64)),
+                            None if en is None or en.size == 0 else en.ctypes.data_as(C.POINTER(C.c_int)),
+                            -1 if tris is None else tris.shape[0],
+                            None if tris is None or tris.size == 0 else tris.ctypes.data_as(fp), ptr(cap_out))
         sev = self.L.fdsop_cook(self.node, C.byref(geo))
         text = self.L.fdsop_messages(self.node).decode()
         msgs = [tuple(line.split("\t", 1)) for line in text.splitlines() if "\t" in line]
         res = CookResult(sev, msgs, P_out, fall, Cd)
         res.weights = weights[: wcount.value].copy()
+        res.dist2 = cap_out
         return res

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 3   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres (additions only) */
+#define FD_ABI_VERSION 4   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo (additions only) */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -47,6 +47,10 @@ enum {
  *       (model=1 "Multilayer" collapsed to one layer: R = radius, lambda = lambda)
  *   FD_KERNEL_GAUSSIAN_QNN  exp(-d2/R_j^2), R_j = min(q*nn_j, z*median_k(q*nn_k))
  *       (model=0 "QNN": q = qcoef, z = zcoef)      params {q, z [, lambda]}
+ *       Built in ALGLIB's order, like FD_KERNEL_GAUSSIAN_ML below: the term's polynomial is a
+ *       least-squares fit to the deltas, removed first; then (Phi + lambda I) w = f - P a (Phi is
+ *       not symmetric with per-centre radii: pivoted LU).  The median is element M/2 of the
+ *       sorted radii.
  *   FD_KERNEL_THIN_PLATE    r^2 ln r                params {[lambda]}
  *   FD_KERNEL_BIHARMONIC    -r                      params {[lambda]}
  *   FD_KERNEL_CUBIC         r^3                     params {[lambda]}
@@ -209,6 +213,19 @@ int fd_mesh_set(fd_ctx *ctx, int64_t N, const float *P, const float *dist2, cons
                 const float *nrm);
 int64_t fd_mesh_size(const fd_ctx *ctx);
 int fd_deform_mesh(fd_ctx *ctx, float *P_out, float *falloff_out, float radius2, float falloffrate);
+/* ProximityCapture::init + capture (src/capture.cpp:10-99; called at src/SOP_FaceDeform.cpp:310-322)
+ * on the device-resident mesh of fd_mesh_set: the island mask (fd_capture_islands: nearest mesh
+ * point of each of the M rest-rig points, then max_edges edge rings over the CSR adjacency) and,
+ * for the island points, the squared distance to the rig's surface (fd_capture_dist2: T triangles,
+ * 9 floats each; -1 beyond radius2, 0 with dofalloff off and outside every island).  The result
+ * becomes the mesh's dist2 array -- the detached attribute `dist_a` of capture.cpp:31 -- and stays
+ * on the device until the next fd_mesh_set / fd_mesh_capture: fd_deform_mesh gates and falls off
+ * with it.  Host pointers; synchronous.  dist2_out (may be NULL) receives a copy (npoints). */
+int fd_mesh_capture(fd_ctx *ctx, const int64_t *offsets, const int *neighbours, int M, const float *rig_xyz,
+                    int max_edges, int T, const float *tri_xyz, float radius2, int dofalloff, float *dist2_out);
+/* The device-resident dist2 array (uploaded by fd_mesh_set or produced by fd_mesh_capture) into a
+ * host array of fd_mesh_size() floats; FD_E_INVALID when the mesh has none. */
+int fd_mesh_get_dist2(fd_ctx *ctx, float *dist2_out);
 
 /* ---- model access -----------------------------------------------------------
  * W is (C+4) x 3 fp64 row-major: C RBF weights, the constant row, the x,y,z
@@ -396,6 +413,21 @@ typedef struct fdsop_geo {
      * data IDs did not change.  Then the engine's device-resident copy (fd_mesh_set) is used and
      * nothing of the mesh is uploaded; 0 = upload. */
     int mesh_unchanged;
+    /* ---- ProximityCapture's inputs (src/capture.cpp:10-44, 101-141; cook :301-322) -- all optional.
+     * When `dist2` above is NULL and these are present, the cook captures on the device exactly
+     * where the reference does: on the first cook and whenever the rest pose (input 0) or the rest
+     * rig (input 1) changed -- NOT when only radius / maxedges / dofalloff changed (the author's
+     * FIXME at :309, kept) -- and gates / falls off with the result.
+     *   edge_offsets / edge_neighbours   the mesh's edges as a CSR adjacency (what GQ_Detail::
+     *                                    groupEdgePoints walks): offsets[npoints + 1], neighbours[offsets[npoints]]
+     *   rig_tris                         the rest rig's surface as rig_ntris triangles, 9 floats each
+     *                                    (what GU_RayIntersect::minimumPoint searches)
+     *   dist2_out                        out: the captured attribute, npoints floats, or NULL */
+    const int64_t *edge_offsets;
+    const int *edge_neighbours;
+    int64_t rig_ntris;
+    const float *rig_tris;
+    float *dist2_out;
 } fdsop_geo;
 
 fdsop_node *fdsop_create(const fd_config *cfg);

@@ -87,8 +87,10 @@ int fdo_radii(const double *table, int M, int kind, const double *params, int np
         tmp[i] = radii[i];
     }
     qsort(tmp, (size_t)M, sizeof(double), cmp_double);
-    /* lower median for even M */
-    const double med = M > 0 ? tmp[(M - 1) / 2] : 1.0;
+    /* the median is the sorted array's element M / 2 (the UPPER one for even M): ALGLIB's
+     * tmp[n/2] as two independent recollections of its rbf unit have it; ALGLIB is
+     * absent, so this stays a recollection -- DESIGN.md 6d.  Odd M: the one median either way. */
+    const double med = M > 0 ? tmp[M / 2] : 1.0;
     for (int i = 0; i < M; ++i)
         if (radii[i] > z * med) radii[i] = z * med;
     free(tmp);
@@ -163,6 +165,63 @@ static int lu_solve(double *A, int n, double *B, int nrhs)
     return 0;
 }
 
+/* Least-squares polynomial a (T x 3, rows: constant, x, y, z) of the deltas over the rest points:
+ * min |f - P a|_2 by Householder QR of P = [1 x y z] (M x T), then f <- f - P a in place.
+ * This is the order ALGLIB's Gaussian models work in ("Term": the linear /
+ * constant term is fitted first and removed, the RBF fits the remainder).  -4 when P has no full
+ * column rank (fewer points than terms, or all of them in one plane / on one line). */
+static int ls_polynomial(const double *table, int M, int T, double *f /* M x 3 */, double a[4][3])
+{
+    for (int k = 0; k < 4; ++k) a[k][0] = a[k][1] = a[k][2] = 0.0;
+    if (T == 0) return 0;
+    if (M < T) return -4;
+    double *Q = (double *)malloc(sizeof(double) * (size_t)M * (size_t)(T + 3));
+    if (!Q) return -2;
+    const int C = T + 3;                      /* [P | f] goes through the reflectors together */
+    double cn[4] = {0, 0, 0, 0};
+    for (int i = 0; i < M; ++i) {
+        Q[(size_t)i * C] = 1.0;
+        for (int t = 1; t < T; ++t) Q[(size_t)i * C + t] = table[6 * i + t - 1];
+        for (int c = 0; c < 3; ++c) Q[(size_t)i * C + T + c] = f[3 * i + c];
+        for (int t = 0; t < T; ++t) cn[t] += Q[(size_t)i * C + t] * Q[(size_t)i * C + t];
+    }
+    int rc = 0;
+    for (int k = 0; k < T && rc == 0; ++k) {
+        double sigma = 0.0;
+        for (int i = k + 1; i < M; ++i) sigma += Q[(size_t)i * C + k] * Q[(size_t)i * C + k];
+        const double xk = Q[(size_t)k * C + k];
+        const double norm = sqrt(xk * xk + sigma);
+        if (!(norm > 64.0 * (double)M * 2.220446049250313e-16 * sqrt(cn[k]))) { rc = -4; break; }
+        if (sigma > 0.0) {
+            const double beta = xk >= 0.0 ? -norm : norm;
+            const double tau = (beta - xk) / beta, scale = 1.0 / (xk - beta);
+            for (int c = k + 1; c < C; ++c) {
+                double d = Q[(size_t)k * C + c];
+                for (int i = k + 1; i < M; ++i) d += scale * Q[(size_t)i * C + k] * Q[(size_t)i * C + c];
+                Q[(size_t)k * C + c] -= tau * d;
+                for (int i = k + 1; i < M; ++i) Q[(size_t)i * C + c] -= tau * d * scale * Q[(size_t)i * C + k];
+            }
+            Q[(size_t)k * C + k] = beta;
+        }
+    }
+    if (rc == 0) {
+        for (int c = 0; c < 3; ++c)
+            for (int k = T - 1; k >= 0; --k) {
+                double v = Q[(size_t)k * C + T + c];
+                for (int t = k + 1; t < T; ++t) v -= Q[(size_t)k * C + t] * a[t][c];
+                a[k][c] = v / Q[(size_t)k * C + k];
+            }
+        for (int i = 0; i < M; ++i)
+            for (int c = 0; c < 3; ++c) {
+                double p = a[0][c];
+                for (int t = 1; t < T; ++t) p += a[t][c] * table[6 * i + t - 1];
+                f[3 * i + c] -= p;
+            }
+    }
+    free(Q);
+    return rc;
+}
+
 /* ---- A3-A6 (src/SOP_FaceDeform.cpp:331-368) ------------------------------ */
 int fdo_build(const double *table, int M, int kind, const double *params, int nparams,
               int term, double *W, double *radii_out, int *terminationtype)
@@ -201,6 +260,54 @@ int fdo_build(const double *table, int M, int kind, const double *params, int np
         return -5;
     }
     const double lambda = param_lambda(kind, params, nparams);
+    if (kind == FDO_KERNEL_GAUSSIAN_QNN) {
+        /* The SOP's model = 0, rbfsetalgoqnn (src/SOP_FaceDeform.cpp:343-345), in ALGLIB's order:
+         * the term's polynomial by least squares first, then the Gaussians on what is left,
+         *     (Phi + lambda I) w = f - P a,     Phi_ij = exp(-|c_i - c_j|^2 / R_j^2)
+         * (Phi is not symmetric with per-centre radii: pivoted LU).  Round 1 solved the polynomial
+         * together with the weights (the saddle-point system below); both interpolate at the rig
+         * points but differ everywhere else. */
+        double *A = (double *)calloc((size_t)M * M, sizeof(double));
+        double *B = (double *)calloc((size_t)M * 3, sizeof(double));
+        double a[4][3];
+        if (!A || !B) {
+            free(A); free(B); free(radii_own);
+            if (terminationtype) *terminationtype = -4;
+            return -2;
+        }
+        for (int i = 0; i < M; ++i)
+            for (int c = 0; c < 3; ++c) B[(size_t)i * 3 + c] = table[6 * i + 3 + c];
+        int rc = ls_polynomial(table, M, T, B, a);
+        if (rc == 0) {
+            for (int i = 0; i < M; ++i) {
+                for (int j = 0; j < M; ++j) {
+                    const double dx = table[6 * i] - table[6 * j];
+                    const double dy = table[6 * i + 1] - table[6 * j + 1];
+                    const double dz = table[6 * i + 2] - table[6 * j + 2];
+                    A[(size_t)i * M + j] = phi(kind, dx * dx + dy * dy + dz * dz, 1.0 / (radii[j] * radii[j]));
+                }
+                A[(size_t)i * M + i] += lambda;
+            }
+            rc = lu_solve(A, M, B, 3);
+        }
+        if (rc != 0) tt = -4;
+        else {
+            for (int i = 0; i < M; ++i)
+                for (int c = 0; c < 3; ++c) {
+                    if (!isfinite(B[(size_t)i * 3 + c])) tt = -4;
+                    W[(size_t)i * 3 + c] = B[(size_t)i * 3 + c];
+                }
+            for (int k = 0; k < T; ++k)
+                for (int c = 0; c < 3; ++c) {
+                    if (!isfinite(a[k][c])) tt = -4;
+                    W[(size_t)(M + k) * 3 + c] = a[k][c];
+                }
+            if (tt != 1) memset(W, 0, sizeof(double) * (size_t)(M + 4) * 3);
+        }
+        free(A); free(B); free(radii_own);
+        if (terminationtype) *terminationtype = tt;
+        return tt == 1 ? 0 : -4;
+    }
     double *A = (double *)calloc((size_t)n * n, sizeof(double));
     double *B = (double *)calloc((size_t)n * 3, sizeof(double));
     if (!A || !B) {

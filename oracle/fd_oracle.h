@@ -44,6 +44,10 @@ extern "C" {
  * GAUSSIAN      exp(-d2 / R^2), one radius R for all centres   params: {R[, lambda]}
  * GAUSSIAN_QNN  exp(-d2 / R_j^2), R_j = min(q*nn_j, z*median_k(q*nn_k)), nn_j = distance
  *               to the nearest other centre   params: {q, z[, lambda]}
+ *               Built in ALGLIB's order: the term's polynomial is a least-squares fit to the
+ *               deltas, removed first; the Gaussians then fit the remainder,
+ *               (Phi + lambda I) w = f - P a.  (Every other kind solves polynomial and weights
+ *               together: the constrained saddle-point system of north_star.)
  * THIN_PLATE    r^2 ln r = 0.5 * d2 * ln d2, 0 at d2 = 0       params: {[lambda]}
  * BIHARMONIC    -r   (SciPy 'linear' sign convention)          params: {[lambda]}
  * CUBIC         r^3                                             params: {[lambda]}

@@ -42,7 +42,7 @@ def qnn_radii(y, q, z):
     d = np.linalg.norm(y[:, None, :] - y[None, :, :], axis=2)
     np.fill_diagonal(d, np.inf)
     r = q * d.min(axis=1)
-    med = np.sort(r)[(len(r) - 1) // 2]
+    med = np.sort(r)[len(r) // 2]        # ALGLIB's tmp[n/2] (recollection)
     return np.minimum(r, z * med)
 
 
@@ -54,20 +54,17 @@ def numpy_qnn_case(rest, deform, x, term, q, z, lam=0.0):
     d2 = ((y[:, None, :] - y[None, :, :]) ** 2).sum(axis=2)
     Phi = np.exp(-d2 / (R[None, :] ** 2)) + lam * np.eye(M)
     T = {"linear": 4, "const": 1, "zero": 0}[term]
+    # ALGLIB's order for its Gaussian models: the term's polynomial is a
+    # least-squares fit to the deltas, removed first; the Gaussians fit what is left.
     P = np.concatenate([np.ones((M, 1)), y], axis=1)[:, :T]
-    A = np.zeros((M + T, M + T))
-    A[:M, :M] = Phi
-    A[:M, M:] = P
-    A[M:, :M] = P.T
-    rhs = np.zeros((M + T, 3))
-    rhs[:M] = f
-    sol = np.linalg.solve(A, rhs)
+    a = np.linalg.lstsq(P, f, rcond=None)[0] if T else np.zeros((0, 3))
+    w = np.linalg.solve(Phi, f - P @ a)
     xx = x.astype(np.float64)
     e2 = ((xx[:, None, :] - y[None, :, :]) ** 2).sum(axis=2)
-    out = np.exp(-e2 / (R[None, :] ** 2)) @ sol[:M]
+    out = np.exp(-e2 / (R[None, :] ** 2)) @ w
     if T:
-        out = out + np.concatenate([np.ones((xx.shape[0], 1)), xx], axis=1)[:, :T] @ sol[M:]
-    return out, sol[:M], R
+        out = out + np.concatenate([np.ones((xx.shape[0], 1)), xx], axis=1)[:, :T] @ a
+    return out, w, R
 
 
 def main():

@@ -28,15 +28,15 @@ def test_header_symbols_all_exported(hip_lib):
 
 
 def test_abi_version(hip_lib):
-    assert hip_lib.fd_abi_version() == 3   # 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres
+    assert hip_lib.fd_abi_version() == 4   # 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres; 4: fd_mesh_capture + the capture inputs of fdsop_geo
 
 
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.FdConfig) == 32
     assert C.sizeof(capi.FdReport) == 32
-    assert C.sizeof(capi.FdsopGeo) == 21 * 8   # (the two trailing int flags share the last slot)
-    assert capi.FdsopGeo.mesh_unchanged.offset == 20 * 8 + 4
-    assert C.sizeof(capi.FdsopGeo) == 21 * 8   # 13 mesh/rig fields + 7 morph-space fields (two ints share a slot) + the rig flag
+    assert capi.FdsopGeo.mesh_unchanged.offset == 20 * 8 + 4   # (the two trailing int flags of ABI 3 share a slot)
+    assert capi.FdsopGeo.edge_offsets.offset == 21 * 8
+    assert C.sizeof(capi.FdsopGeo) == 26 * 8   # 13 mesh/rig fields + 7 morph-space fields + the flags + 5 capture fields
 
 
 @pytest.mark.skipif(HAVE_GPU, reason="checks the no-device failure mode")

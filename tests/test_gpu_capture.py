@@ -147,3 +147,79 @@ def test_islands_match_oracle_and_feed_the_capture(hip_lib, oracle):
         np.all(np.abs(d2 - oracle.capture_dist2(P, tris, r2, True, mask))[(d2 >= 0)] <= 2e-6 * 2.0)
     assert np.all(d2[mask == 0] == 0.0)
     e.close()
+
+
+def test_sop_cook_captures_on_the_device_and_caches_like_the_reference(hip_lib, oracle):
+    """ProximityCapture inside the cook (reference src/SOP_FaceDeform.cpp:301-322): with the mesh's
+    edge adjacency and the rig's triangles on the geometry and no dist2 array of the caller's,
+    fdsop_cook runs islands -> dist2 -> gate / fall-off -> deformation on the device.
+    Checked stage by stage against the oracle (fdo_capture_islands, fdo_capture_dist2, fdo_deform)
+    and end to end; plus the reference's caching: a radius / maxedges / dofalloff change alone does
+    NOT re-capture (the FIXME at :309), a rest-rig or rest-pose change does."""
+    from facedeform_amd.sop import FaceDeformSOP
+    N, M, K = 30_000, 40, 6
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    deform = synth.deformed_rig(rest, 1)
+    offsets, nb = _knn_adjacency(P)
+    tris = _rig_triangles(rest)
+    node = FaceDeformSOP()
+    node.set("kernel", 1)                      # thin-plate
+    node.set("radius", 0.2); node.set("maxedges", K); node.set("dofalloff", 1); node.set("falloffrate", 1.5)
+    kw = dict(edge_offsets=offsets, edge_neighbours=nb, rig_tris=tris, want_dist2=True)
+    res = node.cook(P, rest, deform, **kw)
+    assert res.severity == capi.FDSOP_MESSAGE, res.messages          # no "Can't find distance capture attribute"
+    r2 = np.float32(0.2) * np.float32(0.2)
+    # -- stage 1+2: the captured attribute against the oracle's capture
+    mask = oracle.capture_islands(P, offsets, nb, rest, K)
+    d2_ref = oracle.capture_dist2(P, tris, r2, True, mask)
+    exact = oracle.capture_dist2(P, tris, 1e30, True)
+    margin = 2e-6 * (exact + 1.0)
+    decided = np.abs(exact - r2) > margin
+    got = res.dist2
+    assert np.all(got[mask == 0] == 0.0) and mask.sum() > M
+    assert np.all(got[decided & (d2_ref == -1)] == -1.0)
+    sel = decided & (d2_ref >= 0) & (mask == 1)
+    assert sel.sum() > 50 and np.all(np.abs(got[sel] - d2_ref[sel]) <= margin[sel])
+    # -- stage 3: the deformation that consumed it, oracle fed with the device's attribute: 1e-5
+    table = oracle.control_table(rest, deform)
+    rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [0.0], 0)
+    ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=got, radius2=r2, falloffrate=1.5)
+    assert parity_ratio(res.P, ref, P, 1e-5) <= 1.0
+    assert np.allclose(res.fd_falloff, ref_fall, rtol=2e-6, atol=1e-7)
+    assert (res.fd_falloff > 1.0).any()                               # B4: dist2 = -1 overshoots
+    # -- end to end: oracle capture -> oracle deform, nothing of the device's in between.  The bar is
+    # the capture's: an fp32 distance within 2e-6 (d2 + L^2) moves the fall-off (1 - d2 / r2)^1.5 by up
+    # to 1.5 * margin / r2 = 8e-5 of the displacement at r2 = 0.04.
+    ref_e2e, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=d2_ref, radius2=r2, falloffrate=1.5)
+    plain, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    assert parity_ratio(res.P[decided], ref_e2e[decided], P[decided], 1e-4, scale_out=plain[decided]) <= 1.0
+    # -- caching (B12): parms alone do not re-capture ...
+    node.set("radius", 0.35); node.set("maxedges", 2); node.set("dofalloff", 0)
+    res2 = node.cook(P, rest, deform, rig_rest_unchanged=True, mesh_unchanged=True, **kw)
+    assert np.array_equal(res2.dist2, got)
+    # ... (the gate and the fall-off do use the new radius: :402, :423)
+    r2b = np.float32(0.35) * np.float32(0.35)
+    ref2, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=got, radius2=r2b, falloffrate=1.5)
+    assert parity_ratio(res2.P, ref2, P, 1e-5) <= 1.0
+    # ... a rest-rig change does: dofalloff is off now, so every island point reads 0 (capture.cpp:71-75)
+    res3 = node.cook(P, rest, deform, rig_rest_unchanged=False, mesh_unchanged=True, **kw)
+    assert np.all(res3.dist2 == 0.0)
+    ref3, fall3 = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=np.zeros(N, np.float32), radius2=r2b, falloffrate=1.5)
+    assert parity_ratio(res3.P, ref3, P, 1e-5) <= 1.0 and np.array_equal(res3.fd_falloff, fall3)
+    # ... and so does a new mesh (rest pose changed): fall-off on again, the wider radius, two rings
+    node.set("dofalloff", 1)
+    P2 = (P * np.float32(1.01)).astype(np.float32)
+    res4 = node.cook(P2, rest, deform, rig_rest_unchanged=True, mesh_unchanged=False, **kw)
+    mask4 = oracle.capture_islands(P2, offsets, nb, rest, 2)
+    d4 = oracle.capture_dist2(P2, tris, r2b, True, mask4)
+    ex4 = oracle.capture_dist2(P2, tris, 1e30, True)
+    dec4 = np.abs(ex4 - r2b) > 2e-6 * (ex4 + 1.0)
+    assert np.all(res4.dist2[mask4 == 0] == 0.0) and mask4.sum() < mask.sum()
+    s4 = dec4 & (d4 >= 0) & (mask4 == 1)
+    assert np.all(np.abs(res4.dist2[s4] - d4[s4]) <= 2e-6 * (ex4[s4] + 1.0))
+    # without the capture's inputs and without a dist2 array: the reference's warning, no gate, no fall-off
+    res5 = node.cook(P, rest, deform)
+    assert res5.warnings == ["Can't find distance capture attribute. Won't apply radius nor falloff."]
+    assert np.array_equal(res5.fd_falloff, np.ones(N, np.float32))
+    node.close()
