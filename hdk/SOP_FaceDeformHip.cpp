@@ -7,10 +7,14 @@
 // reference src/SOP_FaceDeform.cpp:35-46; parm tokens and defaults: :99-137) and hands the cook
 // to fdsop_cook(), the HDK-free mirror of cookMySop in facedeform_amd/csrc/fd_sop_host.cpp.
 //
-// What stays on the host, as in the reference: input locking, duplicatePointSource, data-ID
-// bumping, and ProximityCapture (reference src/capture.cpp), whose product -- the per-point
-// squared distance -- is handed over as the `dist2` array.  Morph space (DirectBSEdit) is not
-// part of the boundary yet.
+// What stays on the host, as in the reference: input locking, duplicatePointSource, the point
+// group of the `group` parm (cookInputGroups, :155-173) and the conditional data-ID bump it
+// governs (:485-486).  ProximityCapture (reference src/capture.cpp) runs on the device: this file
+// only gathers what it walks -- the mesh's edges as a CSR adjacency (what
+// GQ_Detail::groupEdgePoints follows) and the rest rig's surface as triangles (what
+// GU_RayIntersect::minimumPoint searches) -- and fdsop_cook captures where the reference does
+// (:301-322), cached across cooks as m_mesh_capture is.  Morph space (DirectBSEdit, :175-213,
+// 444-482) goes through the same geometry struct (inputs 3..).
 #include <UT/UT_DSOVersion.h>
 
 #include <GA/GA_AIFNumericArray.h>
@@ -18,6 +22,7 @@
 #include <GA/GA_PageHandle.h>
 #include <GA/GA_SplittableRange.h>
 #include <GU/GU_Detail.h>
+#include <GEO/GEO_Primitive.h>
 #include <UT/UT_Array.h>
 #include <OP/OP_AutoLockInputs.h>
 #include <OP/OP_Operator.h>
@@ -25,6 +30,7 @@
 #include <PRM/PRM_Include.h>
 #include <SOP/SOP_Node.h>
 
+#include <algorithm>
 #include <string>
 #include <memory>
 #include <vector>
@@ -159,6 +165,57 @@ static void scatterV3(GU_Detail *gdp, GA_Attribute *attr, const PinnedF &in)
     }
 }
 
+// The mesh's edges as a CSR adjacency over point INDICES: every primitive contributes the edges
+// between consecutive vertices (closed: last to first as well), both directions, duplicates
+// removed.  This is the graph GQ_Detail::groupEdgePoints walks in the reference
+// (src/capture.cpp:24,134).  Rebuilt only when input 0's topology changed.
+static void gatherEdgeAdjacency(const GU_Detail *gdp, std::vector<int64_t> &offsets, std::vector<int> &neighbours)
+{
+    const size_t n = (size_t)gdp->getNumPoints();
+    std::vector<std::vector<int>> adj(n);
+    const GEO_Primitive *prim;
+    GA_FOR_ALL_PRIMITIVES(gdp, prim) {
+        const GA_Size nv = prim->getVertexCount();
+        if (nv < 2) continue;
+        const bool closed = prim->isClosed();
+        for (GA_Size v = 0; v + 1 < nv || (closed && v < nv); ++v) {
+            const GA_Index a = gdp->pointIndex(prim->getPointOffset(v));
+            const GA_Index b = gdp->pointIndex(prim->getPointOffset((v + 1) % nv));
+            if (a == b) continue;
+            adj[(size_t)a].push_back((int)b);
+            adj[(size_t)b].push_back((int)a);
+        }
+    }
+    offsets.assign(n + 1, 0);
+    neighbours.clear();
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<int> &row = adj[i];
+        std::sort(row.begin(), row.end());
+        row.erase(std::unique(row.begin(), row.end()), row.end());
+        neighbours.insert(neighbours.end(), row.begin(), row.end());
+        offsets[i + 1] = (int64_t)neighbours.size();
+    }
+}
+
+// The rest rig's surface as triangles (a fan per polygon), 9 floats each: what
+// GU_RayIntersect::minimumPoint searches in the reference (src/capture.cpp:19,81).  Curves and
+// points have no surface and contribute nothing (every distance then reads -1, as a miss does).
+static void gatherRigTriangles(const GU_Detail *rig, std::vector<float> &tris)
+{
+    tris.clear();
+    const GEO_Primitive *prim;
+    GA_FOR_ALL_PRIMITIVES(rig, prim) {
+        const GA_Size nv = prim->getVertexCount();
+        if (nv < 3 || !prim->isClosed()) continue;
+        const UT_Vector3 a = rig->getPos3(prim->getPointOffset(0));
+        for (GA_Size v = 1; v + 1 < nv; ++v) {
+            const UT_Vector3 b = rig->getPos3(prim->getPointOffset(v)), c = rig->getPos3(prim->getPointOffset(v + 1));
+            const float t[9] = {a.x(), a.y(), a.z(), b.x(), b.y(), b.z(), c.x(), c.y(), c.z()};
+            tris.insert(tris.end(), t, t + 9);
+        }
+    }
+}
+
 class SOP_FaceDeformHip : public SOP_Node
 {
 public:
@@ -172,6 +229,14 @@ public:
     ~SOP_FaceDeformHip() override { fdsop_destroy(myNode); }
 
 protected:
+    // reference src/SOP_FaceDeform.cpp:155-173, verbatim in effect: the point group of the `group`
+    // parm into myGroup.  The evaluation ignores it (the reference's loop runs over every point,
+    // :404); it only decides whether P's data ID is bumped at the end (:485).
+    OP_ERROR cookInputGroups(OP_Context &context, int alone = 0) override
+    {
+        return cookInputPointGroups(context, myGroup, alone, true, 0, -1, true, false, true, 0);
+    }
+
     OP_ERROR cookMySop(OP_Context &context) override
     {
         OP_AutoLockInputs inputs(this);
@@ -199,13 +264,16 @@ protected:
         const GA_Attribute *aV = gdp->findFloatTuple(GA_ATTRIB_POINT, "tangentv", 3);
         const GA_Attribute *aN = gdp->findFloatTuple(GA_ATTRIB_POINT, "N", 3);
         if (aU && aV && aN) { gatherV3(gdp, aU, tu); gatherV3(gdp, aV, tv); gatherV3(gdp, aN, nn); }
-        // dist2: the detached attribute ProximityCapture maintains (reference src/capture.cpp:31);
-        // the capture itself stays host code and is not reproduced here.
-        if (const GA_Attribute *aD = captureDistanceAttribute()) {
-            dist2.resize((size_t)gdp->getNumPoints());
-            GA_ROHandleF h(aD);
-            GA_Offset o;
-            GA_FOR_ALL_PTOFF(gdp, o) dist2[(size_t)gdp->pointIndex(o)] = h.get(o);
+        // ProximityCapture's inputs (reference :310-322 -> src/capture.cpp): gathered when the
+        // topology they come from changed; the capture itself runs in fdsop_cook on the device
+        // and its result, the detached attribute `dist_a` (capture.cpp:31), never leaves it.
+        {
+            int topoChanged = myEdgeOffsets.empty(), rigChanged = myRigTris.empty() && !myRigGathered;
+            int c = 0;
+            checkChangedSourceFlags(0, context, &c); topoChanged |= c;
+            checkChangedSourceFlags(1, context, &c); rigChanged |= c;
+            if (topoChanged || myEdgeOffsets.size() != (size_t)gdp->getNumPoints() + 1) gatherEdgeAdjacency(gdp, myEdgeOffsets, myEdgeNeighbours);
+            if (rigChanged) { gatherRigTriangles(rest, myRigTris); myRigGathered = true; }
         }
         const size_t n = (size_t)gdp->getNumPoints();
         Pout.resize(3 * n); falloff.resize(n);
@@ -216,7 +284,11 @@ protected:
         geo.tangentu = tu.empty() ? nullptr : tu.data();
         geo.tangentv = tv.empty() ? nullptr : tv.data();
         geo.N = nn.empty() ? nullptr : nn.data();
-        geo.dist2 = dist2.empty() ? nullptr : dist2.data();
+        geo.dist2 = nullptr;                   // no attribute of the caller's: the cook captures on the device
+        geo.edge_offsets = myEdgeOffsets.data();
+        geo.edge_neighbours = myEdgeNeighbours.empty() ? nullptr : myEdgeNeighbours.data();
+        geo.rig_ntris = (int64_t)(myRigTris.size() / 9);
+        geo.rig_tris = myRigTris.empty() ? nullptr : myRigTris.data();
         geo.rest_npoints = rest->getNumPoints();
         geo.deform_npoints = deform->getNumPoints();
         geo.rest_P = restP.data();
@@ -270,6 +342,8 @@ protected:
             checkChangedSourceFlags(0, context, &meshChanged);
             geo.mesh_unchanged = !meshChanged;
         }
+        // :380 -- the group parm, before the evaluation as in the reference
+        if (cookInputGroups(context) >= UT_ERROR_ABORT) return error();
         fdsop_cook(myNode, &geo);
 
         // replay the engine's messages through the node's own channels
@@ -300,16 +374,19 @@ protected:
             wAif->set(wAttrib, 0, arr);
             wAttrib->bumpDataId();
         }
-        gdp->getP()->bumpDataId();
+        // :483-486 -- we manage our own data IDs: P is bumped unless the group parm names an empty group
+        if (!myGroup || !myGroup->isEmpty()) gdp->getP()->bumpDataId();
         return error();
     }
 
 private:
-    // Hook for the host-side ProximityCapture of the reference; returns nullptr when the
-    // capture has not run (the cook then warns exactly as the reference does, :398).
-    const GA_Attribute *captureDistanceAttribute() const { return nullptr; }
-
     fdsop_node *myNode = nullptr;
+    const GA_PointGroup *myGroup = nullptr;       // reference src/SOP_FaceDeform.hpp:108
+    // ProximityCapture's inputs, kept from cook to cook (a static mesh builds them once)
+    std::vector<int64_t> myEdgeOffsets;
+    std::vector<int> myEdgeNeighbours;
+    std::vector<float> myRigTris;
+    bool myRigGathered = false;
     PinnedF myP, myRestP, myDeformP, myTu, myTv, myNn, myDist2, myPout, myFalloff, myRestAttr;
     // one gather buffer per blendshape input (PinnedF is not movable: held by pointer)
     struct ShapeSlot {
