@@ -64,6 +64,7 @@ EXPORTS = [
     "fd_morph_get_qr",
     "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error",
     "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result", "fd_batch_deform_dev",
+    "fd_batch_deform_shared_dev",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
     "fdsop_get_float", "fdsop_get_int", "fdsop_parm_count", "fdsop_parm_token", "fdsop_cook",
     "fdsop_messages", "fdsop_effective_float", "fdsop_engine",
@@ -150,6 +151,8 @@ def load() -> C.CDLL:
     pv = C.POINTER(vp)
     L.fd_batch_deform_dev.argtypes = [vp, vp, i64, pv, pv, pv, pv, pv, pv, pv, C.c_float, C.c_float]
     L.fd_batch_deform_dev.restype = i32
+    L.fd_batch_deform_shared_dev.argtypes = [vp, vp, i64, vp, pv, vp, pv, vp, vp, vp, C.c_float, C.c_float]
+    L.fd_batch_deform_shared_dev.restype = i32
     L.fdsop_create.argtypes = [C.POINTER(FdConfig)]; L.fdsop_create.restype = vp
     L.fdsop_destroy.argtypes = [vp]; L.fdsop_destroy.restype = None
     L.fdsop_set_float.argtypes = [vp, C.c_char_p, i32, C.c_double]; L.fdsop_set_float.restype = i32
@@ -478,6 +481,20 @@ class Batch:
         self._check(self.L.fd_batch_deform_dev(self.h, C.c_void_p(stream_ptr or 0), N, tab(d_P_in), tab(d_P_out),
                                                tab(d_dist2), tab(d_falloff), tu, tv, nr, float(radius2),
                                                float(falloffrate)))
+
+    def deform_shared_dev(self, N: int, d_P_in: int, d_P_out, d_dist2: int = 0, d_falloff=None, d_tangents=None,
+                          radius2=1.0, falloffrate=1.0, stream_ptr: int | None = None):
+        """Frames of one mesh and one rest rig: ONE input mesh (device pointer), one output per context."""
+        n = len(self.engines)
+        if len(d_P_out) != n or (d_falloff is not None and len(d_falloff) != n):
+            raise ValueError("one output pointer per context")
+        vp = C.c_void_p
+        outs = (vp * n)(*d_P_out)
+        falls = None if d_falloff is None else (vp * n)(*[p or None for p in d_falloff])
+        tu, tv, nr = d_tangents if d_tangents is not None else (0, 0, 0)
+        self._check(self.L.fd_batch_deform_shared_dev(self.h, vp(stream_ptr or 0), N, vp(d_P_in), outs, vp(d_dist2 or None),
+                                                      falls, vp(tu or None), vp(tv or None), vp(nr or None),
+                                                      float(radius2), float(falloffrate)))
 
     def build_result(self, check: bool = True):
         n = len(self.engines)

@@ -19,6 +19,7 @@ struct fd_ctx {
     int eval_variant = 0;
     int solver = FD_SOLVER_AUTO;
     int imported_layers = 0;         // a multilayer model that came in through fd_import_model
+    const float *rest_src = nullptr; // caller's device array the rest points were last read from in place (fd_batch_set_points_dev), else null
     bool prefer_lu = false;          // the Cholesky path lost definiteness on this rig: LU until kernel, term or M change
     bool last_spd = false;           // the build in flight / last finished took the Cholesky path
 
@@ -110,6 +111,9 @@ struct fd_batch {
     // a stream that already waits for the current build (set by the first evaluation that
     // needed it): the other contexts' evaluations on that stream need no wait of their own
     hipStream_t waited_stream = nullptr;
+    // scratch of the shared-rig evaluation (fd_batch_deform_shared_dev): weight tiles + frame records
+    void *d_wtiles = nullptr, *d_frames = nullptr;
+    size_t cap_wtiles = 0, cap_frames = 0;
     char err[512] = {0};
 };
 
@@ -397,6 +401,7 @@ static int set_points_common(fd_ctx *ctx, const float *rest, const float *delta,
     if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));  // caller may reuse its arrays
     if (M != ctx->M) ctx->prefer_lu = false;
     ctx->M = M;
+    ctx->rest_src = nullptr;
     ctx->points_set = true;
     ctx->built = false;
     ctx->build_pending = false;
@@ -1236,6 +1241,8 @@ void fd_batch_destroy(fd_batch *b)
     for (hipEvent_t e : b->lu_events) if (e) (void)hipEventDestroy(e);
     if (b->lu_stream) (void)hipStreamDestroy(b->lu_stream);
     if (b->d_slots) (void)hipFree(b->d_slots);
+    if (b->d_wtiles) (void)hipFree(b->d_wtiles);
+    if (b->d_frames) (void)hipFree(b->d_frames);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -1261,6 +1268,7 @@ int fd_batch_set_points_dev(fd_batch *b, const float *const *d_rest_xyz, const f
         c->build_pending = false;
         c->have_factor = false;
         c->deltas_only = false;
+        c->rest_src = d_rest_xyz[i];
         b->src.rest[i] = d_rest_xyz[i];
         b->src.delta[i] = d_delta_xyz[i];
     }
@@ -1423,6 +1431,71 @@ int fd_batch_deform_dev(fd_batch *b, void *hip_stream, int64_t N, const float *c
     }
     hipError_t e = launch_deform_batch(args, b->n, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_batch failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    return FD_OK;
+}
+
+// Frames of ONE mesh and ONE rest rig: phi(|x - c|^2) is formed once per (vertex, centre) for all of
+// them and the weight contraction runs on the matrix pipe (fd_eval.hip, k_deform32_tps_shared).
+int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const float *d_P_in, float *const *d_P_out,
+                               const float *d_dist2, float *const *d_falloff_out, const float *d_tu,
+                               const float *d_tv, const float *d_nrm, float radius2, float falloffrate)
+{
+    if (!b || !d_P_out) return FD_E_INVALID;
+    if (N < 0 || (N > 0 && !d_P_in)) { batch_err(b, "fd_batch_deform_shared_dev: bad N / P_in"); return FD_E_INVALID; }
+    const int ntan = (d_tu != nullptr) + (d_tv != nullptr) + (d_nrm != nullptr);
+    if (ntan != 0 && ntan != 3) { batch_err(b, "fd_batch_deform_shared_dev: tu, tv, nrm must be all set or all NULL"); return FD_E_INVALID; }
+    if (N == 0) return FD_OK;
+    fd_ctx *c0 = b->ctxs[0];
+    int rc = use_device(c0);
+    if (rc) { batch_err(b, "%s", c0->err); return rc; }
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(c0);
+    bool fast = c0->kind == FD_KERNEL_THIN_PLATE && round_up(c0->M, kRecPad) >= 32;
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        if (!d_P_out[i]) { batch_err(b, "fd_batch_deform_shared_dev: NULL output array for context %d", i); return FD_E_INVALID; }
+        if (!c->built && !c->build_pending) { batch_err(b, "fd_batch_deform_shared_dev: context %d has no built model", i); return FD_E_NOT_BUILT; }
+        // one rest rig: every context read its rest points in place from the SAME device array
+        if (!c->rest_src || c->rest_src != c0->rest_src || c->M != c0->M || c->kind != c0->kind || c->term != c0->term) {
+            batch_err(b, "fd_batch_deform_shared_dev: the contexts must share one rest rig (fd_batch_set_points_dev with the "
+                         "same rest array for all), kernel and term; context %d does not", i);
+            return FD_E_INVALID;
+        }
+        if (c->eval_precision != FD_EVAL_FP32 || c->eval_variant > 0 || record_layers(c) != 0) fast = false;
+    }
+    if (!fast) {
+        // any other kernel / precision: the per-frame launches on the shared arrays (same results as fd_deform_dev)
+        const float *pin[kMaxBatch], *pd2[kMaxBatch], *ptu[kMaxBatch], *ptv[kMaxBatch], *pnr[kMaxBatch];
+        for (int i = 0; i < b->n; ++i) { pin[i] = d_P_in; pd2[i] = d_dist2; ptu[i] = d_tu; ptv[i] = d_tv; pnr[i] = d_nrm; }
+        return fd_batch_deform_dev(b, hip_stream, N, pin, d_P_out, d_dist2 ? pd2 : nullptr, d_falloff_out, d_tu ? ptu : nullptr,
+                                   d_tu ? ptv : nullptr, d_tu ? pnr : nullptr, radius2, falloffrate);
+    }
+    SharedDeformArgs a{};
+    a.N = N; a.P_in = d_P_in; a.dist2 = d_dist2; a.tu = d_tu; a.tv = d_tv; a.nrm = d_nrm;
+    a.radius2 = radius2; a.falloffrate = falloffrate;
+    a.Mpad = round_up(c0->M, kRecPad); a.nF = b->n;
+    a.ctiles = c0->d_tiles16;
+    a.falloff_out = d_falloff_out;
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        a.rec32[i] = c->d_rec32; a.model[i] = c->d_model; a.P_out[i] = d_P_out[i];
+        if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
+    }
+    const size_t wb = shared_wtile_bytes(a.Mpad, a.nF), fb = shared_frame_bytes(a.nF);
+    if (wb > b->cap_wtiles || fb > b->cap_frames) {
+        // (hipFree drains the device: no launch still reads the old scratch)
+        if (b->d_wtiles) (void)hipFree(b->d_wtiles);
+        if (b->d_frames) (void)hipFree(b->d_frames);
+        b->d_wtiles = b->d_frames = nullptr; b->cap_wtiles = b->cap_frames = 0;
+        if (hipMalloc(&b->d_wtiles, wb) != hipSuccess || hipMalloc(&b->d_frames, fb) != hipSuccess) {
+            (void)hipGetLastError();
+            batch_err(b, "fd_batch_deform_shared_dev: scratch allocation (%zu bytes) failed", wb + fb);
+            return FD_E_NOMEM;
+        }
+        b->cap_wtiles = wb; b->cap_frames = fb;
+    }
+    a.wtiles = b->d_wtiles; a.frames = b->d_frames;
+    hipError_t e = launch_deform_shared(a, stream);
+    if (e != hipSuccess) { batch_err(b, "launch_deform_shared failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
     return FD_OK;
 }
 

@@ -787,6 +787,372 @@ __global__ __launch_bounds__(kBlock) void k_deform64(const EvalParams p)
     }
 }
 
+// ---- frames that share the mesh AND the rest rig: the contraction on the matrix pipe ------------------
+// The frames of an animated shot, the blendshapes of one head (BASELINE configs 4 and 2-as-benchmarked):
+// the same vertices against the same centres, only the deltas -- hence the weights -- differ.  Then
+//     Delta_f(x_v) = poly_f(x_v) + sum_j phi(|x_v - c_j|^2) w_f[j]
+// is Phi (N x M) times W (M x 3F): phi is formed ONCE per (vertex, centre) -- d2 on the matrix pipe as
+// in k_deform32_tps_mfma, then one v_log_f32 and one multiply -- and the 3F-wide contraction, which is
+// what costs 24 of the 38 vector instructions per 4 pairs in the one-frame kernel, becomes
+// v_mfma_f32_16x16x32_f16 work: north_star's "N x M evaluation recast as a dense GEMM-like contraction".
+// fp16 has 11 significant bits, so both operands go in as two pieces (hi = RN16(v), lo = RN16(v - hi):
+// 22 bits) and a product is three instructions, hi*hi + hi*lo + lo*hi (the dropped lo*lo is 2^-22
+// relative); accumulation is fp32 inside the matrix pipe.  Per-frame weights are scaled by a power of
+// two so that their largest piece sits at 2^13 (fp16 range), undone exactly in the epilogue.
+//
+// Layout: a workgroup of 8 waves (two per SIMD) keeps the centre tiles and the weight tiles of a chunk
+// of centres in LDS -- the whole model at M = 256, F = 32: 12 + 128 KiB -- and walks vertex groups of
+// 512; a wave owns 64 vertices = 4 vertex tiles of 16.  Per 32 centres (one K block) and vertex tile:
+// two d2 instructions, 8 log + 8 multiplies + the fp16 split per lane, and that lane's 8 phi values
+// ARE its B operand (the k-slot <-> centre map is a free choice as long as the weight tiles use the
+// same one: slot 8g + s = centre 32 kb + 16 (s >> 2) + 4 g + (s & 3)).  An output tile is 16 rows
+// x 16 vertices with rows = 4 frames x (x, y, z, unused): lane group g' of the accumulator then holds
+// all three components of frame 4 T + g' for its vertex and writes them as 12 contiguous bytes.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kSharedThreads = 512;
+constexpr int kSharedFramesPerTile = 4;
+constexpr size_t kSharedLdsBudget = 150 * 1024;   // of 160 KiB: the build kernels that run beside it need a few KiB too
+
+struct SharedFrame {              // one per frame slot (nT * 4), written by k_pack_shared
+    float poly[15];               // DevModel::poly32 of the frame's model
+    float inv_scale;              // 2^-k: undoes the weight scaling
+    int built;                    // terminationtype == 1
+    int pad[3];
+    float *P_out, *falloff_out;   // the frame's outputs (read per lane from LDS: 64 pointers as kernel
+                                  // arguments end up hoisted into SGPRs and spilled)
+};
+static_assert(sizeof(SharedFrame) == 96, "frame record");
+
+struct SharedOut {                // per-frame outputs (kernel argument)
+    float *P_out[kMaxBatch];
+    float *falloff_out[kMaxBatch];
+};
+
+struct SharedParams {
+    int64_t N;
+    const float *P_in;
+    const float *dist2;
+    const float *tu, *tv, *nrm;
+    float radius2, falloffrate;
+    int ntiles;                   // centre tiles (Mpad / 16)
+    int nkb;                      // K blocks of 32 centres = ceil(ntiles / 2)
+    int nF, nT;                   // frames, output tiles (4 frames each)
+    int kchunk;                   // K blocks staged in LDS at a time
+    const MfmaTileH *ctiles;      // centre tiles of the shared rest rig (any one context's)
+    const DevModel *model0;       // normalisation of the shared rest rig
+    const uint4 *wtiles;          // [nkb][nT][2 (hi, lo)][64 lanes] x 16 B
+    const SharedFrame *frames;    // [nT * 4]
+    int dbg;                      // FD_SHARED_DBG (diagnostics): 1 = no stores unless a sum is NaN, 2 = no main loop
+    int stagger;                  // waves 4..7 start this many x 8192 cycles late (resident model only)
+};
+
+struct SharedSlots {              // the models of the frames (kernel argument of the pack kernel)
+    const Rec32 *rec32[kMaxBatch];
+    const DevModel *model[kMaxBatch];
+};
+
+// weight tiles + frame records from the solved models.  grid (nkb, nT), 64 threads.
+__global__ __launch_bounds__(64) void k_pack_shared(const SharedSlots slots, const SharedOut out, int nF, int Mpad, uint4 *wtiles, SharedFrame *frames)
+{
+    const int kb = blockIdx.x, T = blockIdx.y, nT = gridDim.y;
+    const int lane = threadIdx.x, g = lane >> 4, rho = lane & 15;
+    const int fi = rho >> 2, c = rho & 3;
+    // scale of each of this tile's four frames: largest |weight| to [2^13, 2^14)
+    __shared__ float s_scale[4];
+    for (int q = 0; q < kSharedFramesPerTile; ++q) {
+        const int f = 4 * T + q;
+        float m = 0.f;
+        if (f < nF) {
+            const Rec32 *r = slots.rec32[f];
+            for (int j = lane; j < Mpad; j += 64) m = fmaxf(m, fmaxf(fabsf(r[j].wx), fmaxf(fabsf(r[j].wy), fabsf(r[j].wz))));
+        }
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) {
+            int k = 0;
+            if (m > 0.f && m < INFINITY) k = 13 - (__builtin_amdgcn_frexp_expf(m) - 1);
+            k = k < -100 ? -100 : (k > 100 ? 100 : k);
+            s_scale[q] = ldexpf(1.f, k);
+            if (kb == 0) {
+                SharedFrame fr;
+                for (int e = 0; e < 15; ++e) fr.poly[e] = f < nF ? slots.model[f]->poly32[e] : 0.f;
+                fr.inv_scale = ldexpf(1.f, -k);
+                fr.built = (f < nF && slots.model[f]->terminationtype == 1) ? 1 : 0;
+                fr.pad[0] = fr.pad[1] = fr.pad[2] = 0;
+                fr.P_out = f < nF ? out.P_out[f] : nullptr;
+                fr.falloff_out = f < nF ? out.falloff_out[f] : nullptr;
+                frames[4 * T + q] = fr;
+            }
+        }
+    }
+    __syncthreads();
+    const int f = 4 * T + fi;
+    const float sc = s_scale[fi];
+    f16x8 hi, lo;
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+        const int centre = 32 * kb + 16 * (sidx >> 2) + 4 * g + (sidx & 3);
+        float w = 0.f;
+        if (f < nF && c < 3 && centre < Mpad) {
+            const Rec32 r = slots.rec32[f][centre];
+            w = (c == 0 ? r.wx : (c == 1 ? r.wy : r.wz)) * sc;
+        }
+        const _Float16 h = (_Float16)w;
+        hi[sidx] = h;
+        lo[sidx] = (_Float16)(w - (float)h);
+    }
+    uint4 *dst = wtiles + ((size_t)kb * nT + T) * 128;
+    dst[lane] = __builtin_bit_cast(uint4, hi);
+    dst[64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+// fp32 pair -> its two fp16 pieces, packed: hi = RN16(v), lo = RN16(v - hi).  One v_cvt_pk_f16_f32 and
+// two mixed-precision fmas that subtract the fp16 piece from the fp32 value and round the
+// remainder to fp16 in the same instruction (v_fma_mixlo/hi_f16 write one half of the destination
+// and keep the other) -- three instructions for two values, no unpacking, no repacking.
+__device__ __forceinline__ void split_pair_f16(float v0, float v1, unsigned &hi, unsigned &lo)
+{
+    const f16x2 hh = __builtin_convertvector((f32x2){v0, v1}, f16x2);
+    hi = __builtin_bit_cast(unsigned, hh);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(v1));
+    lo = l;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// one vertex position as a single 12-byte store (dword-aligned: global_store_dwordx3)
+struct __attribute__((packed, aligned(4))) Pos3 { float x, y, z; };
+__device__ __forceinline__ void store_pos3(Pos3 FD_GLOBAL *dst, float x, float y, float z)
+{
+    dst->x = x; dst->y = y; dst->z = z;      // member-wise: a struct assignment through an address-space pointer does not compile on the host pass
+}
+
+template <int NT>
+__global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_deform32_tps_shared(const SharedParams p, int ngroups)
+{
+    constexpr int TV = 4;                        // vertex tiles per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [frames NT*4][centre tiles kchunk*2][weight tiles kchunk*NT*2*64 x 16 B]
+    SharedFrame *s_frames = reinterpret_cast<SharedFrame *>(smem);
+    MfmaTileH *s_ct = reinterpret_cast<MfmaTileH *>(smem + sizeof(SharedFrame) * (size_t)(NT * 4));
+    uint4 *s_w = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(s_ct) + sizeof(MfmaTileH) * (size_t)(2 * p.kchunk));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const float n0 = p.model0->norm32[0], n1 = p.model0->norm32[1], n2 = p.model0->norm32[2];
+    const float inv_s = p.model0->norm32[3];
+    const bool resident = p.nkb <= p.kchunk;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int kb0, int nk) {
+        __syncthreads();
+        {   // centre tiles 2 kb0 .. 2 (kb0 + nk) - 1; beyond ntiles: zeros
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.ctiles + 2 * kb0);
+            uint4 *dst = reinterpret_cast<uint4 *>(s_ct);
+            const int per = (int)(sizeof(MfmaTileH) / 16);
+            const int have = (p.ntiles - 2 * kb0) * per;
+            for (int q = tid; q < 2 * nk * per; q += kSharedThreads) dst[q] = q < have ? src[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        {
+            const uint4 *src = p.wtiles + (size_t)kb0 * NT * 128;
+            const int n16 = nk * NT * 128;
+            for (int q = tid; q < n16; q += kSharedThreads) s_w[q] = src[q];
+        }
+        __syncthreads();
+    };
+
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.frames);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_frames);
+        for (int q = tid; q < NT * 4 * (int)(sizeof(SharedFrame) / 16); q += kSharedThreads) dst[q] = src[q];
+    }
+    if (resident) {
+        stage(0, p.nkb);
+        // The two waves of a SIMD (w and w + 4) run the same program: left alone they reach their
+        // logarithm phase together and their matrix phase together, and each phase then has one
+        // pipe idle.  Half a K block of delay for the second half puts one wave's vector work
+        // beside the other's matrix work (no barrier follows while the model is resident).
+        // The same goes for the epilogue, where a wave issues 96 stores and waits on the memory
+        // pipeline: with all eight waves there at once the matrix pipe idles for the whole burst.
+        // A start-up delay of about half a vertex group for waves 4..7 keeps one wave of every SIMD
+        // in its K loop while the other stores.
+        if (wave >= 4) {
+            __builtin_amdgcn_s_sleep(12);
+            for (int q = 0; q < p.stagger; ++q) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t vbase = ((int64_t)grp * (kSharedThreads / 64) + wave) * (16 * TV);
+        // every lane group holds vertex (vt, j): the d2 operand needs one coordinate of it per lane
+        // group; the epilogue (frame 4 T + g of that vertex) re-reads the position
+        float d2v[TV];
+        f16x4 bop[TV];
+        bool lane_live = false;
+#pragma unroll
+        for (int t = 0; t < TV; ++t) {
+            const int64_t vi = vbase + 16 * t + j;
+            const int64_t vc = vi < p.N ? vi : p.N - 1;
+            const float x = (p.P_in[3 * vc] - n0) * inv_s, y = (p.P_in[3 * vc + 1] - n1) * inv_s, z = (p.P_in[3 * vc + 2] - n2) * inv_s;
+            d2v[t] = p.dist2 ? p.dist2[vc] : 0.f;
+            lane_live |= (vi < p.N) && !(d2v[t] > p.radius2);
+            const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+            const float v2 = g == 0 ? -2.f * x : (g == 1 ? -2.f * y : (g == 2 ? -2.f * z : xx));
+            const _Float16 h = (_Float16)v2;
+            const _Float16 l = (_Float16)(v2 - (float)h);
+            const _Float16 one = (_Float16)1.0f;
+            bop[t] = g < 3 ? (f16x4){h, l, h, l} : (f16x4){one, one, h, l};
+        }
+        const bool wave_work = __any(lane_live);
+
+        f32x4 acc[NT][TV];
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int t = 0; t < TV; ++t) acc[T][t] = zero4;
+
+        for (int kb0 = 0; kb0 < p.nkb; kb0 += p.kchunk) {
+            const int nk = p.nkb - kb0 < p.kchunk ? p.nkb - kb0 : p.kchunk;
+            if (!resident) stage(kb0, nk);
+            if (!wave_work || (p.dbg & 2)) continue;
+            for (int kb = 0; kb < nk; ++kb) {
+                const uint4 *wk = s_w + (size_t)kb * NT * 128 + lane;
+                // the first weight tile travels from LDS while the logarithms run
+                u32x4 wh = __builtin_bit_cast(u32x4, wk[0]), wl = __builtin_bit_cast(u32x4, wk[64]);
+                const f16x4 aopA = *reinterpret_cast<const f16x4 *>(&s_ct[2 * kb].a[lane][0]);
+                const f16x4 aopB = *reinterpret_cast<const f16x4 *>(&s_ct[2 * kb + 1].a[lane][0]);
+                u32x4 bh[TV], bl[TV];
+#pragma unroll
+                for (int t = 0; t < TV; ++t) {
+                    const f32x4 da = __builtin_amdgcn_mfma_f32_16x16x16f16(aopA, bop[t], zero4, 0, 0, 0);
+                    const f32x4 db = __builtin_amdgcn_mfma_f32_16x16x16f16(aopB, bop[t], zero4, 0, 0, 0);
+                    unsigned h, l;
+                    split_pair_f16(d2_log_d2(da[0]), d2_log_d2(da[1]), h, l); bh[t][0] = h; bl[t][0] = l;
+                    split_pair_f16(d2_log_d2(da[2]), d2_log_d2(da[3]), h, l); bh[t][1] = h; bl[t][1] = l;
+                    split_pair_f16(d2_log_d2(db[0]), d2_log_d2(db[1]), h, l); bh[t][2] = h; bl[t][2] = l;
+                    split_pair_f16(d2_log_d2(db[2]), d2_log_d2(db[3]), h, l); bh[t][3] = h; bl[t][3] = l;
+                }
+#pragma unroll
+                for (int T = 0; T < NT; ++T) {
+                    u32x4 nwh = wh, nwl = wl;
+                    if (T + 1 < NT) {            // the next tile's operands are requested before this tile's products
+                        nwh = __builtin_bit_cast(u32x4, wk[(T + 1) * 128]);
+                        nwl = __builtin_bit_cast(u32x4, wk[(T + 1) * 128 + 64]);
+                    }
+                    const f16x8 ah = __builtin_bit_cast(f16x8, wh), al = __builtin_bit_cast(f16x8, wl);
+#pragma unroll
+                    for (int t = 0; t < TV; ++t) {
+                        const f16x8 xh = __builtin_bit_cast(f16x8, bh[t]), xl = __builtin_bit_cast(f16x8, bl[t]);
+                        acc[T][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh, acc[T][t], 0, 0, 0);
+                        acc[T][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh, acc[T][t], 0, 0, 0);
+                        acc[T][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl, acc[T][t], 0, 0, 0);
+                    }
+                    wh = nwh; wl = nwl;
+                }
+            }
+        }
+
+        // ---- epilogue.  The accumulators hold, in lane group g, frame 4 T + g for the four vertex
+        // tiles; a 4 x 4 transpose across the lane groups (two v_permlane32_swap + two
+        // v_permlane16_swap per four registers) turns that into vertex tile g for the four frames
+        // of the tile: every lane then owns ONE vertex (vbase + lane), does the per-vertex work
+        // (gate, fall-off, tangent axes) once, and a frame's 64 positions leave as one contiguous
+        // 768-byte store.  The reference's order: gate -> tangent projection -> fall-off -> add
+        // (src/SOP_FaceDeform.cpp:405-438).
+        // All transposes first, in place (acc[T][k][c] becomes frame 4 T + k, component c, of this
+        // lane's vertex), while the wave is still converged: the lane-crossing instructions sit
+        // in straight-line code behind the K loop, not between the divergent blocks that follow.
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // X_k[g] = (frame g, vertex tile k)  ->  Y_k[g] = (frame k, vertex tile g)
+                const u32x2 s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[T][0][c]), __float_as_uint(acc[T][2][c]), false, false);
+                const u32x2 s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[T][1][c]), __float_as_uint(acc[T][3][c]), false, false);
+                const u32x2 y01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                const u32x2 y23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                acc[T][0][c] = __uint_as_float(y01[0]); acc[T][1][c] = __uint_as_float(y01[1]);
+                acc[T][2][c] = __uint_as_float(y23[0]); acc[T][3][c] = __uint_as_float(y23[1]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t i = vbase + lane;
+        const bool inb = i < p.N;
+        const int64_t ic = inb ? i : p.N - 1;
+        const float pos[3] = {p.P_in[3 * ic], p.P_in[3 * ic + 1], p.P_in[3 * ic + 2]};
+        const float own_d2 = p.dist2 ? p.dist2[ic] : 0.f;
+        const float x = (pos[0] - n0) * inv_s, y = (pos[1] - n1) * inv_s, z = (pos[2] - n2) * inv_s;
+        const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        const bool gated = own_d2 > p.radius2;
+        float fall = 1.f;
+        if (!gated && (p.dist2 != nullptr || !(p.radius2 != 0.f))) {
+            const float q = fminf(own_d2 / p.radius2, 1.f);
+            fall = powf(1.f - q, p.falloffrate);
+        }
+        float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+        if (p.tu && !gated) {
+            // project_to_tangents (src/SOP_FaceDeform.hpp:28-41): the two axes depend on the vertex only
+            float u[3] = {p.tu[3 * ic], p.tu[3 * ic + 1], p.tu[3 * ic + 2]};
+            float v[3] = {p.tv[3 * ic], p.tv[3 * ic + 1], p.tv[3 * ic + 2]};
+            float n[3] = {p.nrm[3 * ic], p.nrm[3 * ic + 1], p.nrm[3 * ic + 2]};
+            normalize3(u[0], u[1], u[2]);
+            normalize3(v[0], v[1], v[2]);
+            normalize3(n[0], n[1], n[2]);
+            float gm[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gm[r][c] = u[r] * u[c] + v[r] * v[c] + n[r] * n[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a1[c] = u[0] * gm[0][c] + u[1] * gm[1][c] + u[2] * gm[2][c];
+                a2[c] = v[0] * gm[0][c] + v[1] * gm[1][c] + v[2] * gm[2][c];
+            }
+            normalize3(a1[0], a1[1], a1[2]);
+            normalize3(a2[0], a2[1], a2[2]);
+        }
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = 4 * T + k;             // wave-uniform
+                if (f >= p.nF || !inb) continue;
+                // the record is read per lane (one LDS address for all: a broadcast).  Left to the
+                // compiler, 32 unrolled frames x 21 wave-uniform scalars are hoisted into SGPRs and spilled.
+                int fidx = f;
+                asm volatile("" : "+v"(fidx));
+                const SharedFrame &fr = s_frames[fidx];
+                // (pointers that come out of memory are generic to the compiler: say that they are global)
+                Pos3 FD_GLOBAL *Pout = (Pos3 FD_GLOBAL *)as_global(fr.P_out) + i;
+                float FD_GLOBAL *Fout = as_global(fr.falloff_out);
+                if (gated || !fr.built) {
+                    if (fr.P_out != p.P_in) store_pos3(Pout, pos[0], pos[1], pos[2]);
+                    continue;
+                }
+                float disp[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float poly = __builtin_fmaf(fr.poly[5 * c + 4], xx, __builtin_fmaf(fr.poly[5 * c + 3], z,
+                                         __builtin_fmaf(fr.poly[5 * c + 2], y, __builtin_fmaf(fr.poly[5 * c + 1], x, fr.poly[5 * c]))));
+                    disp[c] = __builtin_fmaf(acc[T][k][c], fr.inv_scale, poly);
+                }
+                if ((p.dbg & 1) && disp[0] + disp[1] + disp[2] == disp[0] + disp[1] + disp[2]) continue;
+                if (p.tu) {
+                    const float da1 = disp[0] * a1[0] + disp[1] * a1[1] + disp[2] * a1[2];
+                    const float da2 = disp[0] * a2[0] + disp[1] * a2[1] + disp[2] * a2[2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
+                }
+                if (fr.falloff_out) Fout[i] = fall;
+                store_pos3(Pout, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+            }
+        }
+    }
+}
+
 template <int KIND>
 hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t stream)
 {
@@ -977,6 +1343,70 @@ hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream)
     hipLaunchKernelGGL((k_deform32_tps_mfma_batch<TV, true>), dim3(grid, (unsigned)n), dim3(kBlock), sizeof(MfmaTileH) * nres, stream,
                        args, (int)ngroups);
     return hipGetLastError();
+}
+
+// Frames of one mesh and one rest rig (SharedDeformArgs): pack the weight tiles, then one launch.
+hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
+{
+    if (a.N <= 0 || a.nF <= 0) return hipSuccess;
+    if (a.nF > kMaxBatch || a.Mpad % 16 != 0) return hipErrorInvalidValue;
+    const int ntiles = a.Mpad / 16, nkb = (ntiles + 1) / 2;
+    const int nT = (a.nF + kSharedFramesPerTile - 1) / kSharedFramesPerTile;
+    SharedSlots slots{};
+    SharedOut out{};
+    for (int f = 0; f < kMaxBatch; ++f) {
+        const int q = f < a.nF ? f : 0;
+        slots.rec32[f] = a.rec32[q]; slots.model[f] = a.model[q];
+        out.P_out[f] = a.P_out[q]; out.falloff_out[f] = a.falloff_out ? a.falloff_out[q] : nullptr;
+    }
+    hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(64), 0, stream, slots, out, a.nF, a.Mpad, (uint4 *)a.wtiles, (SharedFrame *)a.frames);
+    SharedParams p{};
+    p.N = a.N; p.P_in = a.P_in; p.dist2 = a.dist2; p.tu = a.tu; p.tv = a.tv; p.nrm = a.nrm;
+    p.radius2 = a.radius2; p.falloffrate = a.falloffrate;
+    p.ntiles = ntiles; p.nkb = nkb; p.nF = a.nF; p.nT = nT;
+    p.ctiles = a.ctiles; p.model0 = a.model[0];
+    p.wtiles = (const uint4 *)a.wtiles; p.frames = (const SharedFrame *)a.frames;
+    { static const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
+    { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 3; }
+    const size_t fixed = sizeof(SharedFrame) * (size_t)(nT * 4);
+    const size_t per_kb = 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
+    int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);
+    if (kchunk < 1) return hipErrorInvalidValue;
+    if (kchunk > nkb) kchunk = nkb;
+    p.kchunk = kchunk;
+    const size_t lds = fixed + per_kb * (size_t)kchunk;
+    const int64_t per = kSharedThreads / 64 * 64;          // vertices per workgroup and group
+    const int64_t ngroups = (a.N + per - 1) / per;
+    const unsigned grid = (unsigned)(ngroups < (int64_t)kNumCU ? ngroups : (int64_t)kNumCU);
+#define FD_SHARED_CASE(NTV)                                                                                          \
+    case NTV: {                                                                                                      \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared<NTV>,                            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+            if (e != hipSuccess) return e;                                                                           \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL(k_deform32_tps_shared<NTV>, dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
+        break;                                                                                                       \
+    }
+    switch (nT) {
+        FD_SHARED_CASE(1) FD_SHARED_CASE(2) FD_SHARED_CASE(3) FD_SHARED_CASE(4)
+        FD_SHARED_CASE(5) FD_SHARED_CASE(6) FD_SHARED_CASE(7) FD_SHARED_CASE(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef FD_SHARED_CASE
+    return hipGetLastError();
+}
+
+size_t shared_wtile_bytes(int Mpad, int nF)
+{
+    const int nkb = (Mpad / 16 + 1) / 2, nT = (nF + kSharedFramesPerTile - 1) / kSharedFramesPerTile;
+    return (size_t)nkb * nT * 128 * 16;
+}
+size_t shared_frame_bytes(int nF)
+{
+    return sizeof(SharedFrame) * (size_t)((nF + kSharedFramesPerTile - 1) / kSharedFramesPerTile * 4);
 }
 
 const char *deform_kernel_name(int kind, int precision, int variant)

@@ -201,6 +201,25 @@ struct DeformArgs {
 };
 hipError_t launch_deform(const DeformArgs &a, hipStream_t stream);
 hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream);
+// frames that share the mesh and the rest rig (fd_eval.hip, k_deform32_tps_shared): phi once per
+// (vertex, centre), the 3 F-wide weight contraction on the matrix pipe
+struct SharedDeformArgs {
+    int64_t N;
+    const float *P_in;                    // the one mesh
+    const float *dist2;
+    const float *tu, *tv, *nrm;
+    float radius2, falloffrate;
+    int Mpad, nF;
+    const MfmaTileH *ctiles;              // centre tiles of the shared rest rig
+    const Rec32 *rec32[kMaxBatch];        // per frame: the solved model's records (weights)
+    const DevModel *model[kMaxBatch];
+    float *P_out[kMaxBatch];
+    float *const *falloff_out;            // nF entries or nullptr
+    void *wtiles, *frames;                // scratch of shared_wtile_bytes / shared_frame_bytes
+};
+hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream);
+size_t shared_wtile_bytes(int Mpad, int nF);
+size_t shared_frame_bytes(int nF);
 // island mask (fd_capture.hip): nearest mesh point per rig point + max_edges breadth-first rings
 hipError_t launch_capture_islands(const float *d_P, int64_t N, const int64_t *d_offsets, const int *d_neighbours,
                                   const float *d_rig, int M, int max_edges, unsigned char *d_mask, hipStream_t stream);

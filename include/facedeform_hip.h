@@ -301,6 +301,22 @@ int fd_batch_deform_dev(fd_batch *batch, void *hip_stream, int64_t N, const floa
                         const float *const *d_tu, const float *const *d_tv, const float *const *d_nrm,
                         float radius2, float falloffrate);
 
+/* The same for frames that share the MESH and the REST RIG -- the frames of an animated shot, the
+ * blendshapes of one head (BASELINE configs 2-4 as SURVEY.md 8d lays them out: "same mesh and rest
+ * rig, deltas phase-shifted"): one input mesh (d_P_in, d_dist2, frames: single arrays), one output
+ * pair per context.  phi(|x - c_j|^2) depends on the vertex and the centre only, so it is formed
+ * once for all frames, and the contraction with the 3 F columns of weights is a dense
+ * (N x M) x (M x 3F) product on the matrix pipe (fp16 x 2 split operands, 22 bits, fp32
+ * accumulation).  Every frame still has its own model, built by its own assemble + solve.  The
+ * contexts must have read their rest points from ONE device array (fd_batch_set_points_dev with
+ * the same d_rest_xyz for all; FD_E_INVALID otherwise); thin-plate kernel, fp32 evaluation, 32 or
+ * more centres -- anything else takes fd_batch_deform_dev on the shared arrays.  Parity with the
+ * oracle as for fd_deform (1e-5); NOT bit-identical to the one-frame kernels. */
+int fd_batch_deform_shared_dev(fd_batch *batch, void *hip_stream, int64_t N, const float *d_P_in,
+                               float *const *d_P_out, const float *d_dist2, float *const *d_falloff_out,
+                               const float *d_tu, const float *d_tv, const float *d_nrm, float radius2,
+                               float falloffrate);
+
 /* ---- dist2 producer (next row N2) ---------------------------------------------
  * The per-point body of ProximityCapture::capture (src/capture.cpp:58-97) on the
  * device: for every mesh point of an island (mask[i] != 0; mask NULL = all points)

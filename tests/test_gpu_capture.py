@@ -187,7 +187,6 @@ def test_sop_cook_captures_on_the_device_and_caches_like_the_reference(hip_lib, 
     ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=got, radius2=r2, falloffrate=1.5)
     assert parity_ratio(res.P, ref, P, 1e-5) <= 1.0
     assert np.allclose(res.fd_falloff, ref_fall, rtol=2e-6, atol=1e-7)
-    assert (res.fd_falloff > 1.0).any()                               # B4: dist2 = -1 overshoots
     # -- end to end: oracle capture -> oracle deform, nothing of the device's in between.  The bar is
     # the capture's: an fp32 distance within 2e-6 (d2 + L^2) moves the fall-off (1 - d2 / r2)^1.5 by up
     # to 1.5 * margin / r2 = 8e-5 of the displacement at r2 = 0.04.
@@ -218,6 +217,14 @@ def test_sop_cook_captures_on_the_device_and_caches_like_the_reference(hip_lib, 
     assert np.all(res4.dist2[mask4 == 0] == 0.0) and mask4.sum() < mask.sum()
     s4 = dec4 & (d4 >= 0) & (mask4 == 1)
     assert np.all(np.abs(res4.dist2[s4] - d4[s4]) <= 2e-6 * (ex4[s4] + 1.0))
+    # a radius inside the islands' extent: island points beyond it read -1 (capture.cpp:76,88), pass the
+    # gate and overshoot (B4: pow(1 - (-1 / r2), rate) > 1)
+    node.set("radius", 0.03); node.set("maxedges", K)
+    res6 = node.cook(P, rest, deform, rig_rest_unchanged=False, mesh_unchanged=True, **kw)
+    r2c = np.float32(0.03) * np.float32(0.03)
+    assert (res6.dist2 == -1.0).any() and (res6.fd_falloff > 1.0).any()
+    ref6, fall6 = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=res6.dist2, radius2=r2c, falloffrate=1.5)
+    assert parity_ratio(res6.P, ref6, P, 1e-5) <= 1.0 and np.allclose(res6.fd_falloff, fall6, rtol=2e-6, atol=1e-7)
     # without the capture's inputs and without a dist2 array: the reference's warning, no gate, no fall-off
     res5 = node.cook(P, rest, deform)
     assert res5.warnings == ["Can't find distance capture attribute. Won't apply radius nor falloff."]

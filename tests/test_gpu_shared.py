@@ -1,0 +1,139 @@
+"""GPU: frames that share the mesh and the rest rig (fd_batch_deform_shared_dev, kernel
+k_deform32_tps_shared): phi once per (vertex, centre), the weight contraction on the matrix pipe
+from fp16 x 2 split operands.  Not bit-identical to the one-frame kernels by construction; the bar
+is the oracle's, 1e-5 of the displacement (conftest.parity_ratio and the stricter l2_parity_ulp),
+for every frame, with gate, fall-off, tangent frames, ragged sizes and vertices sitting on centres."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import l2_parity, l2_parity_ulp, parity_ratio
+from facedeform_amd import capi, synth
+from oracle import fd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _setup(M, N, F, kind=capi.KERNEL_THIN_PLATE, params=(), noise=False):
+    dev = torch.device("cuda", 0)
+    P = synth.head_mesh(max(N, 100_000))[:: max(N, 100_000) // N][:N].copy()
+    rest = synth.control_points(M, "head")
+    P[:6] = rest[:6]                                   # vertices on centres: d2 == 0
+    # frames as SURVEY.md 8d lays them out: same mesh and rest rig, deltas phase-shifted (C4's eight
+    # phases; further frames repeat them at another amplitude).  Phases whose displacement field passes
+    # through zero at some vertices (0.3 * 19 rad does) are the province of
+    # tests/tools/scaled_delta_parity.py: there EVERY fp32 kernel, this one, the one-frame ones and the
+    # all-VALU one alike, is limited by cancellation (sum|phi w| / |d| up to 450) -- DESIGN.md 4.1.
+    deltas = np.stack([synth.smooth_deltas(rest, f % 8) * np.float32(1.0 + 0.25 * (f // 8)) for f in range(F)]).astype(np.float32)
+    d_P = torch.from_numpy(P).to(dev)
+    d_rest = torch.from_numpy(rest).to(dev)
+    d_deltas = torch.from_numpy(deltas).to(dev)
+    engines = []
+    for _ in range(F):
+        e = capi.Engine()
+        e.set_kernel(kind, params); e.set_term(capi.TERM_LINEAR)
+        engines.append(e)
+    batch = capi.Batch(engines)
+    batch.set_points_dev([d_rest.data_ptr()] * F, [d_deltas.data_ptr() + f * M * 12 for f in range(F)], M)
+    batch.build_async()
+    assert [r.terminationtype for r in batch.build_result()] == [1] * F
+    return dev, P, rest, deltas, d_P, (d_rest, d_deltas), engines, batch
+
+
+def _close(engines, batch):
+    batch.close()
+    for e in engines:
+        e.close()
+
+
+@pytest.mark.parametrize("M,N,F", [(48, 4_099, 3), (256, 20_011, 8), (256, 70_000, 32), (100, 1_000, 1), (800, 3_001, 13)])
+def test_shared_frames_match_oracle(hip_lib, oracle, M, N, F):
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F)
+    rng = np.random.default_rng(M + F)
+    tu, tv, nn = synth.tangent_frames(P)
+    r2 = np.float32(0.49)
+    dist2 = (rng.random(N) * 0.6).astype(np.float32)
+    dist2[::9] = -1.0
+    d_d2 = torch.from_numpy(dist2).to(dev)
+    d_t = [torch.from_numpy(a).to(dev) for a in (tu, tv, nn)]
+    outs = [torch.empty_like(d_P) for _ in range(F)]
+    falls = [torch.full((N,), 7.0, device=dev) for _ in range(F)]
+    for mode in ("plain", "gate", "frames"):
+        kw = {}
+        okw = {}
+        if mode != "plain":
+            kw.update(d_dist2=d_d2.data_ptr(), radius2=r2, falloffrate=1.5)
+            okw.update(dist2=dist2, radius2=r2, falloffrate=1.5)
+        if mode == "frames":
+            kw.update(d_tangents=[t.data_ptr() for t in d_t])
+            okw.update(tangents=(tu, tv, nn))
+        for fl in falls:
+            fl.fill_(7.0)
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], d_falloff=[f.data_ptr() for f in falls], **kw)
+        torch.cuda.synchronize()
+        for f in range(F):
+            table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
+            rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+            ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, **okw)
+            plain = None
+            if mode == "frames":
+                plain, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, **{k: v for k, v in okw.items() if k != "tangents"})
+            out = outs[f].cpu().numpy()
+            ratio = parity_ratio(out, ref, P, TOL, scale_out=plain)
+            assert ratio <= 1.0, (mode, f, ratio)
+            if mode == "plain":
+                assert l2_parity_ulp(out, ref, P, TOL) <= 1.0, (f, l2_parity_ulp(out, ref, P, TOL), l2_parity(out, ref, P))
+            fall = falls[f].cpu().numpy()
+            gated = dist2 > r2 if mode != "plain" else np.zeros(N, bool)
+            assert np.array_equal(out[gated], P[gated]) and np.all(fall[gated] == 7.0)      # B2: untouched
+            assert np.allclose(fall[~gated], ref_fall[~gated], rtol=2e-6, atol=1e-7)
+    _close(engines, batch)
+
+
+def test_shared_c2_full_size_and_against_the_one_frame_kernel(hip_lib, oracle):
+    """C2's sizes, 8 frames: every frame sampled against the oracle (raw 8d metric where it holds,
+    see tests/test_gpu_configs.py) and against the one-frame kernel's output, which it must agree
+    with far inside the tolerance (both sit within ~5e-6 of the oracle)."""
+    M, N, F = 256, 1_000_000, 8
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F)
+    outs = [torch.empty_like(d_P) for _ in range(F)]
+    single = [torch.empty_like(d_P) for _ in range(F)]
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])
+    batch.deform_dev(N, [d_P.data_ptr()] * F, [o.data_ptr() for o in single])
+    torch.cuda.synchronize()
+    idx = np.unique(np.concatenate([np.arange(0, N, 397), [0, 1, 5, 6, 63, 64, 511, 512, N - 1]]))
+    for f in range(F):
+        table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
+        rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+        ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P[idx])
+        out = outs[f].cpu().numpy()
+        assert parity_ratio(out[idx], ref, P[idx], TOL) <= 1.0 and l2_parity_ulp(out[idx], ref, P[idx], TOL) <= 1.0, f
+        one = single[f].cpu().numpy()
+        d = np.linalg.norm(one.astype(np.float64) - P, axis=1)
+        assert np.abs(out.astype(np.float64) - one).max() <= 1e-5 * d.max(), f
+    _close(engines, batch)
+
+
+def test_shared_needs_one_rest_rig_and_falls_back_for_other_kernels(hip_lib):
+    M, N, F = 64, 5_000, 4
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F)
+    outs = [torch.empty_like(d_P) for _ in range(F)]
+    # a context whose rest points came from another array: refused, not silently wrong
+    other = torch.from_numpy(rest.copy()).to(dev)
+    batch.set_points_dev([keep[0].data_ptr()] * (F - 1) + [other.data_ptr()], [keep[1].data_ptr()] * F, M)
+    batch.build_async(); batch.build_result()
+    with pytest.raises(capi.FdError) as ei:
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])
+    assert ei.value.code == capi.FD_E_INVALID and "one rest rig" in ei.value.text
+    _close(engines, batch)
+    # the SOP's default model on shared arrays: the per-frame kernels, bit for bit
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F, kind=capi.KERNEL_GAUSSIAN_QNN, params=[1.0, 5.0])
+    a = [torch.empty_like(d_P) for _ in range(F)]
+    b = [torch.empty_like(d_P) for _ in range(F)]
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in a])
+    batch.deform_dev(N, [d_P.data_ptr()] * F, [o.data_ptr() for o in b])
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    _close(engines, batch)
