@@ -22,6 +22,7 @@
 // Built with -ffp-contract=off: every fused multiply-add is written out, so a vertex
 // gets the same bits whichever lane / register slot it lands in (range splits are
 // bit-identical) and the fp32 epilogue rounds like the reference's unfused CPU code.
+#include <cstdio>
 #include <cstdlib>
 
 #include <type_traits>
@@ -813,17 +814,16 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSharedThreads = 512;
 constexpr int kSharedFramesPerTile = 4;
-constexpr size_t kSharedLdsBudget = 150 * 1024;   // of 160 KiB: the build kernels that run beside it need a few KiB too
+constexpr size_t kSharedLdsBudget = 158 * 1024;   // of 160 KiB (one workgroup per CU)
 
 struct SharedFrame {              // one per frame slot (nT * 4), written by k_pack_shared
-    float poly[15];               // DevModel::poly32 of the frame's model
-    float inv_scale;              // 2^-k: undoes the weight scaling
+    float inv_scale;              // 2^-k: undoes the scaling of the frame's weights and polynomial
     int built;                    // terminationtype == 1
-    int pad[3];
-    float *P_out, *falloff_out;   // the frame's outputs (read per lane from LDS: 64 pointers as kernel
-                                  // arguments end up hoisted into SGPRs and spilled)
+    int pad[2];
+    float *P_out, *falloff_out;   // the frame's outputs (read from LDS inside the frame loop: 64 pointers
+                                  // as kernel arguments end up hoisted into SGPRs all at once and spilled)
 };
-static_assert(sizeof(SharedFrame) == 96, "frame record");
+static_assert(sizeof(SharedFrame) == 32, "frame record");
 
 struct SharedOut {                // per-frame outputs (kernel argument)
     float *P_out[kMaxBatch];
@@ -842,10 +842,11 @@ struct SharedParams {
     int kchunk;                   // K blocks staged in LDS at a time
     const MfmaTileH *ctiles;      // centre tiles of the shared rest rig (any one context's)
     const DevModel *model0;       // normalisation of the shared rest rig
-    const uint4 *wtiles;          // [nkb][nT][2 (hi, lo)][64 lanes] x 16 B
+    const uint4 *wtiles;          // [nkb][nT][2 (hi, lo)][64 lanes] x 16 B, then the polynomial tiles [nT][64 lanes] x 16 B
     const SharedFrame *frames;    // [nT * 4]
-    int dbg;                      // FD_SHARED_DBG (diagnostics): 1 = no stores unless a sum is NaN, 2 = no main loop
+    int dbg;                      // FD_SHARED_DBG (diagnostics, tests/tools/shared_eval_timing.py): 1 = no stores, 2 = no K loop
     int stagger;                  // waves 4..7 start this many x 8192 cycles late (resident model only)
+    unsigned long long *stamps;   // diagnostics (FD_SHARED_STAMPS): shader-clock shares of the phases, per wave of workgroup 0
 };
 
 struct SharedSlots {              // the models of the frames (kernel argument of the pack kernel)
@@ -853,13 +854,17 @@ struct SharedSlots {              // the models of the frames (kernel argument o
     const DevModel *model[kMaxBatch];
 };
 
-// weight tiles + frame records from the solved models.  grid (nkb, nT), 64 threads.
+// weight tiles, polynomial tiles and frame records from the solved models.  grid (nkb, nT), 64 threads.
+// The polynomial part of a frame (DevModel::poly32: C0 + L.x' + q |x'|^2 per output) rides in the
+// same matrix product as five more "centres" whose phi are (1, x', y', z', |x'|^2): one K = 32
+// instruction per output tile and vertex tile holds all three split products -- lane group 0
+// pairs hi x hi, group 1 lo(vertex) x hi(coefficient), group 2 hi(vertex) x lo(coefficient).
 __global__ __launch_bounds__(64) void k_pack_shared(const SharedSlots slots, const SharedOut out, int nF, int Mpad, uint4 *wtiles, SharedFrame *frames)
 {
-    const int kb = blockIdx.x, T = blockIdx.y, nT = gridDim.y;
+    const int kb = blockIdx.x, T = blockIdx.y, nT = gridDim.y, nkb = gridDim.x;
     const int lane = threadIdx.x, g = lane >> 4, rho = lane & 15;
     const int fi = rho >> 2, c = rho & 3;
-    // scale of each of this tile's four frames: largest |weight| to [2^13, 2^14)
+    // scale of each of this tile's four frames: largest |weight| or |polynomial coefficient| to [2^13, 2^14)
     __shared__ float s_scale[4];
     for (int q = 0; q < kSharedFramesPerTile; ++q) {
         const int f = 4 * T + q;
@@ -867,6 +872,7 @@ __global__ __launch_bounds__(64) void k_pack_shared(const SharedSlots slots, con
         if (f < nF) {
             const Rec32 *r = slots.rec32[f];
             for (int j = lane; j < Mpad; j += 64) m = fmaxf(m, fmaxf(fabsf(r[j].wx), fmaxf(fabsf(r[j].wy), fabsf(r[j].wz))));
+            if (lane < 15) m = fmaxf(m, fabsf(slots.model[f]->poly32[lane]));
         }
         for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         if (lane == 0) {
@@ -876,10 +882,9 @@ __global__ __launch_bounds__(64) void k_pack_shared(const SharedSlots slots, con
             s_scale[q] = ldexpf(1.f, k);
             if (kb == 0) {
                 SharedFrame fr;
-                for (int e = 0; e < 15; ++e) fr.poly[e] = f < nF ? slots.model[f]->poly32[e] : 0.f;
                 fr.inv_scale = ldexpf(1.f, -k);
                 fr.built = (f < nF && slots.model[f]->terminationtype == 1) ? 1 : 0;
-                fr.pad[0] = fr.pad[1] = fr.pad[2] = 0;
+                fr.pad[0] = fr.pad[1] = 0;
                 fr.P_out = f < nF ? out.P_out[f] : nullptr;
                 fr.falloff_out = f < nF ? out.falloff_out[f] : nullptr;
                 frames[4 * T + q] = fr;
@@ -905,6 +910,19 @@ __global__ __launch_bounds__(64) void k_pack_shared(const SharedSlots slots, con
     uint4 *dst = wtiles + ((size_t)kb * nT + T) * 128;
     dst[lane] = __builtin_bit_cast(uint4, hi);
     dst[64 + lane] = __builtin_bit_cast(uint4, lo);
+    if (kb == 0) {
+        // polynomial tile of output tile T: k-slot s < 5 of lane group g carries coefficient s
+        // ({C0, Lx, Ly, Lz, q}) of row rho -- hi piece in groups 0 and 1, lo piece in group 2
+        f16x8 pt;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            float w = 0.f;
+            if (f < nF && c < 3 && sidx < 5 && g < 3) w = slots.model[f]->poly32[5 * c + sidx] * sc;
+            const _Float16 h = (_Float16)w;
+            pt[sidx] = g == 2 ? (_Float16)(w - (float)h) : h;
+        }
+        wtiles[(size_t)nkb * nT * 128 + (size_t)T * 64 + lane] = __builtin_bit_cast(uint4, pt);
+    }
 }
 
 // fp32 pair -> its two fp16 pieces, packed: hi = RN16(v), lo = RN16(v - hi).  One v_cvt_pk_f16_f32 and
@@ -922,6 +940,7 @@ __device__ __forceinline__ void split_pair_f16(float v0, float v1, unsigned &hi,
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 // one vertex position as a single 12-byte store (dword-aligned: global_store_dwordx3)
 struct __attribute__((packed, aligned(4))) Pos3 { float x, y, z; };
 __device__ __forceinline__ void store_pos3(Pos3 FD_GLOBAL *dst, float x, float y, float z)
@@ -935,12 +954,14 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 {
     constexpr int TV = 4;                        // vertex tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: [frames NT*4][centre tiles kchunk*2][weight tiles kchunk*NT*2*64 x 16 B]
+    // LDS: [frames NT*4][polynomial tiles NT*64 x 16 B][centre tiles kchunk*2][weight tiles kchunk*NT*2*64 x 16 B]
     SharedFrame *s_frames = reinterpret_cast<SharedFrame *>(smem);
-    MfmaTileH *s_ct = reinterpret_cast<MfmaTileH *>(smem + sizeof(SharedFrame) * (size_t)(NT * 4));
+    uint4 *s_poly = reinterpret_cast<uint4 *>(smem + sizeof(SharedFrame) * (size_t)(NT * 4));
+    MfmaTileH *s_ct = reinterpret_cast<MfmaTileH *>(s_poly + NT * 64);
     uint4 *s_w = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(s_ct) + sizeof(MfmaTileH) * (size_t)(2 * p.kchunk));
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler should know it
     const int g = lane >> 4, j = lane & 15;
     const float n0 = p.model0->norm32[0], n1 = p.model0->norm32[1], n2 = p.model0->norm32[2];
     const float inv_s = p.model0->norm32[3];
@@ -964,55 +985,101 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
         __syncthreads();
     };
 
+    // The frame records (scale, status, output pointers: 8 dwords x 4 NT frames) live across the
+    // lanes of NT / 2 registers for the whole kernel; the epilogue picks a frame's scalars out with
+    // v_readlane -- no memory round trip per frame.  (From LDS every frame paid an LDS read behind
+    // the other wave's operand traffic; through the scalar cache 800 cycles per pair of frames; as
+    // kernel arguments the compiler hoists 32 x 6 scalars above the K loop and spills them.)
+    constexpr int kTabRegs = (NT * 32 + 63) / 64;
+    unsigned tab[kTabRegs];
+#pragma unroll
+    for (int q = 0; q < kTabRegs; ++q) {
+        const int idx = 64 * q + lane;
+        tab[q] = idx < NT * 32 ? reinterpret_cast<const unsigned *>(p.frames)[idx] : 0u;
+    }
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.frames);
         uint4 *dst = reinterpret_cast<uint4 *>(s_frames);
         for (int q = tid; q < NT * 4 * (int)(sizeof(SharedFrame) / 16); q += kSharedThreads) dst[q] = src[q];
+        const uint4 *psrc = p.wtiles + (size_t)p.nkb * NT * 128;
+        for (int q = tid; q < NT * 64; q += kSharedThreads) s_poly[q] = psrc[q];
     }
     if (resident) {
         stage(0, p.nkb);
         // The two waves of a SIMD (w and w + 4) run the same program: left alone they reach their
         // logarithm phase together and their matrix phase together, and each phase then has one
-        // pipe idle.  Half a K block of delay for the second half puts one wave's vector work
-        // beside the other's matrix work (no barrier follows while the model is resident).
-        // The same goes for the epilogue, where a wave issues 96 stores and waits on the memory
-        // pipeline: with all eight waves there at once the matrix pipe idles for the whole burst.
-        // A start-up delay of about half a vertex group for waves 4..7 keeps one wave of every SIMD
-        // in its K loop while the other stores.
+        // pipe idle.  A start-up delay for the second half puts one wave's vector work beside
+        // the other's matrix work (no barrier follows while the model is resident).
         if (wave >= 4) {
             __builtin_amdgcn_s_sleep(12);
             for (int q = 0; q < p.stagger; ++q) __builtin_amdgcn_s_sleep(127);
         }
+    } else {
+        __syncthreads();
     }
 
+    const bool stamp = p.stamps != nullptr && blockIdx.x == 0;
+    unsigned long long st_prev = 0, st_acc[5] = {0, 0, 0, 0, 0};
+#define FD_SSTAMP(K) if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[K] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+    if (stamp) st_prev = __builtin_amdgcn_s_memtime();
+    // Inputs of a vertex group as lane (g, j) holds them: the four vertices (vt, j).  The NEXT group's
+    // are requested before this group's stores go out: vector memory operations of a wave retire in
+    // issue order, so a load queued behind the epilogue's 64 stores would wait for all of them.
+    struct GroupRaw { float p[TV][3]; float d2[TV]; };
+    auto load_raw = [&](int grp_) {
+        GroupRaw r;
+        const int64_t vb = ((int64_t)grp_ * (kSharedThreads / 64) + wave) * (16 * TV);
+#pragma unroll
+        for (int t = 0; t < TV; ++t) {
+            const int64_t vi = vb + 16 * t + j;
+            const int64_t vc = vi < p.N ? vi : p.N - 1;
+            r.p[t][0] = p.P_in[3 * vc]; r.p[t][1] = p.P_in[3 * vc + 1]; r.p[t][2] = p.P_in[3 * vc + 2];
+            r.d2[t] = p.dist2 ? p.dist2[vc] : 0.f;
+        }
+        return r;
+    };
+    GroupRaw nxt = load_raw(blockIdx.x < (unsigned)ngroups ? (int)blockIdx.x : 0);
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int64_t vbase = ((int64_t)grp * (kSharedThreads / 64) + wave) * (16 * TV);
+        const GroupRaw cur = nxt;
+        // this lane's own vertex in the epilogue is (vt = g, j): one of the four it has loaded
+        const float pos[3] = {g == 0 ? cur.p[0][0] : (g == 1 ? cur.p[1][0] : (g == 2 ? cur.p[2][0] : cur.p[3][0])),
+                              g == 0 ? cur.p[0][1] : (g == 1 ? cur.p[1][1] : (g == 2 ? cur.p[2][1] : cur.p[3][1])),
+                              g == 0 ? cur.p[0][2] : (g == 1 ? cur.p[1][2] : (g == 2 ? cur.p[2][2] : cur.p[3][2]))};
+        const float own_d2 = g == 0 ? cur.d2[0] : (g == 1 ? cur.d2[1] : (g == 2 ? cur.d2[2] : cur.d2[3]));
         // every lane group holds vertex (vt, j): the d2 operand needs one coordinate of it per lane
-        // group; the epilogue (frame 4 T + g of that vertex) re-reads the position
-        float d2v[TV];
+        // group, the polynomial operand all of them
         f16x4 bop[TV];
+        f32x4 acc[NT][TV];
         bool lane_live = false;
 #pragma unroll
         for (int t = 0; t < TV; ++t) {
             const int64_t vi = vbase + 16 * t + j;
-            const int64_t vc = vi < p.N ? vi : p.N - 1;
-            const float x = (p.P_in[3 * vc] - n0) * inv_s, y = (p.P_in[3 * vc + 1] - n1) * inv_s, z = (p.P_in[3 * vc + 2] - n2) * inv_s;
-            d2v[t] = p.dist2 ? p.dist2[vc] : 0.f;
-            lane_live |= (vi < p.N) && !(d2v[t] > p.radius2);
+            const float x = (cur.p[t][0] - n0) * inv_s, y = (cur.p[t][1] - n1) * inv_s, z = (cur.p[t][2] - n2) * inv_s;
+            const float d2v = cur.d2[t];
+            lane_live |= (vi < p.N) && !(d2v > p.radius2);
             const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
             const float v2 = g == 0 ? -2.f * x : (g == 1 ? -2.f * y : (g == 2 ? -2.f * z : xx));
             const _Float16 h = (_Float16)v2;
             const _Float16 l = (_Float16)(v2 - (float)h);
             const _Float16 one = (_Float16)1.0f;
             bop[t] = g < 3 ? (f16x4){h, l, h, l} : (f16x4){one, one, h, l};
+            // polynomial operand: k-slots {1, x', y', z', |x'|^2}: hi pieces in lane groups 0 and 2,
+            // lo pieces in group 1 (against the coefficients' hi), nothing in group 3
+            unsigned xyh, xyl, zxh, zxl;
+            split_pair_f16(x, y, xyh, xyl);
+            split_pair_f16(z, xx, zxh, zxl);
+            u32x4 pb;
+            if (g == 1) pb = (u32x4){xyl << 16, (xyl >> 16) | (zxl << 16), zxl >> 16, 0u};                  // {0, xl, yl, zl, xxl}
+            else pb = (u32x4){0x3c00u | (xyh << 16), (xyh >> 16) | (zxh << 16), zxh >> 16, 0u};            // {1, xh, yh, zh, xxh}
+            if (g == 3) pb = (u32x4){0u, 0u, 0u, 0u};
+            const f16x8 pbv = __builtin_bit_cast(f16x8, pb);
+#pragma unroll
+            for (int T = 0; T < NT; ++T)
+                acc[T][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s_poly[T * 64 + lane]), pbv, zero4, 0, 0, 0);
         }
         const bool wave_work = __any(lane_live);
-
-        f32x4 acc[NT][TV];
-#pragma unroll
-        for (int T = 0; T < NT; ++T)
-#pragma unroll
-            for (int t = 0; t < TV; ++t) acc[T][t] = zero4;
+        FD_SSTAMP(0)
 
         for (int kb0 = 0; kb0 < p.nkb; kb0 += p.kchunk) {
             const int nk = p.nkb - kb0 < p.kchunk ? p.nkb - kb0 : p.kchunk;
@@ -1055,16 +1122,14 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
             }
         }
 
+        FD_SSTAMP(1)
         // ---- epilogue.  The accumulators hold, in lane group g, frame 4 T + g for the four vertex
         // tiles; a 4 x 4 transpose across the lane groups (two v_permlane32_swap + two
         // v_permlane16_swap per four registers) turns that into vertex tile g for the four frames
         // of the tile: every lane then owns ONE vertex (vbase + lane), does the per-vertex work
         // (gate, fall-off, tangent axes) once, and a frame's 64 positions leave as one contiguous
-        // 768-byte store.  The reference's order: gate -> tangent projection -> fall-off -> add
-        // (src/SOP_FaceDeform.cpp:405-438).
-        // All transposes first, in place (acc[T][k][c] becomes frame 4 T + k, component c, of this
-        // lane's vertex), while the wave is still converged: the lane-crossing instructions sit
-        // in straight-line code behind the K loop, not between the divergent blocks that follow.
+        // 768-byte store.  All transposes first, in place (acc[T][k][c] becomes frame 4 T + k,
+        // component c, of this lane's vertex), while the wave is still converged.
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
 #pragma unroll
@@ -1078,79 +1143,93 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
                 acc[T][2][c] = __uint_as_float(y23[0]); acc[T][3][c] = __uint_as_float(y23[1]);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        // the reference's order: gate -> tangent projection -> fall-off -> add (src/SOP_FaceDeform.cpp:405-438)
         const int64_t i = vbase + lane;
         const bool inb = i < p.N;
         const int64_t ic = inb ? i : p.N - 1;
-        const float pos[3] = {p.P_in[3 * ic], p.P_in[3 * ic + 1], p.P_in[3 * ic + 2]};
-        const float own_d2 = p.dist2 ? p.dist2[ic] : 0.f;
-        const float x = (pos[0] - n0) * inv_s, y = (pos[1] - n1) * inv_s, z = (pos[2] - n2) * inv_s;
-        const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
         const bool gated = own_d2 > p.radius2;
-        float fall = 1.f;
-        if (!gated && (p.dist2 != nullptr || !(p.radius2 != 0.f))) {
-            const float q = fminf(own_d2 / p.radius2, 1.f);
-            fall = powf(1.f - q, p.falloffrate);
+        const unsigned off12 = 12u * (unsigned)lane, off4 = 4u * (unsigned)lane;   // byte offsets inside the wave's 64-vertex window
+        {
+            const int gn = grp + (int)gridDim.x;
+            nxt = load_raw(gn < ngroups ? gn : grp);
         }
-        float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
-        if (p.tu && !gated) {
-            // project_to_tangents (src/SOP_FaceDeform.hpp:28-41): the two axes depend on the vertex only
-            float u[3] = {p.tu[3 * ic], p.tu[3 * ic + 1], p.tu[3 * ic + 2]};
-            float v[3] = {p.tv[3 * ic], p.tv[3 * ic + 1], p.tv[3 * ic + 2]};
-            float n[3] = {p.nrm[3 * ic], p.nrm[3 * ic + 1], p.nrm[3 * ic + 2]};
-            normalize3(u[0], u[1], u[2]);
-            normalize3(v[0], v[1], v[2]);
-            normalize3(n[0], n[1], n[2]);
-            float gm[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) gm[r][c] = u[r] * u[c] + v[r] * v[c] + n[r] * n[c];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                a1[c] = u[0] * gm[0][c] + u[1] * gm[1][c] + u[2] * gm[2][c];
-                a2[c] = v[0] * gm[0][c] + v[1] * gm[1][c] + v[2] * gm[2][c];
+        FD_SSTAMP(2)
+        if (inb && gated) {
+            // B2: a gated vertex keeps its position (and no fd_falloff entry is written)
+            for (int f = 0; f < p.nF; ++f) {
+                float *dstp = s_frames[f].P_out;
+                if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
             }
-            normalize3(a1[0], a1[1], a1[2]);
-            normalize3(a2[0], a2[1], a2[2]);
+        }
+        float fall = 1.f;
+        float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+        const bool doit = inb && !gated;
+        if (doit) {
+            if (p.dist2 != nullptr || !(p.radius2 != 0.f)) {
+                const float q = fminf(own_d2 / p.radius2, 1.f);
+                fall = powf(1.f - q, p.falloffrate);
+            }
+            if (p.tu) {
+                // project_to_tangents (src/SOP_FaceDeform.hpp:28-41): the two axes depend on the vertex only
+                float u[3] = {p.tu[3 * ic], p.tu[3 * ic + 1], p.tu[3 * ic + 2]};
+                float v[3] = {p.tv[3 * ic], p.tv[3 * ic + 1], p.tv[3 * ic + 2]};
+                float n[3] = {p.nrm[3 * ic], p.nrm[3 * ic + 1], p.nrm[3 * ic + 2]};
+                normalize3(u[0], u[1], u[2]);
+                normalize3(v[0], v[1], v[2]);
+                normalize3(n[0], n[1], n[2]);
+                float gm[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gm[r][c] = u[r] * u[c] + v[r] * v[c] + n[r] * n[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    a1[c] = u[0] * gm[0][c] + u[1] * gm[1][c] + u[2] * gm[2][c];
+                    a2[c] = v[0] * gm[0][c] + v[1] * gm[1][c] + v[2] * gm[2][c];
+                }
+                normalize3(a1[0], a1[1], a1[2]);
+                normalize3(a2[0], a2[1], a2[2]);
+            }
         }
 #pragma unroll
         for (int T = 0; T < NT; ++T) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int f = 4 * T + k;             // wave-uniform
-                if (f >= p.nF || !inb) continue;
-                // the record is read per lane (one LDS address for all: a broadcast).  Left to the
-                // compiler, 32 unrolled frames x 21 wave-uniform scalars are hoisted into SGPRs and spilled.
-                int fidx = f;
-                asm volatile("" : "+v"(fidx));
-                const SharedFrame &fr = s_frames[fidx];
-                // (pointers that come out of memory are generic to the compiler: say that they are global)
-                Pos3 FD_GLOBAL *Pout = (Pos3 FD_GLOBAL *)as_global(fr.P_out) + i;
-                float FD_GLOBAL *Fout = as_global(fr.falloff_out);
-                if (gated || !fr.built) {
-                    if (fr.P_out != p.P_in) store_pos3(Pout, pos[0], pos[1], pos[2]);
+                if (f >= p.nF) continue;
+                // word w of frame f sits in lane (8 f + w) % 64 of tab[(8 f + w) / 64]
+                const float inv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f) / 64], (8 * f) % 64));
+                const bool built = __builtin_amdgcn_readlane((int)tab[(8 * f + 1) / 64], (8 * f + 1) % 64) != 0;
+                const uint64_t pout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 5) / 64], (8 * f + 5) % 64) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 4) / 64], (8 * f + 4) % 64);
+                const uint64_t fout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 7) / 64], (8 * f + 7) % 64) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 6) / 64], (8 * f + 6) % 64);
+                if (!doit) continue;
+                // scalar base (the wave's window of the frame's arrays) + a 32-bit lane offset
+                Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)((char FD_GLOBAL *)(pout + 12ull * (uint64_t)vbase) + off12);
+                if (!built) {
+                    if (pout != (uint64_t)p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
                     continue;
                 }
-                float disp[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float poly = __builtin_fmaf(fr.poly[5 * c + 4], xx, __builtin_fmaf(fr.poly[5 * c + 3], z,
-                                         __builtin_fmaf(fr.poly[5 * c + 2], y, __builtin_fmaf(fr.poly[5 * c + 1], x, fr.poly[5 * c]))));
-                    disp[c] = __builtin_fmaf(acc[T][k][c], fr.inv_scale, poly);
-                }
-                if ((p.dbg & 1) && disp[0] + disp[1] + disp[2] == disp[0] + disp[1] + disp[2]) continue;
+                // 2^-k is exact: disp is the sum the matrix pipe accumulated, polynomial included
+                float disp[3] = {acc[T][k][0] * inv, acc[T][k][1] * inv, acc[T][k][2] * inv};
+                if (p.dbg & 1) continue;         // diagnostics: everything but the stores
                 if (p.tu) {
                     const float da1 = disp[0] * a1[0] + disp[1] * a1[1] + disp[2] * a1[2];
                     const float da2 = disp[0] * a2[0] + disp[1] * a2[1] + disp[2] * a2[2];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
                 }
-                if (fr.falloff_out) Fout[i] = fall;
-                store_pos3(Pout, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+                if (fout) *(float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4) = fall;
+                store_pos3(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
             }
         }
+        FD_SSTAMP(3)
     }
+    if (stamp && lane == 0) {
+        for (int q = 0; q < 4; ++q) p.stamps[wave * 8 + q] = st_acc[q];
+    }
+#undef FD_SSTAMP
 }
 
 template <int KIND>
@@ -1367,8 +1446,12 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     p.ctiles = a.ctiles; p.model0 = a.model[0];
     p.wtiles = (const uint4 *)a.wtiles; p.frames = (const SharedFrame *)a.frames;
     { static const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
-    { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 3; }
-    const size_t fixed = sizeof(SharedFrame) * (size_t)(nT * 4);
+    { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+    static unsigned long long *d_stamps = nullptr;
+    static const bool want_stamps = getenv("FD_SHARED_STAMPS") != nullptr;
+    if (want_stamps && !d_stamps) (void)hipMalloc((void **)&d_stamps, 64 * sizeof(unsigned long long));
+    p.stamps = want_stamps ? d_stamps : nullptr;
+    const size_t fixed = sizeof(SharedFrame) * (size_t)(nT * 4) + (size_t)nT * 64 * 16;
     const size_t per_kb = 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
     int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);
     if (kchunk < 1) return hipErrorInvalidValue;
@@ -1396,13 +1479,21 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     default: return hipErrorInvalidValue;
     }
 #undef FD_SHARED_CASE
+    if (want_stamps && d_stamps) {
+        unsigned long long h[64];
+        if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[shared stamps, shader cycles per wave of workgroup 0: load+poly | K loop | transposes | per-vertex + frames]\n");
+            for (int w = 0; w < 8; ++w)
+                fprintf(stderr, "   wave %d: %8llu %8llu %8llu %8llu\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3]);
+        }
+    }
     return hipGetLastError();
 }
 
 size_t shared_wtile_bytes(int Mpad, int nF)
 {
     const int nkb = (Mpad / 16 + 1) / 2, nT = (nF + kSharedFramesPerTile - 1) / kSharedFramesPerTile;
-    return (size_t)nkb * nT * 128 * 16;
+    return (size_t)nkb * nT * 128 * 16 + (size_t)nT * 64 * 16;      // weight tiles + polynomial tiles
 }
 size_t shared_frame_bytes(int nF)
 {
