@@ -42,6 +42,7 @@ CONFIGS = {
 }
 METRIC = "deformed Mverts/sec at 256 ctrl pts, 1/2/4/8 MI355X vs host-CPU ref"
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA dense peak
+PEAK_FP16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
 FLOPS_PER_PAIR = 17        # thin-plate: SURVEY.md 8d
 FLOPS_PER_VERTEX_AFFINE = 24
@@ -63,8 +64,14 @@ def parse_args():
                     help="groups of frames in flight per GPU (one stream + one fd_batch each)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="evaluations per HIP event pair (a pair costs ~4-5 us of stream time, spread over the run)")
-    ap.add_argument("--eval-launch", choices=["batched", "single"], default="batched",
-                    help="evaluate the frames of a group with one launch (fd_batch_deform_dev) or one launch per frame")
+    ap.add_argument("--eval-launch", choices=["shared", "batched", "single"], default="shared",
+                    help="shared: the frames of a group share the mesh and the rest rig (they do, in every BASELINE "
+                         "configuration): phi once per (vertex, centre), weight contraction on the matrix pipe "
+                         "(fd_batch_deform_shared_dev); batched: one launch, every frame evaluated on its own "
+                         "(fd_batch_deform_dev); single: one launch per frame")
+    ap.add_argument("--eval-cus", type=int, default=0,
+                    help="shared evaluation: CUs it occupies (one persistent workgroup each); the rest stay free for the "
+                         "builds of the next group (0 = all 256)")
     ap.add_argument("--c5-solve", choices=["broadcast", "redundant"], default="broadcast",
                     help="config c5: rank 0 solves and broadcasts the models (default), or every rank solves them itself")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
@@ -324,6 +331,8 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
+    if args.eval_cus > 0:
+        os.environ["FD_SHARED_CUS"] = str(args.eval_cus)       # read once by the library at its first shared launch
     import torch
     import torch.distributed as dist
     from facedeform_amd import capi, synth
@@ -394,7 +403,8 @@ def main():
 
     delta_stride = n_ctrl * 3 * 4
     ev_runs, ev_run_ends = {}, {}      # first step of a timed run -> its length; last step -> first step
-    batched_eval = args.eval_launch == "batched" and B > 1
+    shared_eval = args.eval_launch == "shared" and B > 1
+    batched_eval = (args.eval_launch == "batched" and B > 1) or shared_eval
 
     def group(g, first, count, ev=None):
         """Cook steps first .. first+count-1 (count <= B frames) on lane g % n_lanes."""
@@ -422,8 +432,12 @@ def main():
             es.wait_event(ln["built"])
             if ev:
                 ev[first][2].record(es)
-            batch.deform_dev(n_verts, [d_P.data_ptr()] * count, [o.data_ptr() for o in ln["out"][:count]],
-                             d_falloff=[f.data_ptr() for f in ln["fall"][:count]], stream_ptr=es.cuda_stream)
+            if shared_eval:
+                batch.deform_shared_dev(n_verts, d_P.data_ptr(), [o.data_ptr() for o in ln["out"][:count]],
+                                        d_falloff=[f.data_ptr() for f in ln["fall"][:count]], stream_ptr=es.cuda_stream)
+            else:
+                batch.deform_dev(n_verts, [d_P.data_ptr()] * count, [o.data_ptr() for o in ln["out"][:count]],
+                                 d_falloff=[f.data_ptr() for f in ln["fall"][:count]], stream_ptr=es.cuda_stream)
             if ev:
                 ev[first][3].record(es)
             ln["evals_done"].record(es)
@@ -553,6 +567,51 @@ def main():
                 traffic = tj.get("hbm_bytes_per_frame", tj.get("hbm_bytes_per_launch")) * frames_per_launch
             except Exception:
                 traffic = None
+        mfma_eval = precision == capi.EVAL_FP32 and n_ctrl >= 49
+        use_shared = shared_eval and mfma_eval and n_ctrl >= 32
+        if use_shared:
+            # Frames of a launch share the mesh and the rest rig: phi is formed once per (vertex, centre)
+            # and contracted with the 3 F weight columns on the matrix pipe.  Algorithmic work of the
+            # launch: per pair 8 flop once (d2: 5, d2 log d2: 3) + 6 flop per frame;
+            # per vertex 24 flop of polynomial per frame; bytes: P read once, P + fd_falloff written per frame.
+            Fl = frames_per_launch
+            flops_launch = ((8 + 6 * Fl) * n_ctrl + FLOPS_PER_VERTEX_AFFINE * Fl) * n_verts
+            bytes_launch = (12 + 16 * Fl) * n_verts
+            kern = "k_deform32_tps_shared"
+            # executed on the matrix pipe: 3 split products x 16/12 (one unused row in four) of the contraction
+            mfma_exec = (3 * 2 * 4 * n_ctrl * Fl + 2 * 16 * n_ctrl) * n_verts        # flop, fp16 MFMA
+            roof = {
+                # Binding pipe: the matrix pipe (PMC: busy ~53 % of the kernel, profiles/r02_pmc_shared_c2.txt);
+                # HBM (outputs) is the second roof, reported beside it.  Peak: dense fp16 MFMA, 2.5 PFLOP/s.
+                "bound": "mfma", "kernel": kern,
+                "achieved": flops_launch / (launch_ms * 1e-3) / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops_launch / (launch_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic,
+                "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms, "frames_per_launch": Fl,
+                "note": "algorithmic flops; the pipe executes 4x the contraction (fp16 x 2 split: three products; "
+                        "one row in four of an output tile unused)",
+                "executed_mfma": {"achieved": mfma_exec / (launch_ms * 1e-3) / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": mfma_exec / (launch_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS},
+                "hbm": {"achieved": bytes_launch / (launch_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": bytes_launch / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": bytes_launch},
+            }
+        else:
+            roof = {
+                # the one-frame kernels are compute-bound at this M (intensity ~182 flop/B vs ridge ~20) and
+                # their binding pipe is the fp32 VECTOR unit (logarithm + weight contraction), not the
+                # matrix pipe, which only forms the squared distances: PMC in profiles/ (VALU active
+                # ~90-100 % of busy cycles, MFMA pipe busy 13-17 %).  Roof: 157.3 TFLOP/s fp32 vector.
+                "bound": "valu_fp32",
+                "kernel": ("k_deform32_tps_mfma_batch" if frames_per_launch > 1 else "k_deform32_tps_mfma")
+                          if mfma_eval else ("k_deform32" if precision == capi.EVAL_FP32 else "k_deform64"),
+                "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
+                # a launch evaluates frames_per_launch frames (algorithmic flops per frame x frames)
+                "flops_per_launch": flops * frames_per_launch, "avg_launch_ms": launch_ms,
+                "frames_per_launch": frames_per_launch,
+                "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": achieved_gbs / PEAK_HBM_GBS,
+                        "bytes_per_launch": BYTES_PER_VERTEX * n_verts * frames_per_launch},
+            }
         line = {
             "metric": METRIC,
             "value": total_verts / elapsed / 1e6,
@@ -568,34 +627,22 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{desc}, thin-plate kernel, linear term, {args.precision} evaluation"
-                            + (" (squared distances on the matrix pipe from fp16 x 2 split operands, 22 bits; fp32 "
-                               "logarithm, weights and accumulation)" if (precision == capi.EVAL_FP32 and n_ctrl >= 49) else "")
-                            + ", fp64 dense solve rebuilt every step (assemble + direct solve + evaluate), one frame per step",
+                            + (" (squared distances on the matrix pipe from fp16 x 2 split operands, 22 bits; fp32 logarithm"
+                               + ("; the frames of a group share the mesh and the rest rig, so d2 log d2 is formed once per "
+                                  "(vertex, centre) and contracted with every frame's weights on the matrix pipe, fp16 x 2 split "
+                                  "operands, fp32 accumulation)" if use_shared else "; fp32 weights and accumulation)") if mfma_eval else "")
+                            + ", every frame's model assembled and solved on its own in fp64, every step (as the reference rebuilds "
+                              "its model every cook), one frame per step",
                 "n_verts": n_verts, "n_ctrl": n_ctrl,
                 "frames_per_batched_build": B, "frames_per_evaluation_launch": frames_per_launch,
+                "evaluation": args.eval_launch if B > 1 else "single",
+                "evaluation_cus": args.eval_cus or 256,
                 "lanes_per_gpu": n_lanes,
                 "parallelism": f"independent frames: {world} GPU(s) x {n_lanes} lanes x {B} frames per batched "
                                "build and per evaluation launch (one build stream per lane, one evaluation "
                                "stream), no collective",
             },
-            "roofline": {
-                # the evaluation kernel is compute-bound at this M (intensity ~182 flop/B vs ridge ~20) and
-                # its binding pipe is the fp32 VECTOR unit (logarithm + weight contraction), not the
-                # matrix pipe, which only forms the squared distances: PMC in profiles/ (VALU active
-                # ~90-100 % of busy cycles, MFMA pipe busy 13-17 %).  Roof: 157.3 TFLOP/s fp32 vector.
-                "bound": "valu_fp32",
-                "kernel": ("k_deform32_tps_mfma_batch" if frames_per_launch > 1 else "k_deform32_tps_mfma")
-                          if (precision == capi.EVAL_FP32 and n_ctrl >= 49) else
-                          ("k_deform32" if precision == capi.EVAL_FP32 else "k_deform64"),
-                "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                # a launch evaluates frames_per_launch frames (algorithmic flops per frame x frames)
-                "flops_per_launch": flops * frames_per_launch, "avg_launch_ms": launch_ms,
-                "frames_per_launch": frames_per_launch,
-                "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": achieved_gbs / PEAK_HBM_GBS,
-                        "bytes_per_launch": BYTES_PER_VERTEX * n_verts * frames_per_launch},
-            },
+            "roofline": roof,
             "ranks": ranks,
             "phases_ms": {"build_per_frame_batched": build_ms, "build_batch": build_group_ms,
                           "evaluate": eval_ms, "single_cook_latency": latency_ms},

@@ -1460,7 +1460,15 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     const size_t lds = fixed + per_kb * (size_t)kchunk;
     const int64_t per = kSharedThreads / 64 * 64;          // vertices per workgroup and group
     const int64_t ngroups = (a.N + per - 1) / per;
-    const unsigned grid = (unsigned)(ngroups < (int64_t)kNumCU ? ngroups : (int64_t)kNumCU);
+    // One persistent workgroup per CU (150 KiB of LDS, two 240-register waves per SIMD: nothing else
+    // fits beside it).  FD_SHARED_CUS < 256 leaves the other CUs to whatever runs on other streams --
+    // the builds of the next frames in a pipeline (bench.py).
+    static const int64_t max_wgs = [] {
+        const char *e = getenv("FD_SHARED_CUS");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v > 0 && v < (long)kNumCU ? v : (long)kNumCU);
+    }();
+    const unsigned grid = (unsigned)(ngroups < max_wgs ? ngroups : max_wgs);
 #define FD_SHARED_CASE(NTV)                                                                                          \
     case NTV: {                                                                                                      \
         static bool attr_set = false;                                                                                \
