@@ -64,6 +64,16 @@ struct fd_ctx {
     struct fd_batch *wait_batch = nullptr;
     hipEvent_t tev0 = nullptr, tev_mid = nullptr, tev1 = nullptr;   // events the report's timings come from
     ModelHeader *h_header = nullptr;  // pinned, for device-side export
+    // Asynchronous status: after every enqueued build a one-thread kernel drops the model's
+    // terminationtype into this page-locked word and status_ev is recorded behind it.  Every later
+    // call on the context polls the event (no wait): a Cholesky that lost definiteness is then
+    // rebuilt with the LU right away, on the stream, before whatever the call enqueues; a failure
+    // the LU confirms becomes a sticky error that fd_deform* returns until the next set-up call.
+    int *h_status = nullptr;
+    hipEvent_t status_ev = nullptr;
+    hipEvent_t status_poll = nullptr;   // the event that says h_status is in: status_ev, or the one of the batch that built the model
+    bool status_inflight = false;
+    int sticky_rc = FD_OK;
 
     // staging for the host-pointer deform
     int64_t cap_N = 0;
@@ -111,6 +121,7 @@ struct fd_batch {
     // a stream that already waits for the current build (set by the first evaluation that
     // needed it): the other contexts' evaluations on that stream need no wait of their own
     hipStream_t waited_stream = nullptr;
+    hipEvent_t status_ev = nullptr;     // behind the kernel that posts every context's status after a batched build
     // scratch of the shared-rig evaluation (fd_batch_deform_shared_dev): weight tiles + frame records
     void *d_wtiles = nullptr, *d_frames = nullptr;
     size_t cap_wtiles = 0, cap_frames = 0;
@@ -284,6 +295,28 @@ static int order_after_batch(fd_ctx *ctx, hipStream_t s)
     return FD_OK;
 }
 
+// the model's status into page-locked host memory (one thread; the build's last kernel wrote it)
+__global__ void k_post_status(const DevModel *model, int *host_word) { *host_word = model->terminationtype; }
+struct StatusTable { const DevModel *model[kMaxBatch]; int *host_word[kMaxBatch]; };
+__global__ void k_post_status_batch(const StatusTable t, int n)
+{
+    const int i = threadIdx.x;
+    if (i < n) *t.host_word[i] = t.model[i]->terminationtype;
+}
+
+static int post_status(fd_ctx *ctx, hipStream_t s)
+{
+    int *dword = nullptr;
+    if (hipHostGetDevicePointer((void **)&dword, ctx->h_status, 0) != hipSuccess) { (void)hipGetLastError(); return FD_OK; }
+    hipLaunchKernelGGL(k_post_status, dim3(1), dim3(1), 0, s, ctx->d_model, dword);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(ctx->status_ev, s) != hipSuccess) { (void)hipGetLastError(); return FD_OK; }
+    ctx->status_poll = ctx->status_ev;
+    ctx->status_inflight = true;
+    return FD_OK;
+}
+
+static int poll_status(fd_ctx *ctx);
+
 extern "C" {
 
 int fd_abi_version(void) { return FD_ABI_VERSION; }
@@ -333,6 +366,8 @@ fd_ctx *fd_create(const fd_config *cfg)
     ok = ok && hipMalloc((void **)&ctx->d_slot, sizeof(BatchSlot)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_model, sizeof(DevModel), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_header, sizeof(ModelHeader), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&ctx->h_status, sizeof(int), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->status_ev, hipEventDisableTiming) == hipSuccess;
     if (ok) ok = hipMemset(ctx->d_model, 0, sizeof(DevModel)) == hipSuccess;
     if (!ok) {
         set_err(nullptr, "fd_create: device resource allocation failed: %s",
@@ -357,6 +392,8 @@ void fd_destroy(fd_ctx *ctx)
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (ctx->h_model) (void)hipHostFree(ctx->h_model);
     if (ctx->h_header) (void)hipHostFree(ctx->h_header);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    if (ctx->status_ev) (void)hipEventDestroy(ctx->status_ev);
     if (ctx->build_exec) (void)hipGraphExecDestroy(ctx->build_exec);
     if (ctx->resolve_exec) (void)hipGraphExecDestroy(ctx->resolve_exec);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -402,6 +439,7 @@ static int set_points_common(fd_ctx *ctx, const float *rest, const float *delta,
     if (M != ctx->M) ctx->prefer_lu = false;
     ctx->M = M;
     ctx->rest_src = nullptr;
+    ctx->sticky_rc = FD_OK; ctx->status_inflight = false;
     ctx->points_set = true;
     ctx->built = false;
     ctx->build_pending = false;
@@ -434,6 +472,7 @@ static int set_deltas_common(fd_ctx *ctx, const float *delta, int M, bool on_dev
     ctx->deltas_only = true;
     ctx->built = false;
     ctx->build_pending = false;
+    ctx->sticky_rc = FD_OK; ctx->status_inflight = false;
     return FD_OK;
 }
 
@@ -592,7 +631,8 @@ int fd_build_async(fd_ctx *ctx)
         ctx->build_pending = true;
         ctx->built = false;
         ctx->have_report = false;
-        return FD_OK;
+        ctx->sticky_rc = FD_OK;
+        return post_status(ctx, st);
     }
     if (make_lookahead(&ctx->lu_stream, ctx->lu_events)) {
         b.aux_stream = ctx->lu_stream;
@@ -645,7 +685,8 @@ int fd_build_async(fd_ctx *ctx)
     ctx->build_pending = true;
     ctx->built = false;
     ctx->have_report = false;
-    return FD_OK;
+    ctx->sticky_rc = FD_OK;
+    return post_status(ctx, cur_stream(ctx));
 }
 
 int fd_build_result(fd_ctx *ctx, fd_report *report)
@@ -657,6 +698,7 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
         if ((rc = order_after_batch(ctx, cur_stream(ctx)))) return rc;
         FD_HIP(ctx, hipMemcpyAsync(ctx->h_model, ctx->d_model, sizeof(DevModel), hipMemcpyDeviceToHost, cur_stream(ctx)));
         FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+        ctx->status_inflight = false;
         ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;   // the batched build it named is complete
         fd_report r{};
         r.terminationtype = ctx->h_model->terminationtype;
@@ -703,6 +745,42 @@ int fd_build(fd_ctx *ctx, fd_report *report)
     return fd_build_result(ctx, report);
 }
 
+}  // extern "C"
+
+// Non-blocking look at the status the last enqueued build posted (see fd_ctx::h_status).
+static int poll_status(fd_ctx *ctx)
+{
+    if (ctx->sticky_rc != FD_OK) {
+        set_err(ctx, ctx->sticky_rc == FD_E_DUPLICATE ? "the model's build failed: coincident control points"
+                                                      : "the model's build failed: singular system");
+        return ctx->sticky_rc;
+    }
+    if (!ctx->status_inflight) return FD_OK;
+    const hipError_t q = hipEventQuery(ctx->status_poll);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return FD_OK; }     // not known yet: nothing to act on
+    ctx->status_inflight = false;
+    if (q != hipSuccess) { (void)hipGetLastError(); return FD_OK; }
+    const int tt = *ctx->h_status;
+    if (tt == 1 || tt == 0) return FD_OK;
+    if (tt == -4 && ctx->last_spd && ctx->points_set) {
+        // the Cholesky lost definiteness on this rig (header: FD_SOLVER_AUTO): the LU now, enqueued on
+        // the context's stream ahead of whatever the caller is about to enqueue
+        ctx->prefer_lu = true;
+        ctx->have_factor = false;
+        ctx->deltas_only = false;
+        // rare path: evaluations of the failed model enqueued earlier (pass-throughs) may still be reading
+        // its buffers on streams this context knows nothing about
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
+        return fd_build_async(ctx);
+    }
+    ctx->sticky_rc = tt == -5 ? FD_E_DUPLICATE : FD_E_SINGULAR;
+    set_err(ctx, tt == -5 ? "the model's build failed: coincident control points" : "the model's build failed: singular system");
+    return ctx->sticky_rc;
+}
+
+extern "C" {
+
 int fd_deform_dev(fd_ctx *ctx, int64_t N, const float *d_P_in, float *d_P_out, const float *d_dist2,
                   float *d_falloff_out, const float *d_tu, const float *d_tv, const float *d_nrm,
                   float radius2, float falloffrate)
@@ -725,6 +803,7 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
     if (N == 0) return FD_OK;
     int rc = use_device(ctx);
     if (rc) return rc;
+    if ((rc = poll_status(ctx))) return rc;           // a failed asynchronous build: repaired here, or reported
     DeformArgs a;
     a.N = N;
     a.P_in = d_P_in; a.P_out = d_P_out;
@@ -1216,6 +1295,7 @@ fd_batch *fd_batch_create(fd_ctx *const *ctxs, int n)
     ok = ok && hipMalloc((void **)&b->d_slots, sizeof(BatchSlot) * (size_t)n) == hipSuccess;
     ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev_mid) == hipSuccess &&
          hipEventCreate(&b->ev1) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&b->status_ev, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         set_err(nullptr, "fd_batch_create: device resource allocation failed: %s", hipGetErrorString(hipGetLastError()));
         fd_batch_destroy(b);
@@ -1236,7 +1316,9 @@ void fd_batch_destroy(fd_batch *b)
             c->wait_event = nullptr; c->wait_stream = nullptr; c->wait_batch = nullptr;
         }
         if (c && c->tev0 == b->ev0) { c->tev0 = c->ev0; c->tev_mid = c->ev_mid; c->tev1 = c->ev1; }
+        if (c && c->status_poll == b->status_ev) { c->status_poll = c->status_ev; c->status_inflight = false; }
     }
+    if (b->status_ev) (void)hipEventDestroy(b->status_ev);
     if (b->exec) (void)hipGraphExecDestroy(b->exec);
     for (hipEvent_t e : b->lu_events) if (e) (void)hipEventDestroy(e);
     if (b->lu_stream) (void)hipStreamDestroy(b->lu_stream);
@@ -1376,6 +1458,44 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         c->build_pending = true;
         c->built = false;
         c->have_report = false;
+        c->sticky_rc = FD_OK;
+    }
+    // the statuses of all contexts: one launch, one event (recorded on every context's own event
+    // object would cost a stream operation each)
+    {
+        StatusTable st{};
+        bool ok = true;
+        for (int i = 0; i < b->n && ok; ++i) {
+            st.model[i] = b->ctxs[i]->d_model;
+            int *dword = nullptr;
+            ok = hipHostGetDevicePointer((void **)&dword, b->ctxs[i]->h_status, 0) == hipSuccess;
+            st.host_word[i] = dword;
+        }
+        if (ok) {
+            hipLaunchKernelGGL(k_post_status_batch, dim3(1), dim3(kMaxBatch), 0, stream, st, b->n);
+            ok = hipGetLastError() == hipSuccess && hipEventRecord(b->status_ev, stream) == hipSuccess;
+            for (int i = 0; i < b->n && ok; ++i) { b->ctxs[i]->status_poll = b->status_ev; b->ctxs[i]->status_inflight = true; }
+        }
+        if (!ok) (void)hipGetLastError();
+    }
+    return FD_OK;
+}
+
+// the statuses a batched build posted: one event query while they are in flight, then every context on its own
+static int batch_poll(fd_batch *b)
+{
+    bool any = false;
+    for (int i = 0; i < b->n; ++i) any = any || b->ctxs[i]->status_inflight || b->ctxs[i]->sticky_rc != FD_OK;
+    if (!any) return FD_OK;
+    bool shared_pending = false;
+    for (int i = 0; i < b->n; ++i) shared_pending = shared_pending || (b->ctxs[i]->status_inflight && b->ctxs[i]->status_poll == b->status_ev);
+    if (shared_pending) {
+        const hipError_t q = hipEventQuery(b->status_ev);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return FD_OK; }
+    }
+    for (int i = 0; i < b->n; ++i) {
+        const int rc = poll_status(b->ctxs[i]);
+        if (rc) { batch_err(b, "context %d: %s", i, b->ctxs[i]->err); return rc; }
     }
     return FD_OK;
 }
@@ -1429,6 +1549,7 @@ int fd_batch_deform_dev(fd_batch *b, void *hip_stream, int64_t N, const float *c
         a.variant = c->eval_variant;
         if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
     }
+    if ((rc = batch_poll(b))) return rc;
     hipError_t e = launch_deform_batch(args, b->n, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_batch failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
     return FD_OK;
@@ -1480,6 +1601,7 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
         a.rec32[i] = c->d_rec32; a.model[i] = c->d_model; a.P_out[i] = d_P_out[i];
         if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
     }
+    if ((rc = batch_poll(b))) return rc;
     const size_t wb = shared_wtile_bytes(a.Mpad, a.nF), fb = shared_frame_bytes(a.nF);
     if (wb > b->cap_wtiles || fb > b->cap_frames) {
         // (hipFree drains the device: no launch still reads the old scratch)

@@ -96,9 +96,13 @@ enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
  * system on which the Cholesky loses definiteness to rounding (centres one fp32 step apart, a
  * fixed-radius Gaussian wider than the rig) is rebuilt with the LU before anything is reported,
  * and the context keeps the LU until its kernel, term or M change: nothing the LU accepts fails.
- * (The rebuild happens where the status is read -- fd_build, fd_build_result, fd_batch_build_result;
- * a pipeline that enqueues builds and evaluations without ever collecting a result evaluates such
- * a rig as a failed model, i.e. passes the mesh through, until it does.)  Both
+ * The rebuild happens where the status is first seen: in fd_build / fd_build_result /
+ * fd_batch_build_result, or -- in a pipeline that enqueues builds and evaluations without collecting
+ * results -- in the first fd_deform* / fd_batch_deform* call made after the build has executed
+ * (every enqueued build posts its status to page-locked memory; every later call polls it without
+ * waiting).  Evaluations enqueued BEFORE the status could be known pass the mesh through; from then
+ * on the rig is evaluated correctly, or, if the LU fails too, fd_deform* returns FD_E_SINGULAR /
+ * FD_E_DUPLICATE (sticky until the next fd_set_points / fd_set_deltas).  Both
  * are fp64 direct solves of the same system: their weights agree to rounding (~1e-12 relative
  * on the benchmark rigs), far inside the parity tolerance. */
 enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1 };
@@ -166,7 +170,8 @@ int fd_set_term(fd_ctx *ctx, int term);
  * matrix assembly + dense solve on the device; synchronises; fills *report.
  * Returns FD_OK iff report->terminationtype == 1.
  * fd_build_async enqueues the same work and returns; fd_build_result waits and
- * reports.  A deform enqueued after a failed build passes P through unchanged. */
+ * reports.  A deform enqueued after a failed build passes P through unchanged; once the failure is
+ * known to the host (no wait: see FD_SOLVER_AUTO) fd_deform* repairs it or returns its error code. */
 int fd_build(fd_ctx *ctx, fd_report *report);
 int fd_build_async(fd_ctx *ctx);
 int fd_build_result(fd_ctx *ctx, fd_report *report);

@@ -220,7 +220,7 @@ def test_sop_cook_captures_on_the_device_and_caches_like_the_reference(hip_lib, 
     # a radius inside the islands' extent: island points beyond it read -1 (capture.cpp:76,88), pass the
     # gate and overshoot (B4: pow(1 - (-1 / r2), rate) > 1)
     node.set("radius", 0.03); node.set("maxedges", K)
-    res6 = node.cook(P, rest, deform, rig_rest_unchanged=False, mesh_unchanged=True, **kw)
+    res6 = node.cook(P, rest, deform, rig_rest_unchanged=False, mesh_unchanged=False, **kw)     # back to the first mesh
     r2c = np.float32(0.03) * np.float32(0.03)
     assert (res6.dist2 == -1.0).any() and (res6.fd_falloff > 1.0).any()
     ref6, fall6 = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, dist2=res6.dist2, radius2=r2c, falloffrate=1.5)

@@ -233,3 +233,50 @@ def test_every_block_shape_of_the_fused_step(hip_lib):
                 W.append(e.get_weights()[0])
                 e.close()
             assert np.abs(W[0] - W[1]).max() <= 1e-8 * np.abs(W[1]).max(), (kind, M)
+
+
+def test_failed_async_build_is_repaired_or_reported_without_reading_the_result(hip_lib, oracle):
+    """A pipeline that enqueues build + evaluations and never calls fd_build_result.
+    Rig: two centres one fp32 step apart under the cubic kernel -- the Cholesky loses definiteness,
+    the LU does not.  The evaluation enqueued right behind the build cannot know yet and passes the
+    mesh through; once the build has executed, the next evaluation finds the posted status, rebuilds
+    with the LU on the stream and is CORRECT.  With coincident centres (nothing can solve that) the
+    next evaluation returns FD_E_DUPLICATE instead of passing the mesh through in silence."""
+    M, N = 300, 20_000
+    dev = torch.device("cuda:0")
+    rest = synth.control_points(M, "head")
+    near = rest.copy(); near[17] = near[200] + np.float32(1e-7) * np.array([1, 0.5, -0.3], np.float32)
+    delta = synth.smooth_deltas(rest, 0).astype(np.float32)
+    P = synth.head_mesh(N)
+    d_P = torch.from_numpy(P).to(dev)
+    out1, out2 = torch.empty_like(d_P), torch.empty_like(d_P)
+    e = _engine(capi.KERNEL_CUBIC, [], capi.TERM_LINEAR, near, delta, capi.SOLVER_AUTO)
+    e.build_async()
+    e.deform_dev(N, d_P.data_ptr(), out1.data_ptr())          # enqueued before the status can be known
+    torch.cuda.synchronize()                                    # (not an fd_* call: the engine is told nothing)
+    e.deform_dev(N, d_P.data_ptr(), out2.data_ptr())          # finds the status, repairs, evaluates
+    torch.cuda.synchronize()
+    ref = _engine(capi.KERNEL_CUBIC, [], capi.TERM_LINEAR, near, delta, capi.SOLVER_LU)
+    ref.build()
+    want, _ = ref.deform(P)
+    got = out2.cpu().numpy()
+    assert not np.array_equal(got, P)                           # not a pass-through
+    assert np.array_equal(got, want)                            # the LU's model, bit for bit
+    assert e.build_result().terminationtype == 1
+    e.close(); ref.close()
+    # nothing solves coincident centres: reported, not passed through
+    dup = rest.copy(); dup[9] = dup[2]
+    e = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, dup, delta, capi.SOLVER_AUTO)
+    e.build_async()
+    torch.cuda.synchronize()
+    with pytest.raises(capi.FdError) as ei:
+        e.deform_dev(N, d_P.data_ptr(), out2.data_ptr())
+    assert ei.value.code == capi.FD_E_DUPLICATE
+    with pytest.raises(capi.FdError):                            # sticky
+        e.deform_dev(N, d_P.data_ptr(), out2.data_ptr())
+    e.set_points(rest, delta)                                    # a new set-up clears it
+    e.build_async()
+    e.deform_dev(N, d_P.data_ptr(), out2.data_ptr())
+    torch.cuda.synchronize()
+    assert e.build_result().terminationtype == 1
+    e.close()
