@@ -14,7 +14,7 @@ SOURCES = ["fd_eval.hip", "fd_build.hip", "fd_nullspace.hip", "fd_capi.hip", "fd
 # per-file extras: keep the bf16 MFMA results of the evaluation kernel in VGPRs (the default puts
 # them in AGPRs and pays one v_accvgpr_read per value)
 EXTRA_FLAGS = {"fd_eval.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-HEADERS = [os.path.join(CSRC, "fd_internal.h"), os.path.join(_ROOT, "include", "facedeform_hip.h")]
+HEADERS = [os.path.join(CSRC, "fd_internal.h"), os.path.join(CSRC, "fd_pack.h"), os.path.join(_ROOT, "include", "facedeform_hip.h")]
 
 
 def hipcc_path() -> str:

@@ -24,6 +24,7 @@
 //               layout, then C -= L21 * U12 with v_mfma_f64_16x16x4_f64.
 // Back substitution: one workgroup, bottom up over 32-row blocks.
 #include "fd_internal.h"
+#include "fd_pack.h"
 
 namespace fd {
 
@@ -738,228 +739,17 @@ __global__ __launch_bounds__(256) void k_backsub_update(const BatchSlot *tab, in
     A[(size_t)(npad + 2) * lda + i] -= a2;
 }
 
-// ---- pack: solution -> weights, evaluation records, status -----------------------
-// from_w != 0: the weights are already in W (fd_import_model); only the records,
-// the affine part and the status are produced.
-//
-// The fp32 evaluation runs in normalised coordinates x' = (x - x0) / s, s a power of two:
-// thin-plate's log makes fp32 accuracy depend on the length unit (at scale 100 the direct
-// form degrades to 2-3e-5), and a far-away origin costs bits in every kernel.  Homogeneous
-// kernels only rescale their weights; thin-plate also needs
-//     sum_j w_j (1/2) d^2 ln d^2 = s^2 sum_j w_j (1/2) d'^2 ln d'^2 + (s^2 ln s) sum_j w_j d'^2
-// whose last sum is the quadratic |x'|^2 m0 - 2 x'.m1 + m2 of three moments of the weights.
-// x0 = 0 and s = 1 for unit-scale data near the origin, which leaves those results unchanged.
-__device__ __forceinline__ double block_sum(double v, double *scratch, int tid)
-{
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    __syncthreads();
-    if ((tid & 63) == 0) scratch[tid >> 6] = v;
-    __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
-}
-__device__ __forceinline__ double block_max(double v, double *scratch, int tid)
-{
-    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(v, off); v = o > v ? o : v; }
-    __syncthreads();
-    if ((tid & 63) == 0) scratch[tid >> 6] = v;
-    __syncthreads();
-    const double a = scratch[0] > scratch[1] ? scratch[0] : scratch[1];
-    const double b = scratch[2] > scratch[3] ? scratch[2] : scratch[3];
-    return a > b ? a : b;
-}
-
+// ---- pack: solution -> weights, evaluation records, status (bodies in fd_pack.h) ------------------
 // one 128-VGPR slot: the kernel runs beside the evaluation of earlier frames (fd_nullspace.hip, FD_FIT_BESIDE_EVAL)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_pack(const BatchSlot *tab, int npad, int M, int Mpad, int T, int kind,
                                               int from_w, int layers)
 {
-    const BatchSlot &slot = tab[blockIdx.z];
-    const double *X = from_w ? nullptr : slot.X;
-    const double *centres = slot.centres, *radii = slot.radii;
-    double *W = slot.W;
-    Rec32 *rec32 = slot.rec32;
-    Rec64 *rec64 = slot.rec64;
-    DevModel *model = slot.model;
-    __shared__ int s_bad;
-    __shared__ double s_red[4];
-    const int tid = threadIdx.x;
-    if (tid == 0) s_bad = 0;
-    __syncthreads();
-    const double kLn2 = 0.6931471805599453;
-    const double kLog2e = 1.4426950408889634;
-    const bool gauss = kind == FD_KERNEL_GAUSSIAN || kind == FD_KERNEL_GAUSSIAN_QNN;
-
-    // ---- normalisation: x0 = centroid of the centres (0 if they already sit around the
-    //      origin), s = power of two nearest to their largest distance from x0
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int j = tid; j < M; j += 256) { sx += centres[3 * j]; sy += centres[3 * j + 1]; sz += centres[3 * j + 2]; }
-    double cenx = block_sum(sx, s_red, tid) / M, ceny = block_sum(sy, s_red, tid) / M, cenz = block_sum(sz, s_red, tid) / M;
-    double r2 = 0.0, r2o = 0.0;
-    for (int j = tid; j < M; j += 256) {
-        const double x = centres[3 * j], y = centres[3 * j + 1], z = centres[3 * j + 2];
-        const double d = (x - cenx) * (x - cenx) + (y - ceny) * (y - ceny) + (z - cenz) * (z - cenz);
-        r2 = d > r2 ? d : r2;
-        const double o = x * x + y * y + z * z;
-        r2o = o > r2o ? o : r2o;
-    }
-    const double rad_c = sqrt(block_max(r2, s_red, tid));
-    const double rad_o = sqrt(block_max(r2o, s_red, tid));
-    const double cen = sqrt(cenx * cenx + ceny * ceny + cenz * cenz);
-    double x0[3] = {0.0, 0.0, 0.0};
-    double rad = rad_o;
-    if (cen > rad_c * 0.0625) { x0[0] = (double)(float)cenx; x0[1] = (double)(float)ceny; x0[2] = (double)(float)cenz; rad = rad_c; }
-    double sc = 1.0;
-    if (rad > 0.0 && isfinite(rad)) {
-        int e = (int)rint(log2(rad));
-        e = e < -100 ? -100 : (e > 100 ? 100 : e);
-        sc = ldexp(1.0, e);
-    }
-    const double inv_s = 1.0 / sc;
-    double w32 = 1.0, w64 = 1.0, kappa = 0.0;
-    if (kind == FD_KERNEL_THIN_PLATE) { w32 = 0.5 * kLn2 * sc * sc; w64 = 0.5; kappa = sc * sc * log(sc); }
-    if (kind == FD_KERNEL_BIHARMONIC) { w32 = -sc; w64 = -1.0; }
-    if (kind == FD_KERNEL_CUBIC) { w32 = sc * sc * sc; }
-
-    // ---- records + moments of the weights in normalised coordinates
-    bool bad = false;
-    double m[15];   // per output c: m0, m1x, m1y, m1z, m2
-#pragma unroll
-    for (int q = 0; q < 15; ++q) m[q] = 0.0;
-    for (int j = tid; j < Mpad; j += 256) {
-        Rec32 r32 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        Rec64 r64 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (j < M) {
-            const double w[3] = {from_w ? W[3 * j] : X[j], from_w ? W[3 * j + 1] : X[npad + j],
-                                 from_w ? W[3 * j + 2] : X[2 * (size_t)npad + j]};
-            bad |= !(isfinite(w[0]) && isfinite(w[1]) && isfinite(w[2]));
-            if (!from_w) { W[3 * j] = w[0]; W[3 * j + 1] = w[1]; W[3 * j + 2] = w[2]; }
-            const double R = radii[j];
-            r64.cx = centres[3 * j]; r64.cy = centres[3 * j + 1]; r64.cz = centres[3 * j + 2];
-            r64.s = gauss ? -1.0 / (R * R) : 0.0;
-            r64.wx = w[0] * w64; r64.wy = w[1] * w64; r64.wz = w[2] * w64;
-            const double cn[3] = {(r64.cx - x0[0]) * inv_s, (r64.cy - x0[1]) * inv_s, (r64.cz - x0[2]) * inv_s};
-            r32.cx = (float)cn[0]; r32.cy = (float)cn[1]; r32.cz = (float)cn[2];
-            r32.s = gauss ? (float)(-kLog2e * sc * sc / (R * R)) : 0.f;
-            r32.wx = (float)(w[0] * w32); r32.wy = (float)(w[1] * w32); r32.wz = (float)(w[2] * w32);
-            const double cc2 = cn[0] * cn[0] + cn[1] * cn[1] + cn[2] * cn[2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                m[5 * c] += w[c];
-                m[5 * c + 1] += w[c] * cn[0];
-                m[5 * c + 2] += w[c] * cn[1];
-                m[5 * c + 3] += w[c] * cn[2];
-                m[5 * c + 4] += w[c] * cc2;
-            }
-        }
-        // multilayer model: W is layer-major (record l * Mc + c), the evaluation wants the layers of
-        // a centre side by side (c * layers + l) so that they can share its distances
-        int jo = j;
-        if (layers > 1 && j < M) { const int Mc = M / layers; jo = (j % Mc) * layers + j / Mc; }
-        rec32[jo] = r32;
-        rec64[jo] = r64;
-    }
-#pragma unroll
-    for (int q = 0; q < 15; ++q) m[q] = block_sum(m[q], s_red, tid);
-
-    // ---- affine part: W rows M..M+3 = const, x, y, z (raw coordinates)
-    __shared__ double s_aff[12];
-    if (tid < 12) {
-        const int cc = tid / 4, k = tid % 4;
-        double v = 0.0;
-        if (from_w) v = W[3 * (M + k) + cc];
-        else if (k < T) v = X[(size_t)cc * npad + M + k];
-        bad |= !isfinite(v);
-        if (!from_w) W[3 * (M + k) + cc] = v;
-        model->affine64[tid] = v;
-        s_aff[tid] = v;
-    }
-    if (bad) s_bad = 1;
-    __syncthreads();
-    if (tid < 3) {
-        const int c = tid;
-        const double *a = s_aff + 4 * c;   // {v0, Vx, Vy, Vz}
-        model->poly32[5 * c + 0] = (float)(a[0] + a[1] * x0[0] + a[2] * x0[1] + a[3] * x0[2] + kappa * m[5 * c + 4]);
-        model->poly32[5 * c + 1] = (float)(a[1] * sc - 2.0 * kappa * m[5 * c + 1]);
-        model->poly32[5 * c + 2] = (float)(a[2] * sc - 2.0 * kappa * m[5 * c + 2]);
-        model->poly32[5 * c + 3] = (float)(a[3] * sc - 2.0 * kappa * m[5 * c + 3]);
-        model->poly32[5 * c + 4] = (float)(kappa * m[5 * c]);
-        model->norm32[c] = (float)x0[c];
-    }
-    if (tid == 0) {
-        model->norm32[3] = (float)inv_s;
-        int tt = 1;
-        if (from_w == 1) {
-            if (s_bad) tt = -4;
-        } else {
-            if (model->sing_flag || s_bad) tt = -4;
-            if (model->dup_flag) tt = -5;
-        }
-        model->terminationtype = tt;
-    }
-}
-
-// ---- thin-plate only: centre tiles for the matrix-pipe evaluation ------------------------
-// An fp32 value splits EXACTLY into three bf16 pieces hi + mid + lo (8 significant bits each,
-// by truncation).  d2 = |x'|^2 - 2 x'.c' + |c'|^2 then runs on the bf16 MFMA to fp32 accuracy:
-// per coordinate the six products (hi,hi) (hi,mid) (mid,hi) (mid,mid) (hi,lo) (lo,hi) -- the
-// three dropped ones are below 2^-24 relative -- and, in lane group 3, |c'|^2 against 1 and 1
-// against |x'|^2 in three slots each.
-__device__ __forceinline__ void split3_bf16(float x, unsigned &hi, unsigned &mid, unsigned &lo)
-{
-    const unsigned u = __float_as_uint(x);
-    const float r1 = x - __uint_as_float(u & 0xffff0000u);     // exact
-    const unsigned u1 = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);   // exact, at most 8 significant bits left
-    hi = u >> 16; mid = u1 >> 16; lo = __float_as_uint(r2) >> 16;
+    packing::pack_body(tab[blockIdx.z], npad, M, Mpad, T, kind, from_w, layers);
 }
 
 __global__ __launch_bounds__(64) void k_pack_tiles(const BatchSlot *tab, int Mpad)
 {
-    const Rec32 *rec32 = tab[blockIdx.z].rec32;
-    MfmaTile *tiles = tab[blockIdx.z].tiles;
-    const int tile = blockIdx.x, lane = threadIdx.x;
-    const int g = lane >> 4, i = lane & 15;
-    const Rec32 r = rec32[16 * tile + i];          // Mpad is a multiple of 16; padding records are zero
-    unsigned h, m, l;
-    unsigned k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (g < 3) {
-        const float c = g == 0 ? r.cx : (g == 1 ? r.cy : r.cz);
-        split3_bf16(c, h, m, l);
-        k[0] = h; k[1] = h; k[2] = m; k[3] = m; k[4] = h; k[5] = l;     // against x: hi mid hi mid lo hi
-    } else {
-        const float cc = fmaf(r.cz, r.cz, fmaf(r.cy, r.cy, r.cx * r.cx));
-        split3_bf16(cc, h, m, l);
-        k[0] = h; k[1] = m; k[2] = l;                                   // against 1, 1, 1
-        k[3] = 0x3f80; k[4] = 0x3f80; k[5] = 0x3f80;                    // 1 against the pieces of |x'|^2
-    }
-    MfmaTile &t = tiles[tile];
-    t.a[lane][0] = k[0] | (k[1] << 16);
-    t.a[lane][1] = k[2] | (k[3] << 16);
-    t.a[lane][2] = k[4] | (k[5] << 16);
-    t.a[lane][3] = k[6] | (k[7] << 16);
-    if (i < 12) {
-        // slot i of group g: pair p = i / 6 (rows 2p, 2p+1), output c = (i % 6) / 2, half = i % 2
-        const int pair = i / 6, c = (i % 6) / 2, half = i % 2;
-        const Rec32 rw = rec32[16 * tile + 4 * g + 2 * pair + half];
-        t.w[g][i] = c == 0 ? rw.wx : (c == 1 ? rw.wy : rw.wz);
-    }
-    if (lane < 16) t.pad[lane] = 0.f;
-    (void)Mpad;
-
-    // fp16 form: pieces hi = RN16(v), lo = RN16(v - hi).  Lane group g < 3: {c_hi, c_hi, c_lo, c_lo}
-    // against the vertex's {x_hi, x_lo, x_hi, x_lo}; group 3: {|c|^2_hi, |c|^2_lo, 1, 1} against
-    // {1, 1, |x|^2_hi, |x|^2_lo}.
-    MfmaTileH *tiles16 = tab[blockIdx.z].tiles16;
-    if (tiles16) {
-        MfmaTileH &th = tiles16[tile];
-        const float v = g < 3 ? (g == 0 ? r.cx : (g == 1 ? r.cy : r.cz)) : fmaf(r.cz, r.cz, fmaf(r.cy, r.cy, r.cx * r.cx));
-        const _Float16 vh = (_Float16)v;
-        const _Float16 vl = (_Float16)(v - (float)vh);
-        const unsigned uh = (unsigned)__builtin_bit_cast(unsigned short, vh), ul = (unsigned)__builtin_bit_cast(unsigned short, vl);
-        if (g < 3) { th.a[lane][0] = uh | (uh << 16); th.a[lane][1] = ul | (ul << 16); }
-        else { th.a[lane][0] = uh | (ul << 16); th.a[lane][1] = 0x3c003c00u; }
-        if (i < 12) th.w[g][i] = t.w[g][i];
-        if (lane < 16) th.pad[lane] = 0.f;
-    }
+    packing::pack_tiles_body(tab[blockIdx.z], Mpad, blockIdx.x, threadIdx.x);
 }
 
 // NB of the panel that starts at column k0 (the register budget of one workgroup decides)

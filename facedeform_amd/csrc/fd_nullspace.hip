@@ -44,7 +44,11 @@
 //
 // fd_set_deltas (launch_resolve_spd) sends new right-hand sides through the same kernels with the
 // matrix work switched off: identical operands in identical order, bit-identical weights.
+#include <cstdio>
+#include <cstdlib>
+
 #include "fd_internal.h"
+#include "fd_pack.h"
 
 namespace fd {
 
@@ -61,6 +65,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNB = 32;                 // Cholesky block width
+__device__ __forceinline__ int round_up_dev(int v, int m) { return (v + m - 1) / m * m; }
 constexpr int kSlab = 256;              // rows per workgroup of the panel's triangular solve
 constexpr int kBulk = 4;                // fused step, large systems: the bulk of the trailing matrix is updated every kBulk steps
 constexpr size_t kStepPanelLds = sizeof(double) * (2 * 32 * 34 + 2 * 32);   // diagonal block + its transpose + two 32-vectors
@@ -113,9 +118,8 @@ __device__ __forceinline__ void ns_rhs_body(const BatchSlot &s, int M, int T, in
 // LAPACK dlarfg turned upside down: reflector k acts on rows 0 .. M-1-k and leaves its beta in
 // row M-1-k, so the null-space block comes FIRST in the rotated system and the Cholesky starts
 // at row 0 on tile boundaries.
-__global__ __launch_bounds__(256) void k_ns_reflectors(const BatchSlot *tab, int M, int T, int npad, int lda, int with_rhs)
+__device__ __forceinline__ void ns_reflectors_body(const BatchSlot &s, int M, int T, int npad, int lda, int with_rhs)
 {
-    const BatchSlot &s = tab[blockIdx.z];
     gcdouble *centres = as_global(s.centres);
     gdouble *V = as_global(s.ns), *small = V + (size_t)12 * M;
     __shared__ double s_red[4 * 8];
@@ -204,6 +208,11 @@ __global__ __launch_bounds__(256) void k_ns_reflectors(const BatchSlot *tab, int
         __syncthreads();                      // tau is in memory
         ns_rhs_body(s, M, T, npad, lda, s_red);
     }
+}
+
+__global__ __launch_bounds__(256) void k_ns_reflectors(const BatchSlot *tab, int M, int T, int npad, int lda, int with_rhs)
+{
+    ns_reflectors_body(tab[blockIdx.z], M, T, npad, lda, with_rhs);
 }
 
 // f <- Q^T f = H_{T-1} .. H_0 f in the right-hand-side columns; the pivot rows' values go aside
@@ -304,15 +313,15 @@ __device__ __forceinline__ void ns_w_body(const BatchSlot &s, int M)
 // 64 rows per workgroup, one row per lane (consecutive lanes walk a column of A: coalesced); the
 // four waves split the columns, each with its slice of V in LDS, and their partial sums are added
 // in a fixed order
-__global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int lda)
+// rows 64 vb .. 64 vb + 63 of Y = K V (one workgroup of the k_ns_kv grid, or one turn of the one-launch build's loop)
+__device__ __forceinline__ void ns_kv_body(const BatchSlot &s, int M, int lda, int vb)
 {
-    const BatchSlot &s = tab[blockIdx.z];
     gcdouble *A = as_global(s.A), *V = as_global(s.ns);
     gdouble *Y = as_global(s.ns) + (size_t)4 * M;
     __shared__ __attribute__((aligned(16))) double s_v[4][64][4];
     __shared__ double s_part[4][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
+    const int i = vb * 64 + lane;
     const int ic = i < M ? i : M - 1;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const int per = ((M + 3) / 4 + 63) & ~63;          // columns per wave, a multiple of the LDS slice
@@ -347,6 +356,12 @@ __global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int 
         for (int t = 0; t < 4; ++t)
             Y[4 * (size_t)i + t] = (s_part[0][lane][t] + s_part[1][lane][t]) + (s_part[2][lane][t] + s_part[3][lane][t]);
     }
+}
+
+__global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int lda)
+{
+    const BatchSlot &s = tab[blockIdx.z];
+    ns_kv_body(s, M, lda, blockIdx.x);
     // the last workgroup to get here turns Y into W (it needs all of Y: V^T Y is a sum over every
     // row).  Which workgroup that is does not matter to the result.
     __shared__ unsigned s_ticket;
@@ -362,11 +377,9 @@ __global__ __launch_bounds__(256) void k_ns_kv(const BatchSlot *tab, int M, int 
 // ---- B = K - V W^T - W V^T, lower triangle of the leading n1 x n1 block in place ----------------
 // Rows n1 .. M-1 (pivot row M-1-k = equation of polynomial coefficient k) go to B21 and read as
 // padding afterwards; columns n1 .. npc-1 become identity padding.
-__global__ __launch_bounds__(256) void k_ns_rotate(const BatchSlot *tab, int M, int T, int npc, int lda)
+__device__ __forceinline__ void ns_rotate_body(const BatchSlot &s, int M, int T, int npc, int lda, int ti, int tj)
 {
-    const int ti = blockIdx.x, tj = blockIdx.y;
     if (ti < tj) return;
-    const BatchSlot &s = tab[blockIdx.z];
     gdouble *A = as_global(s.A);
     gcdouble *V = as_global(s.ns), *W = V + (size_t)4 * M;
     gdouble *B21 = as_global(s.ns) + (size_t)8 * M;
@@ -394,6 +407,11 @@ __global__ __launch_bounds__(256) void k_ns_rotate(const BatchSlot *tab, int M, 
             if (i < npc) A[(size_t)j * lda + i] = 0.0;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_ns_rotate(const BatchSlot *tab, int M, int T, int npc, int lda)
+{
+    ns_rotate_body(tab[blockIdx.z], M, T, npc, lda, blockIdx.x, blockIdx.y);
 }
 
 // ---- Cholesky: diagonal block --------------------------------------------------------------------
@@ -745,13 +763,11 @@ __global__ __launch_bounds__(256) void k_ns_recover(const BatchSlot *tab, int M,
 // chain, then the rows above in the range take the block's contribution (the mirrored U = L^T, one
 // row per thread, coalesced).  Ranges above 512 rows are chained with k_backsub_update as in the
 // LU path.  Same role and data layout as fd_build.hip's k_backsub_all.
-__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_backsub_inv(const BatchSlot *tab, int M, int lda, int npad, int row_lo, int row_hi,
-                                                                        int recover_T)
+__device__ __forceinline__ void backsub_inv_body(const BatchSlot &s, int M, int lda, int npad, int row_lo, int row_hi, int recover_T,
+                                                 double *s_y /* dynamic LDS, [3][w] */)
 {
-    const BatchSlot &s = tab[blockIdx.z];
     gcdouble *A = as_global(s.A);
     gdouble *X = as_global(s.X);
-    extern __shared__ __attribute__((aligned(16))) double s_y[];   // [3][w]
     __shared__ double s_li[2][kNB][kNB + 1];
     __shared__ double s_x[kNB][3];
     __builtin_amdgcn_s_setprio(3);
@@ -821,6 +837,13 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_backsub_inv(const Ba
         __syncthreads();
         ns_recover_body(s, M, recover_T, npad, &s_li[0][0][0]);
     }
+}
+
+__global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_backsub_inv(const BatchSlot *tab, int M, int lda, int npad, int row_lo, int row_hi,
+                                                                        int recover_T)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_y_dyn[];   // [3][w]
+    backsub_inv_body(tab[blockIdx.z], M, lda, npad, row_lo, row_hi, recover_T, s_y_dyn);
 }
 
 // ---- Cholesky: trailing update ---------------------------------------------------------------
@@ -1128,6 +1151,204 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
     for (int cc = 0; cc < kNB; ++cc) up[cc] = x[cc];
 }
 
+// ---- the whole build of a small system in ONE launch of ONE workgroup (opt-in: FD_SMALL_BUILD=1) --------------
+// NEGATIVE RESULT, kept selectable and tested: see launch_build_spd for the measurements.
+// A lone order-256 system is 5.6 MFLOP of fp64 work that the chain above spreads over 18 dependent
+// launches: 0.24 ms, most of it launch floor and dispatch.  Up to order 512
+// everything after the assembly of K -- reflectors, Y = K V, W, the rotation, every Cholesky step,
+// back-substitution, recovery of the polynomial, packing of the evaluation records -- runs here in
+// one workgroup of four waves (one per SIMD: the fp64 matrix pipe of a CU is 128 flop / clock, and
+// 1/3 n^3 flop of an order-256 system are 20 us of it), with workgroup barriers where the chain had
+// kernel boundaries.  (The assembly stays a grid of its own: 65 536 fp64 logarithms are ~70 us on
+// one CU and 8 us on sixty-four.)  A batch is a grid of such workgroups, one per model: the same
+// code, so single and batched builds agree bit for bit, and 32 models cost what one does.
+//
+// Per 32 columns (panel k0 solved, block kb = k0 + 32 next):
+//   (i)   all four waves apply panel k0 to the columns kb .. kb+31 (rows >= kb, right-hand sides),
+//   (ii)  wave 0 factorises the diagonal block (kb, kb) -- the only sequential piece, 3.5 us --
+//         WHILE waves 1..3 apply panel k0 to everything right of those columns (look-ahead),
+//   (iii) all waves solve the rows below the block, one row per thread; the right-hand sides ride
+//         along as three more rows, the block's inverse is a by-product (back-substitution).
+// The right-hand sides see exactly the operations, operands and order of k_chol_solve /
+// k_chol_trail (fd_set_deltas), so new deltas through the stored factor stay bit-identical to a rebuild.
+constexpr int kSmallMaxNpc = 512;
+
+// C -= L_r L_c^T on one 32 x 32 macro tile with panel kp, by one wave: rows r0 .., columns c0 .. of
+// the trailing matrix (lower triangle, accumulator transposed as in k_chol_step), or -- rhs_tile --
+// the three right-hand-side rows against the columns c0 .. c0+31
+__device__ __forceinline__ void small_macro_tile(gdouble *A, int lda, int npad, int kp, int c0, int r0, bool rhs_tile, int lane)
+{
+    constexpr int S = kNB / 4;
+    const int c = lane & 15, g = lane >> 4;
+    double ua[S], ub[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        ua[s] = -A[(size_t)(kp + g + 4 * s) * lda + c0 + c];
+        ub[s] = -A[(size_t)(kp + g + 4 * s) * lda + c0 + 16 + c];
+    }
+    if (!rhs_tile) {
+        const size_t cs = (size_t)4 * lda;
+        gdouble *p00 = A + (size_t)(c0 + g) * lda + r0 + c;
+        gdouble *p01 = p00 + (size_t)16 * lda;
+        gdouble *p10 = p00 + 16, *p11 = p01 + 16;
+        double4_t a00, a01, a10, a11;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a00[r] = p00[r * cs]; a01[r] = p01[r * cs]; a10[r] = p10[r * cs]; a11[r] = p11[r * cs]; }
+        gcdouble *aptr = A + (size_t)(kp + g) * lda + r0 + c;
+        double av0[S], av1[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) { av0[s] = aptr[(size_t)(4 * s) * lda]; av1[s] = aptr[(size_t)(4 * s) * lda + 16]; }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[s], av0[s], a00, 0, 0, 0);
+            a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(ub[s], av0[s], a01, 0, 0, 0);
+            a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[s], av1[s], a10, 0, 0, 0);
+            a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(ub[s], av1[s], a11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p00[r * cs] = a00[r]; p01[r * cs] = a01[r]; p10[r * cs] = a10[r]; p11[r * cs] = a11[r]; }
+    } else {
+        gdouble *p0 = A + (size_t)(npad + c) * lda + c0 + g, *p1 = p0 + 16;
+        double4_t a0, a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = p0[4 * r]; a1[r] = p1[4 * r]; }
+        gcdouble *aptr = A + (size_t)(npad + c) * lda + kp + g;
+        double av[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) av[s] = aptr[4 * s];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[s], av[s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ub[s], av[s], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p0[4 * r] = a0[r]; p1[4 * r] = a1[r]; }
+    }
+}
+
+// (one wave per SIMD and no register cap: phases with 32-double rows plus MFMA tiles in flight spilled 237 registers under the 128 of FD_FIT_BESIDE_EVAL)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_build_small(const BatchSlot *tab, int M, int T, int npad, int lda, int kind, int Mpad,
+                                                                        unsigned long long *stamps)
+{
+    const BatchSlot &slot = tab[blockIdx.z];
+    // diagnostics (FD_SMALL_STAMPS): shader-clock stamps of the phases, workgroup 0, thread 0
+    unsigned long long st_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    int st_k = 0;
+#define FD_BSTAMP() if (stamps && blockIdx.z == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps[st_k++] = t_ - st_prev; st_prev = t_; }
+    gdouble *A = as_global(slot.A);
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n1 = M - T, npc = round_up_dev(n1, kNB);
+    __builtin_amdgcn_s_setprio(3);
+
+    // ---- projection: reflectors of P (and Q^T f), Y = K V, W, B = K - V W^T - W V^T
+    if (T > 0) {
+        ns_reflectors_body(slot, M, T, npad, lda, 1);
+        __syncthreads();
+        FD_BSTAMP()
+        for (int vb = 0; vb < (M + 63) / 64; ++vb) { ns_kv_body(slot, M, lda, vb); __syncthreads(); }
+        FD_BSTAMP()
+        ns_w_body(slot, M);
+        __syncthreads();
+        FD_BSTAMP()
+        const int g32 = ((npc > M ? npc : M) + 31) / 32;
+        for (int tj = 0; tj < g32; ++tj)
+            for (int ti = tj; ti < g32; ++ti) ns_rotate_body(slot, M, T, npc, lda, ti, tj);
+        __syncthreads();
+        FD_BSTAMP()
+    }
+
+    // ---- blocked Cholesky with the right-hand sides as three more rows
+    double (*sC)[kLdsRow] = reinterpret_cast<double (*)[kLdsRow]>(dyn_lds);
+    double (*sR)[kLdsRow] = reinterpret_cast<double (*)[kLdsRow]>(dyn_lds + kNB * kLdsRow);
+    double *sCol = dyn_lds + 2 * kNB * kLdsRow;
+    double *sInv = sCol + kNB;
+    for (int k0 = -kNB; k0 + kNB < npc; k0 += kNB) {
+        const int kb = k0 + kNB;
+        const int nbelow = (npc - kb) / kNB;          // 32-row blocks from kb down (the diagonal block included)
+        if (k0 >= 0) {
+            // (i) panel k0 onto the next panel's columns: macro tiles (kb + 32 t, kb), t = 0 .. nbelow - 1, + the RHS tile
+            for (int t = wave; t <= nbelow; t += 4) small_macro_tile(A, lda, npad, k0, kb, kb + kNB * t, t == nbelow, lane);
+            __syncthreads();
+        }
+        if (k0 <= 0) FD_BSTAMP()
+        // (ii) wave 0: the diagonal block; waves 1..3: panel k0 onto the columns right of kb + 31
+        if (wave == 0) {
+            for (int e = lane; e < kNB * kNB; e += 64) {
+                const int r = e & 31, c = e >> 5;
+                sC[r][c] = A[(size_t)(kb + c) * lda + kb + r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            factor_wave(as_global(slot.model), n1, kb, sC, sInv, sCol, true);
+            const int i = tid & 31, h = tid >> 5;      // L11^T for the solves: column k of L11 contiguous, zeros above the diagonal
+#pragma unroll
+            for (int kk = 0; kk < kNB / 2; ++kk) { const int k = 2 * kk + h; sR[k][i] = i >= k ? sC[i][k] : 0.0; }
+        } else if (k0 >= 0) {
+            // column pairs c0 = kb + 32 p, p = 1 .. nbelow - 1; pair p has nbelow - p macro tiles + the RHS tile
+            int idx = wave - 1;
+            for (int pcol = 1; pcol < nbelow; ++pcol) {
+                const int c0 = kb + kNB * pcol, ntile = nbelow - pcol;
+                for (int t = 0; t <= ntile; ++t, ++idx) {
+                    if (idx % 3 != 0) continue;
+                    small_macro_tile(A, lda, npad, k0, c0, c0 + kNB * t, t == ntile, lane);
+                }
+                idx %= 3;
+            }
+        }
+        __syncthreads();
+        if (k0 <= 0) FD_BSTAMP()
+        // (iii) L11 to the side store and into A, its inverse, and X L11^T = A21 on the rows below
+        block_store(slot, M, lda, kb, sC, sInv, true);
+        for (int row = kb + kNB + tid; row < npc; row += 256) {
+            double x[kNB];
+#pragma unroll
+            for (int cc = 0; cc < kNB; ++cc) x[cc] = *pinned_column(A + (size_t)(kb + cc) * lda, 8u * (unsigned)row);
+            solve_row(x, sR, sInv);
+#pragma unroll
+            for (int cc = 0; cc < kNB; ++cc) *pinned_column(A + (size_t)(kb + cc) * lda, 8u * (unsigned)row) = x[cc];
+            gdouble *up = A + (size_t)row * lda + kb;          // mirrored: U[kb + cc][row] = L[row][kb + cc]
+#pragma unroll
+            for (int cc = 0; cc < kNB; ++cc) up[cc] = x[cc];
+        }
+        {
+            const int unit = tid - 64;                         // second wave: row `unit` of the identity -> inverse(L11)
+            const bool rhsrow = tid < 3, invert = unit >= 0 && unit < kNB;
+            if (rhsrow || invert) {
+                gdouble *rowp = A + (size_t)(npad + (rhsrow ? tid : 0)) * lda + kb;
+                double x[kNB];
+#pragma unroll
+                for (int cc = 0; cc < kNB; ++cc) x[cc] = invert ? (cc == unit ? 1.0 : 0.0) : rowp[cc];
+                solve_row(x, sR, sInv);
+                if (invert) {
+                    gdouble *inv = ld_block(slot.ns, M, kb) + kLdInv;
+#pragma unroll
+                    for (int cc = 0; cc < kNB; ++cc) inv[cc * kNB + unit] = x[cc];
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < kNB; ++cc) rowp[cc] = x[cc];
+                }
+            }
+        }
+        __syncthreads();
+        if (k0 <= 0) FD_BSTAMP()
+    }
+    FD_BSTAMP()
+
+    // ---- L^T y = z, the polynomial from R, w = Q [y; 0]; then the evaluation records
+    backsub_inv_body(slot, M, lda, npad, 0, npc, T, dyn_lds);
+    __syncthreads();
+    FD_BSTAMP()
+    packing::pack_body(slot, npad, M, Mpad, T, kind, 0, 0);
+    if (kind == FD_KERNEL_THIN_PLATE) {
+        __syncthreads();
+        for (int tile = wave; tile < Mpad / 16; tile += 4) packing::pack_tiles_body(slot, Mpad, tile, lane);
+    }
+    FD_BSTAMP()
+#undef FD_BSTAMP
+}
+
 // ---- multilayer Gaussian model (FD_KERNEL_GAUSSIAN_ML) ---------------------------------------------
 // The SOP's model = 1, alglib::rbfsetalgomultilayer(model, radius, layers, lambda)
 // (reference src/SOP_FaceDeform.cpp:346-348), in dense form: the term's polynomial is fitted to
@@ -1329,6 +1550,33 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
     const unsigned nb = (unsigned)b.nbatch;
     const int M = b.M, T = b.T;
     const int n1 = M - T, npc = round_up(n1, kNB), npa = round_up(M, 32);
+    // FD_SMALL_BUILD=1: the one-workgroup build (k_build_small) up to order 512.  OFF by default -- measured
+    // on MI355X it LOSES to the chain: 0.37 vs 0.25 ms at M = 256, 1.19 vs 0.43 ms at M = 512, and no gain
+    // for batches of 32 either (profiles/r02_build_small.txt).  With the matrix in L2 every phase is a
+    // handful of dependent ~1 us round trips that four waves cannot hide, where the chain's kernels spread
+    // them over many CUs; what would win is the matrix in registers / LDS.
+    static const bool use_small = [] { const char *e = getenv("FD_SMALL_BUILD"); return e && atoi(e) == 1; }();
+    if (npc <= kSmallMaxNpc && use_small) {
+        // one workgroup per model does everything after the assembly
+        hipError_t e0 = launch_assemble_block(b, stream, npa);
+        if (e0 != hipSuccess) return e0;
+        if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+        const size_t lds = kStepPanelLds > sizeof(double) * 3 * (size_t)npc ? kStepPanelLds : sizeof(double) * 3 * (size_t)npc;
+        static unsigned long long *d_stamps = nullptr;
+        static const bool want_stamps = getenv("FD_SMALL_STAMPS") != nullptr;
+        if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 32 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 32 * sizeof(unsigned long long)); }
+        hipLaunchKernelGGL(k_build_small, dim3(1, 1, nb), dim3(256), lds, stream, b.d_slots, M, T, b.npad, b.lda, b.kind, b.Mpad,
+                           want_stamps ? d_stamps : nullptr);
+        if (want_stamps && d_stamps) {
+            unsigned long long h[32];
+            if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[k_build_small stamps, shader cycles: reflectors | KV | W | rotate | first: factor, solve | step 0: (i), (ii), (iii) | rest of the steps | backsub | pack]\n  ");
+                for (int q = 0; q < 14; ++q) fprintf(stderr, " %llu", h[q]);
+                fprintf(stderr, "\n");
+            }
+        }
+        return hipGetLastError();
+    }
     if (T > 0) {
         hipLaunchKernelGGL(k_ns_reflectors, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, M, T, b.npad, b.lda, 1);
     }

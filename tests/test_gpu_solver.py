@@ -280,3 +280,42 @@ def test_failed_async_build_is_repaired_or_reported_without_reading_the_result(h
     torch.cuda.synchronize()
     assert e.build_result().terminationtype == 1
     e.close()
+
+
+def test_one_workgroup_build_matches_the_chain(hip_lib):
+    """k_build_small (FD_SMALL_BUILD=1: everything after the assembly in one launch of one workgroup).
+    Slower than the launch chain on this hardware and therefore off by default; kept selectable, so it
+    is kept correct: weights against the chain's to rounding, fd_set_deltas bit-identical to a rebuild,
+    batch == single.  The switch is read once per process, hence the child process."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from facedeform_amd import capi, synth
+        out = {}
+        for M in (40, 256, 500):
+            rest = synth.control_points(M, "head")
+            d0 = synth.smooth_deltas(rest, 0).astype(np.float32); d1 = synth.smooth_deltas(rest, 1).astype(np.float32)
+            e = capi.Engine(); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
+            e.set_points(rest, d0); assert e.build().terminationtype == 1
+            out["w%%d" %% M] = e.get_weights()[0]
+            e.set_deltas(d1); assert e.build().terminationtype == 1
+            wd = e.get_weights()[0]
+            e.set_points(rest, d1); e.build()
+            assert np.array_equal(wd, e.get_weights()[0]), M          # new deltas through the stored factor == rebuild
+            out["d%%d" %% M] = wd
+            e.close()
+        np.savez(sys.argv[1], **out)
+    """ % root)
+    import tempfile
+    res = {}
+    for mode in ("0", "1"):
+        path = os.path.join(tempfile.mkdtemp(prefix="fdsmall_"), "w.npz")
+        env = dict(os.environ, FD_SMALL_BUILD=mode)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = np.load(path)
+    for k in res["0"].files:
+        a, b = res["0"][k], res["1"][k]
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max(), k
