@@ -559,14 +559,21 @@ def main():
         flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_verts
         achieved_tflops = flops / (eval_ms * 1e-3) / 1e12
         achieved_gbs = BYTES_PER_VERTEX * n_verts / (eval_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the committed PMC passes (profiles/traffic_<config>.json, one entry per
+        # kernel): what a launch moves whatever its frame count (the mesh, the model) + what it moves per frame.
+        tj = {}
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_frame", tj.get("hbm_bytes_per_launch")) * frames_per_launch
+                tj = json.load(open(tpath))["kernels"]
             except Exception:
-                traffic = None
+                tj = {}
+
+        def measured_traffic(kernel):
+            k = tj.get(kernel)
+            if not k:
+                return None
+            return k["hbm_bytes_fixed_per_launch"] + k["hbm_bytes_per_frame"] * frames_per_launch
         mfma_eval = precision == capi.EVAL_FP32 and n_ctrl >= 49
         use_shared = shared_eval and mfma_eval and n_ctrl >= 32
         if use_shared:
@@ -585,7 +592,7 @@ def main():
                 # HBM (outputs) is the second roof, reported beside it.  Peak: dense fp16 MFMA, 2.5 PFLOP/s.
                 "bound": "mfma", "kernel": kern,
                 "achieved": flops_launch / (launch_ms * 1e-3) / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops_launch / (launch_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic,
+                "frac": flops_launch / (launch_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, "traffic": measured_traffic(kern),
                 "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms, "frames_per_launch": Fl,
                 "note": "algorithmic flops; the pipe executes 4x the contraction (fp16 x 2 split: three products; "
                         "one row in four of an output tile unused)",
@@ -595,16 +602,16 @@ def main():
                         "frac": bytes_launch / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": bytes_launch},
             }
         else:
+            kern = (("k_deform32_tps_mfma_batch" if frames_per_launch > 1 else "k_deform32_tps_mfma")
+                    if mfma_eval else ("k_deform32" if precision == capi.EVAL_FP32 else "k_deform64"))
             roof = {
                 # the one-frame kernels are compute-bound at this M (intensity ~182 flop/B vs ridge ~20) and
                 # their binding pipe is the fp32 VECTOR unit (logarithm + weight contraction), not the
                 # matrix pipe, which only forms the squared distances: PMC in profiles/ (VALU active
                 # ~90-100 % of busy cycles, MFMA pipe busy 13-17 %).  Roof: 157.3 TFLOP/s fp32 vector.
-                "bound": "valu_fp32",
-                "kernel": ("k_deform32_tps_mfma_batch" if frames_per_launch > 1 else "k_deform32_tps_mfma")
-                          if mfma_eval else ("k_deform32" if precision == capi.EVAL_FP32 else "k_deform64"),
+                "bound": "valu_fp32", "kernel": kern,
                 "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
+                "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": measured_traffic(kern),
                 # a launch evaluates frames_per_launch frames (algorithmic flops per frame x frames)
                 "flops_per_launch": flops * frames_per_launch, "avg_launch_ms": launch_ms,
                 "frames_per_launch": frames_per_launch,
