@@ -272,6 +272,12 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
         dist.destroy_process_group()
 
 
+def shared_rows(frames):
+    """Rows of the weight operand the shared-rig launch runs for `frames` frames (16 per output tile; mirrors
+    launch_deform_shared in csrc/fd_eval.hip: 4 frames x (x, y, z, pad) per tile)."""
+    return 16 * ((frames + 3) // 4)
+
+
 def rank_report(torch, dist, rank, world, local_rank, rehearse):
     """Who ran: the process group's size as torch.distributed reports it and every rank's device, so
     that a reader of the JSON line sees N ranks on N GPUs rather than taking n_gpus on trust."""
@@ -585,22 +591,28 @@ def main():
             flops_launch = ((8 + 6 * Fl) * n_ctrl + FLOPS_PER_VERTEX_AFFINE * Fl) * n_verts
             bytes_launch = (12 + 16 * Fl) * n_verts
             kern = "k_deform32_tps_shared"
-            # executed on the matrix pipe: 3 split products x 16/12 (one unused row in four) of the contraction
-            mfma_exec = (3 * 2 * 4 * n_ctrl * Fl + 2 * 16 * n_ctrl) * n_verts        # flop, fp16 MFMA
-            roof = {
-                # Binding pipe: the matrix pipe (PMC: busy ~53 % of the kernel, profiles/r02_pmc_shared_c2.txt);
-                # HBM (outputs) is the second roof, reported beside it.  Peak: dense fp16 MFMA, 2.5 PFLOP/s.
-                "bound": "mfma", "kernel": kern,
-                "achieved": flops_launch / (launch_ms * 1e-3) / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops_launch / (launch_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, "traffic": measured_traffic(kern),
-                "flops_per_launch": flops_launch, "avg_launch_ms": launch_ms, "frames_per_launch": Fl,
-                "note": "algorithmic flops; the pipe executes 4x the contraction (fp16 x 2 split: three products; "
-                        "one row in four of an output tile unused)",
-                "executed_mfma": {"achieved": mfma_exec / (launch_ms * 1e-3) / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": mfma_exec / (launch_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS},
-                "hbm": {"achieved": bytes_launch / (launch_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": bytes_launch / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": bytes_launch},
-            }
+            # executed on the matrix pipe: 3 split products over the rows of the output tiles + the d2 tiles
+            mfma_exec = (3 * 2 * shared_rows(Fl) * n_ctrl + 2 * 16 * n_ctrl) * n_verts        # flop, fp16 MFMA
+            secs = launch_ms * 1e-3
+            mfma_alg = {"achieved": flops_launch / secs / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops_launch / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS, "flops_per_launch": flops_launch,
+                        "executed": {"achieved": mfma_exec / secs / 1e12, "frac": mfma_exec / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                                     "note": "what the pipe runs: fp16 x 2 split = three products; C2 PMC: pipe busy 0.42 of "
+                                             "SIMD-cycles (profiles/r02_pmc_shared_c2.txt)"}}
+            hbm_alg = {"achieved": bytes_launch / secs / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": bytes_launch / secs / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": bytes_launch}
+            # Which roof binds is the roofline model's answer at the launch's ALGORITHMIC intensity: below the
+            # ridge of the fp16 matrix pipe over HBM (312 flop/B) the outputs bound it (C2 x 32 frames: 98 flop/B,
+            # 512 MB written per launch), above it the matrix pipe does (C3: 780 flop/B).  Both are on the line.
+            intensity = flops_launch / bytes_launch
+            ridge = PEAK_FP16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            first, second, key = (hbm_alg, mfma_alg, "mfma") if intensity < ridge else (mfma_alg, hbm_alg, "hbm")
+            roof = {"bound": "hbm" if intensity < ridge else "mfma", "kernel": kern,
+                    "achieved": first["achieved"], "peak": first["peak"], "unit": first["unit"], "frac": first["frac"],
+                    "traffic": measured_traffic(kern), "avg_launch_ms": launch_ms, "frames_per_launch": Fl,
+                    "intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
+                    "bytes_per_launch": bytes_launch, "flops_per_launch": flops_launch, key: second,
+                    ("hbm" if key == "mfma" else "mfma"): first}
         else:
             kern = (("k_deform32_tps_mfma_batch" if frames_per_launch > 1 else "k_deform32_tps_mfma")
                     if mfma_eval else ("k_deform32" if precision == capi.EVAL_FP32 else "k_deform64"))
