@@ -98,6 +98,25 @@ def test_against_oracle_ragged_sizes_and_device_pointers(hip_lib, oracle):
     m.close()
 
 
+@pytest.mark.parametrize("N,S", [(3, 9), (5, 8), (700, 1), (700, 7), (700, 8), (700, 9), (700, 16), (700, 17), (1024 // 3 + 1, 33)])
+def test_panel_edges_of_the_blocked_factorisation(hip_lib, oracle, N, S):
+    """The factorisation works in panels of 8 columns with a block-reflector update behind each
+    (csrc/fd_morph.hip); Eigen's own HouseholderQR is blocked the same way and the packed result is
+    the column-by-column one up to rounding.  Shape counts around the panel width, a square matrix
+    (as many rows as shapes: the last reflector has an empty tail), a single workgroup's worth of rows."""
+    rng = np.random.default_rng(100 * N + S)
+    rest = rng.normal(size=(N, 3)).astype(np.float32)
+    shapes = [(rest + 0.1 * rng.normal(size=(N, 3))).astype(np.float32) for _ in range(S)]
+    A = oracle.morph_shapes_matrix(rest, shapes)
+    QR_ref, tau_ref = oracle.morph_qr(A)
+    m = capi.Morph()
+    m.init(rest, shapes)
+    QR, tau = m.qr()
+    assert np.abs(QR - QR_ref).max() <= 1e-11 * np.abs(QR_ref).max(), np.abs(QR - QR_ref).max() / np.abs(QR_ref).max()
+    assert np.abs(tau - tau_ref).max() <= 1e-12
+    m.close()
+
+
 def test_full_size_properties(hip_lib):
     """N = 1M, S = 24 (the oracle's QR would take minutes): size-independent properties.
     (a) R^T R = A^T A (it is a QR of the shapes matrix); (b) a mesh equal to the rest pose gives
