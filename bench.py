@@ -274,8 +274,9 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
 
 def shared_rows(frames):
     """Rows of the weight operand the shared-rig launch runs for `frames` frames (16 per output tile; mirrors
-    launch_deform_shared in csrc/fd_eval.hip: 4 frames x (x, y, z, pad) per tile)."""
-    return 16 * ((frames + 3) // 4)
+    launch_deform_shared in csrc/fd_eval.hip: 13 frames and more in blocks of 16, one tile per component;
+    fewer as 4 frames x (x, y, z, pad) per tile)."""
+    return 16 * (3 * ((frames + 15) // 16) if frames > 12 else (frames + 3) // 4)
 
 
 def rank_report(torch, dist, rank, world, local_rank, rehearse):
