@@ -69,9 +69,10 @@ def parse_args():
                          "configuration): phi once per (vertex, centre), weight contraction on the matrix pipe "
                          "(fd_batch_deform_shared_dev); batched: one launch, every frame evaluated on its own "
                          "(fd_batch_deform_dev); single: one launch per frame")
-    ap.add_argument("--eval-cus", type=int, default=0,
-                    help="shared evaluation: CUs it occupies (one persistent workgroup each); the rest stay free for the "
-                         "builds of the next group (0 = all 256)")
+    ap.add_argument("--eval-cus", type=int, default=224,
+                    help="shared evaluation: CUs it occupies (one persistent workgroup each, all of a CU's LDS); the rest stay "
+                         "free for the builds of the next groups, which otherwise only run in the gaps between evaluation "
+                         "launches (measured: 224 -> 113k Mverts/s, 256 -> 101k, 192 -> 109k; 0 = all 256)")
     ap.add_argument("--c5-solve", choices=["broadcast", "redundant"], default="broadcast",
                     help="config c5: rank 0 solves and broadcasts the models (default), or every rank solves them itself")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
@@ -422,8 +423,14 @@ def main():
             ln["batches"][count] = capi.Batch(ln["engines"][:count])
         batch = ln["batches"][count]
         frames = [((first + k) * world + rank) % N_FRAMES for k in range(count)]
-        # the lane's previous group must have been evaluated before its models are overwritten
-        stream.wait_event(ln["evals_done"])
+        # The lane's previous group must be done with its models before they are overwritten.  The shared-rig
+        # launch copies what it reads of them in its first small kernel (fd_batch_wait_consumed): the next group's
+        # assemble + solve then runs while the previous one is still being evaluated.  The other launch styles
+        # read the models throughout: wait for the evaluation.
+        if shared_eval and ln.get("last_shared") is not None:
+            ln["last_shared"].wait_consumed(stream.cuda_stream)
+        else:
+            stream.wait_event(ln["evals_done"])
         batch.set_points_dev([d_rest.data_ptr()] * count,
                              [d_deltas.data_ptr() + f * delta_stride for f in frames], n_ctrl)
         if ev:
@@ -442,6 +449,7 @@ def main():
             if shared_eval:
                 batch.deform_shared_dev(n_verts, d_P.data_ptr(), [o.data_ptr() for o in ln["out"][:count]],
                                         d_falloff=[f.data_ptr() for f in ln["fall"][:count]], stream_ptr=es.cuda_stream)
+                ln["last_shared"] = batch
             else:
                 batch.deform_dev(n_verts, [d_P.data_ptr()] * count, [o.data_ptr() for o in ln["out"][:count]],
                                  d_falloff=[f.data_ptr() for f in ln["fall"][:count]], stream_ptr=es.cuda_stream)
@@ -558,9 +566,11 @@ def main():
               f"max {gaps.max():.1f}", file=sys.stderr, flush=True)
     if rank == 0 and os.environ.get("FD_BENCH_GAPS"):
         base = events[0][0]
-        for i in range(0, args.steps, B)[:10]:
+        first = range(0, args.steps, B)
+        for i in list(first[:6]) + list(first[40:52]):
             print(f"[timeline ms] group {i // B}: build {base.elapsed_time(events[i][0]):8.3f} -> "
-                  f"{base.elapsed_time(events[i][1]):8.3f}", file=sys.stderr, flush=True)
+                  f"{base.elapsed_time(events[i][1]):8.3f}   evaluation {base.elapsed_time(events[i][2]):8.3f} -> "
+                  f"{base.elapsed_time(events[i][3]):8.3f}", file=sys.stderr, flush=True)
     if rank == 0:
         total_verts = world * args.steps * n_verts
         flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_verts

@@ -10,11 +10,11 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfacedeform_hip.so")
-SOURCES = ["fd_eval.hip", "fd_build.hip", "fd_nullspace.hip", "fd_capi.hip", "fd_morph.hip", "fd_capture.hip", "fd_sop_host.cpp"]
+SOURCES = ["fd_eval.hip", "fd_eval_shared.hip", "fd_build.hip", "fd_nullspace.hip", "fd_capi.hip", "fd_morph.hip", "fd_capture.hip", "fd_sop_host.cpp"]
 # per-file extras: keep the bf16 MFMA results of the evaluation kernel in VGPRs (the default puts
 # them in AGPRs and pays one v_accvgpr_read per value)
 EXTRA_FLAGS = {"fd_eval.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-HEADERS = [os.path.join(CSRC, "fd_internal.h"), os.path.join(CSRC, "fd_pack.h"), os.path.join(_ROOT, "include", "facedeform_hip.h")]
+HEADERS = [os.path.join(CSRC, "fd_internal.h"), os.path.join(CSRC, "fd_pack.h"), os.path.join(CSRC, "fd_eval_common.h"), os.path.join(_ROOT, "include", "facedeform_hip.h")]
 
 
 def hipcc_path() -> str:

@@ -125,6 +125,8 @@ struct fd_batch {
     // scratch of the shared-rig evaluation (fd_batch_deform_shared_dev): weight tiles + frame records
     void *d_wtiles = nullptr, *d_frames = nullptr;
     size_t cap_wtiles = 0, cap_frames = 0;
+    hipEvent_t packed_ev = nullptr;      // behind the pack kernel of the last shared-rig evaluation (fd_batch_wait_consumed)
+    bool packed_valid = false;
     char err[512] = {0};
 };
 
@@ -1325,6 +1327,7 @@ void fd_batch_destroy(fd_batch *b)
     if (b->d_slots) (void)hipFree(b->d_slots);
     if (b->d_wtiles) (void)hipFree(b->d_wtiles);
     if (b->d_frames) (void)hipFree(b->d_frames);
+    if (b->packed_ev) (void)hipEventDestroy(b->packed_ev);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -1587,8 +1590,18 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
         // any other kernel / precision: the per-frame launches on the shared arrays (same results as fd_deform_dev)
         const float *pin[kMaxBatch], *pd2[kMaxBatch], *ptu[kMaxBatch], *ptv[kMaxBatch], *pnr[kMaxBatch];
         for (int i = 0; i < b->n; ++i) { pin[i] = d_P_in; pd2[i] = d_dist2; ptu[i] = d_tu; ptv[i] = d_tv; pnr[i] = d_nrm; }
-        return fd_batch_deform_dev(b, hip_stream, N, pin, d_P_out, d_dist2 ? pd2 : nullptr, d_falloff_out, d_tu ? ptu : nullptr,
-                                   d_tu ? ptv : nullptr, d_tu ? pnr : nullptr, radius2, falloffrate);
+        rc = fd_batch_deform_dev(b, hip_stream, N, pin, d_P_out, d_dist2 ? pd2 : nullptr, d_falloff_out, d_tu ? ptu : nullptr,
+                                 d_tu ? ptv : nullptr, d_tu ? pnr : nullptr, radius2, falloffrate);
+        // these launches read the models to their end: fd_batch_wait_consumed waits for all of them
+        if (!b->packed_ev && hipEventCreateWithFlags(&b->packed_ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            b->packed_ev = nullptr;
+        }
+        if (rc == FD_OK && b->packed_ev) {
+            if (hipEventRecord(b->packed_ev, stream) != hipSuccess) { (void)hipGetLastError(); if (!rc) rc = FD_E_DEVICE; }
+            b->packed_valid = true;
+        }
+        return rc;
     }
     SharedDeformArgs a{};
     a.N = N; a.P_in = d_P_in; a.dist2 = d_dist2; a.tu = d_tu; a.tv = d_tv; a.nrm = d_nrm;
@@ -1607,6 +1620,7 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
         // (hipFree drains the device: no launch still reads the old scratch)
         if (b->d_wtiles) (void)hipFree(b->d_wtiles);
         if (b->d_frames) (void)hipFree(b->d_frames);
+    if (b->packed_ev) (void)hipEventDestroy(b->packed_ev);
         b->d_wtiles = b->d_frames = nullptr; b->cap_wtiles = b->cap_frames = 0;
         if (hipMalloc(&b->d_wtiles, wb) != hipSuccess || hipMalloc(&b->d_frames, fb) != hipSuccess) {
             (void)hipGetLastError();
@@ -1616,8 +1630,29 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
         b->cap_wtiles = wb; b->cap_frames = fb;
     }
     a.wtiles = b->d_wtiles; a.frames = b->d_frames;
+    if (!b->packed_ev && hipEventCreateWithFlags(&b->packed_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        b->packed_ev = nullptr;
+    }
+    a.packed_ev = b->packed_ev;
+    b->packed_valid = b->packed_ev != nullptr;
     hipError_t e = launch_deform_shared(a, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_shared failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    return FD_OK;
+}
+
+int fd_batch_wait_consumed(fd_batch *b, void *hip_stream)
+{
+    if (!b) return FD_E_INVALID;
+    if (!b->packed_valid) return FD_OK;          // no shared-rig evaluation enqueued: nothing reads the models beyond stream order
+    fd_ctx *c0 = b->ctxs[0];
+    int rc = use_device(c0);
+    if (rc) { batch_err(b, "%s", c0->err); return rc; }
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(c0);
+    if (hipStreamWaitEvent(stream, b->packed_ev, 0) != hipSuccess) {
+        batch_err(b, "fd_batch_wait_consumed: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
+        return FD_E_DEVICE;
+    }
     return FD_OK;
 }
 

@@ -1,0 +1,727 @@
+// fd_eval_shared.hip -- evaluation of ALL frames of a shot in one launch (fd_batch_deform_shared_dev): the frames
+// share the mesh and the rest rig, so phi(|x - c|^2) is formed once per (vertex, centre) and contracted with every
+// frame's weights on the fp16 matrix pipe.  Replaces F runs of the loop body of SOP_FaceDeform::cookMySop,
+// reference src/SOP_FaceDeform.cpp:404-439, for F control-point delta sets on one rest rig (:268-287).
+//
+// Its own translation unit (the file had outgrown one, and the kernel's compile flags can differ from the one-frame
+// kernels').  Accumulators stay in ordinary registers: AGPR accumulators would cost the matrix pipe and the issue
+// port less per instruction (tools/ubench_mfma16.hip: 16.7 vs 18.6 cycles alone, 7.6 vs 10.1 cycles of issue time),
+// but once a kernel uses AGPRs this compiler splits the 256 registers of a two-wave SIMD 128 / 128, and the kernel
+// needs ~150 ordinary registers beside its 96 accumulators (tried: 19 spills, 540 accumulator reads).
+// Built with -ffp-contract=off like the rest (explicit fmas only).
+#include <cstdio>
+#include <cstdlib>
+
+#include <type_traits>
+
+#include "fd_eval_common.h"
+
+namespace fd {
+
+namespace {
+
+// ---- frames that share the mesh AND the rest rig: the contraction on the matrix pipe ------------------
+// The frames of an animated shot, the blendshapes of one head (BASELINE configs 4 and 2-as-benchmarked):
+// the same vertices against the same centres, only the deltas -- hence the weights -- differ.  Then
+//     Delta_f(x_v) = poly_f(x_v) + sum_j phi(|x_v - c_j|^2) w_f[j]
+// is Phi (N x M) times W (M x 3F): phi is formed ONCE per (vertex, centre) -- d2 on the matrix pipe as
+// in k_deform32_tps_mfma, then one v_log_f32 and one multiply -- and the 3F-wide contraction, which is
+// what costs 24 of the 38 vector instructions per 4 pairs in the one-frame kernel, becomes
+// v_mfma_f32_16x16x32_f16 work: north_star's "N x M evaluation recast as a dense GEMM-like contraction".
+// fp16 has 11 significant bits, so both operands go in as two pieces (hi = RN16(v), lo = RN16(v - hi):
+// 22 bits) and a product is three instructions, hi*hi + hi*lo + lo*hi (the dropped lo*lo is 2^-22
+// relative); accumulation is fp32 inside the matrix pipe.  Per-frame weights are scaled by a power of
+// two so that their largest piece sits at 2^13 (fp16 range), undone exactly in the epilogue.
+//
+// Layout: a workgroup of 8 waves (two per SIMD) keeps the centre tiles and the weight tiles of a chunk
+// of centres in LDS -- the whole model at M = 256, F = 32: 12 + 128 KiB -- and walks vertex groups of
+// 512; a wave owns 64 vertices = 4 vertex tiles of 16.  Per 32 centres (one K block) and vertex tile:
+// two d2 instructions, 8 log + 8 multiplies + the fp16 split per lane, and that lane's 8 phi values
+// ARE its B operand (the k-slot <-> centre map is a free choice as long as the weight tiles use the
+// same one: slot 8g + s = centre 32 kb + 16 (s >> 2) + 4 g + (s & 3)).  An output tile is 16 rows
+// x 16 vertices with rows = 4 frames x (x, y, z, unused): lane group g' of the accumulator then holds
+// all three components of frame 4 T + g' for its vertex and writes them as 12 contiguous bytes.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kSharedThreads = 512;
+constexpr size_t kSharedLdsBudget = 158 * 1024;   // of 160 KiB (one workgroup per CU)
+
+// Two row layouts of the output tiles (16 rows x 16 vertices each):
+//   padded (up to 12 frames): tile T holds frames 4 T .. 4 T + 3, row = 4 (frame - 4 T) + component, one row in
+//     four unused -- ceil(F / 4) tiles;
+//   dense (13 frames and more): frames come in blocks of 16 and a block is three tiles, one per component:
+//     tile 3 B + c holds component c of frames 16 B .. 16 B + 15, row = frame - 16 B -- 3 ceil(F / 16) tiles, no
+//     unused rows at F = 16, 32 (6 tiles instead of 8 at 32 frames: a quarter fewer matrix instructions).
+// Either way the 4 x 4 transpose across lane groups in the epilogue leaves every lane with all rows of
+// every tile for ONE vertex.
+constexpr bool shared_dense(int nF) { return nF > 12; }
+constexpr int shared_tiles(int nF) { return shared_dense(nF) ? 3 * ((nF + 15) / 16) : (nF + 3) / 4; }
+constexpr int shared_slots(int nT, bool dense) { return dense ? nT / 3 * 16 : nT * 4; }     // frame records
+
+struct SharedFrame {              // one per frame slot (nT * 4), written by k_pack_shared
+    float inv_scale;              // 2^-k: undoes the scaling of the frame's weights and polynomial
+    int built;                    // terminationtype == 1
+    int pad[2];
+    float *P_out, *falloff_out;   // the frame's outputs (read from LDS inside the frame loop: 64 pointers
+                                  // as kernel arguments end up hoisted into SGPRs all at once and spilled)
+};
+static_assert(sizeof(SharedFrame) == 32, "frame record");
+
+struct SharedOut {                // per-frame outputs (kernel argument)
+    float *P_out[kMaxBatch];
+    float *falloff_out[kMaxBatch];
+};
+
+struct SharedParams {
+    int64_t N;
+    const float *P_in;
+    const float *dist2;
+    const float *tu, *tv, *nrm;
+    float radius2, falloffrate;
+    int ntiles;                   // centre tiles (Mpad / 16)
+    int nkb;                      // K blocks of 32 centres = ceil(ntiles / 2)
+    int nF, nT;                   // frames, output tiles (4 frames each)
+    int kchunk;                   // K blocks staged in LDS at a time
+    const MfmaTileH *ctiles;      // centre tiles of the shared rest rig: the pack kernel's copy, 2 nkb tiles (zeros beyond ntiles)
+    const float *norm;            // normalisation of the shared rest rig (DevModel::norm32), the pack kernel's copy
+    const uint4 *wtiles;          // [nkb][nT][2 (hi, lo)][64 lanes] x 16 B, then the polynomial tiles [nT][64 lanes] x 16 B
+    const SharedFrame *frames;    // [nT * 4]
+    int dbg;                      // FD_SHARED_DBG (diagnostics, tests/tools/shared_eval_timing.py): 1 = no stores, 2 = no K loop
+    int fast;                     // no dist2, no tangent frames, every frame slot in use and built, fd_falloff wanted everywhere:
+                                  // full vertex groups take the branch-free epilogue (below)
+    int stagger;                  // waves 4..7 start this many x 8192 cycles late (resident model only)
+    unsigned long long *stamps;   // diagnostics (FD_SHARED_STAMPS): shader-clock shares of the phases, per wave of workgroup 0
+};
+
+struct SharedSlots {              // the models of the frames (kernel argument of the pack kernel)
+    const Rec32 *rec32[kMaxBatch];
+    const DevModel *model[kMaxBatch];
+};
+
+// weight tiles, polynomial tiles and frame records from the solved models.  grid (nkb, nT), 256 threads (the first 64 write the tile).
+// The polynomial part of a frame (DevModel::poly32: C0 + L.x' + q |x'|^2 per output) rides in the
+// same matrix product as five more "centres" whose phi are (1, x', y', z', |x'|^2): one K = 32
+// instruction per output tile and vertex tile holds all three split products -- lane group 0
+// pairs hi x hi, group 1 lo(vertex) x hi(coefficient), group 2 hi(vertex) x lo(coefficient).
+__global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, const SharedOut out, int nF, int Mpad, int dense,
+                                                      uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles)
+{
+    const int kb = blockIdx.x, T = blockIdx.y, nT = gridDim.y, nkb = gridDim.x;
+    if (T == 0) {
+        // everything else the evaluation reads of the contexts: the rest rig's centre tiles and normalisation.  With
+        // these in the batch's scratch the contexts are free for their next build as soon as THIS kernel has run.
+        constexpr int per = (int)(sizeof(MfmaTileH) / 16);
+        uint4 *dst = wtiles + (size_t)nkb * nT * 128 + (size_t)nT * 64;
+        const int ntiles = Mpad / 16;
+        if ((int)threadIdx.x < 2 * per) {
+            const int tile = 2 * kb + (int)threadIdx.x / per;
+            dst[(size_t)2 * kb * per + threadIdx.x] =
+                tile < ntiles ? reinterpret_cast<const uint4 *>(ctiles + tile)[threadIdx.x % per] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (kb == 0 && threadIdx.x == 255) {
+            const float *nn = slots.model[0]->norm32;
+            dst[(size_t)2 * nkb * per] = make_uint4(__float_as_uint(nn[0]), __float_as_uint(nn[1]), __float_as_uint(nn[2]), __float_as_uint(nn[3]));
+        }
+    }
+    const int lane = threadIdx.x & 63, g = lane >> 4, rho = lane & 15;
+    // row rho of tile T: frame f0 + fi, component c
+    const int nfr = dense ? 16 : 4, f0 = dense ? 16 * (T / 3) : 4 * T;
+    const int fi = dense ? rho : rho >> 2, c = dense ? T % 3 : rho & 3;
+    // scale of each of this tile's frames: largest |weight| or |polynomial coefficient| to [2^13, 2^14).
+    // 256 / nfr lanes per frame, all of a frame's records requested at once.
+    __shared__ float s_scale[16];
+    {
+        const int per = 256 / nfr, q = threadIdx.x / per, l = threadIdx.x % per;
+        const int f = f0 + q;
+        float m = 0.f;
+        if (f < nF) {
+            const Rec32 *r = slots.rec32[f];
+            for (int j = l; j < Mpad; j += per) m = fmaxf(m, fmaxf(fabsf(r[j].wx), fmaxf(fabsf(r[j].wy), fabsf(r[j].wz))));
+            if (l < 15) m = fmaxf(m, fabsf(slots.model[f]->poly32[l]));
+        }
+        for (int off = per / 2; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));      // per is 16 or 64: inside a wave
+        if (l == 0) {
+            int k = 0;
+            if (m > 0.f && m < INFINITY) k = 13 - (__builtin_amdgcn_frexp_expf(m) - 1);
+            k = k < -100 ? -100 : (k > 100 ? 100 : k);
+            s_scale[q] = ldexpf(1.f, k);
+            if (kb == 0 && (!dense || T % 3 == 0)) {
+                SharedFrame fr;
+                fr.inv_scale = ldexpf(1.f, -k);
+                fr.built = (f < nF && slots.model[f]->terminationtype == 1) ? 1 : 0;
+                fr.pad[0] = fr.pad[1] = 0;
+                fr.P_out = f < nF ? out.P_out[f] : nullptr;
+                fr.falloff_out = f < nF ? out.falloff_out[f] : nullptr;
+                frames[f] = fr;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int f = f0 + fi;
+    const float sc = s_scale[fi];
+    f16x8 hi, lo;
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+        const int centre = 32 * kb + 16 * (sidx >> 2) + 4 * g + (sidx & 3);
+        float w = 0.f;
+        if (f < nF && c < 3 && centre < Mpad) {
+            const Rec32 r = slots.rec32[f][centre];
+            w = (c == 0 ? r.wx : (c == 1 ? r.wy : r.wz)) * sc;
+        }
+        const _Float16 h = (_Float16)w;
+        hi[sidx] = h;
+        lo[sidx] = (_Float16)(w - (float)h);
+    }
+    uint4 *dst = wtiles + ((size_t)kb * nT + T) * 128;
+    dst[lane] = __builtin_bit_cast(uint4, hi);
+    dst[64 + lane] = __builtin_bit_cast(uint4, lo);
+    if (kb == 0) {
+        // polynomial tile of output tile T: k-slot s < 5 of lane group g carries coefficient s
+        // ({C0, Lx, Ly, Lz, q}) of row rho -- hi piece in groups 0 and 1, lo piece in group 2
+        f16x8 pt;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            float w = 0.f;
+            if (f < nF && c < 3 && sidx < 5 && g < 3) w = slots.model[f]->poly32[5 * c + sidx] * sc;
+            const _Float16 h = (_Float16)w;
+            pt[sidx] = g == 2 ? (_Float16)(w - (float)h) : h;
+        }
+        wtiles[(size_t)nkb * nT * 128 + (size_t)T * 64 + lane] = __builtin_bit_cast(uint4, pt);
+    }
+}
+
+// fp32 pair -> its two fp16 pieces, packed: hi = RN16(v), lo = RN16(v - hi).  One v_cvt_pk_f16_f32 and
+// two mixed-precision fmas that subtract the fp16 piece from the fp32 value and round the
+// remainder to fp16 in the same instruction (v_fma_mixlo/hi_f16 write one half of the destination
+// and keep the other) -- three instructions for two values, no unpacking, no repacking.
+__device__ __forceinline__ void split_pair_f16(float v0, float v1, unsigned &hi, unsigned &lo)
+{
+    const f16x2 hh = __builtin_convertvector((f32x2){v0, v1}, f16x2);
+    hi = __builtin_bit_cast(unsigned, hh);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(v1));
+    lo = l;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+// one vertex position as a single 12-byte store (dword-aligned: global_store_dwordx3)
+struct __attribute__((packed, aligned(4))) Pos3 { float x, y, z; };
+__device__ __forceinline__ void store_pos3(Pos3 FD_GLOBAL *dst, float x, float y, float z)
+{
+    dst->x = x; dst->y = y; dst->z = z;      // member-wise: a struct assignment through an address-space pointer does not compile on the host pass
+}
+
+template <int NT, bool DENSE>
+__global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_deform32_tps_shared(const SharedParams p, int ngroups)
+{
+    constexpr int TV = 4;                        // vertex tiles per wave
+    constexpr int kSlots = shared_slots(NT, DENSE);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [frame records kSlots][polynomial tiles NT*64 x 16 B][centre tiles kchunk*2][weight tiles kchunk*NT*2*64 x 16 B]
+    SharedFrame *s_frames = reinterpret_cast<SharedFrame *>(smem);
+    uint4 *s_poly = reinterpret_cast<uint4 *>(smem + sizeof(SharedFrame) * (size_t)kSlots);
+    MfmaTileH *s_ct = reinterpret_cast<MfmaTileH *>(s_poly + NT * 64);
+    uint4 *s_w = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(s_ct) + sizeof(MfmaTileH) * (size_t)(2 * p.kchunk));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler should know it
+    const int g = lane >> 4, j = lane & 15;
+    const float n0 = p.norm[0], n1 = p.norm[1], n2 = p.norm[2];
+    const float inv_s = p.norm[3];
+    const bool resident = p.nkb <= p.kchunk;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int kb0, int nk) {
+        __syncthreads();
+        {   // centre tiles 2 kb0 .. 2 (kb0 + nk) - 1; beyond ntiles: zeros
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.ctiles + 2 * kb0);
+            uint4 *dst = reinterpret_cast<uint4 *>(s_ct);
+            const int per = (int)(sizeof(MfmaTileH) / 16);
+            for (int q = tid; q < 2 * nk * per; q += kSharedThreads) dst[q] = src[q];
+        }
+        {
+            const uint4 *src = p.wtiles + (size_t)kb0 * NT * 128;
+            const int n16 = nk * NT * 128;
+            for (int q = tid; q < n16; q += kSharedThreads) s_w[q] = src[q];
+        }
+        __syncthreads();
+    };
+
+    // The frame records (scale, status, output pointers: 8 dwords x 4 NT frames) live across the
+    // lanes of NT / 2 registers for the whole kernel; the epilogue picks a frame's scalars out with
+    // v_readlane -- no memory round trip per frame.  (From LDS every frame paid an LDS read behind
+    // the other wave's operand traffic; through the scalar cache 800 cycles per pair of frames; as
+    // kernel arguments the compiler hoists 32 x 6 scalars above the K loop and spills them.)
+    constexpr int kTabRegs = (kSlots * 8 + 63) / 64;
+    unsigned tab[kTabRegs];
+#pragma unroll
+    for (int q = 0; q < kTabRegs; ++q) {
+        const int idx = 64 * q + lane;
+        tab[q] = idx < kSlots * 8 ? reinterpret_cast<const unsigned *>(p.frames)[idx] : 0u;
+    }
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.frames);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_frames);
+        for (int q = tid; q < kSlots * (int)(sizeof(SharedFrame) / 16); q += kSharedThreads) dst[q] = src[q];
+        const uint4 *psrc = p.wtiles + (size_t)p.nkb * NT * 128;
+        for (int q = tid; q < NT * 64; q += kSharedThreads) s_poly[q] = psrc[q];
+    }
+    if (resident) {
+        stage(0, p.nkb);
+        // The two waves of a SIMD (w and w + 4) run the same program: left alone they reach their
+        // logarithm phase together and their matrix phase together, and each phase then has one
+        // pipe idle.  A start-up delay for the second half puts one wave's vector work beside
+        // the other's matrix work (no barrier follows while the model is resident).
+        if (wave >= 4) {
+            __builtin_amdgcn_s_sleep(12);
+            for (int q = 0; q < (p.stagger & 0xff); ++q) __builtin_amdgcn_s_sleep(127);
+        }
+        // experiment: workgroups start in four phases ((stagger >> 8) x 8128 cycles apart)
+        for (int q = 0; q < (p.stagger >> 8) * (int)(blockIdx.x & 3); ++q) __builtin_amdgcn_s_sleep(127);
+    } else {
+        __syncthreads();
+    }
+
+    const bool stamp = p.stamps != nullptr && blockIdx.x == 0;
+    unsigned long long st_prev = 0, st_acc[5] = {0, 0, 0, 0, 0};
+#define FD_SSTAMP(K) if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[K] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+    if (stamp) st_prev = __builtin_amdgcn_s_memtime();
+    // Inputs of a vertex group as lane (g, j) holds them: the four vertices (vt, j).  The NEXT group's
+    // are requested before this group's stores go out: vector memory operations of a wave retire in
+    // issue order, so a load queued behind the epilogue's 64 stores would wait for all of them.
+    struct GroupRaw { float p[TV][3]; float d2[TV]; };
+    auto load_raw = [&](int grp_, auto fastTag) {
+        constexpr bool FAST = decltype(fastTag)::value;
+        GroupRaw r;
+        const int64_t vb = ((int64_t)grp_ * (kSharedThreads / 64) + wave) * (16 * TV);
+#pragma unroll
+        for (int t = 0; t < TV; ++t) {
+            const int64_t vi = vb + 16 * t + j;
+            const int64_t vc = vi < p.N ? vi : p.N - 1;
+            r.p[t][0] = p.P_in[3 * vc]; r.p[t][1] = p.P_in[3 * vc + 1]; r.p[t][2] = p.P_in[3 * vc + 2];
+            if constexpr (FAST) r.d2[t] = 0.f; else r.d2[t] = p.dist2 ? p.dist2[vc] : 0.f;
+        }
+        return r;
+    };
+    // "These loaded registers are needed now": placed in straight-line code right after a group's stores, it lets the
+    // compiler count exactly how many stores follow the loads and wait with that count; consumed for the first time at
+    // the top of the next iteration -- where the path from the prologue joins -- it would have to assume none.
+    auto settle = [&](const GroupRaw &r) {
+        asm volatile("" :: "v"(r.p[0][0]), "v"(r.p[0][1]), "v"(r.p[0][2]), "v"(r.p[1][0]), "v"(r.p[1][1]), "v"(r.p[1][2]),
+                           "v"(r.p[2][0]), "v"(r.p[2][1]), "v"(r.p[2][2]), "v"(r.p[3][0]), "v"(r.p[3][1]), "v"(r.p[3][2]));
+    };
+    GroupRaw nxt = load_raw(blockIdx.x < (unsigned)ngroups ? (int)blockIdx.x : 0, std::false_type{});
+    settle(nxt);
+    // One vertex group (512 vertices of the workgroup, 64 of this wave).  FAST: the group is full and the
+    // launch has no gate, fall-off, tangent frames or unbuilt frames -- the epilogue is then straight-line
+    // code in which every lane issues every store.  That matters beyond the instruction count: with no
+    // branch that could skip a store, the compiler KNOWS 64 stores follow the next group's loads and waits
+    // for those loads with vmcnt(63); with conditional stores it has to assume none were issued, waits with
+    // vmcnt(0), and every wave sits out the drain of its own 32 KB of stores (all waves at once: the whole
+    // chip alternated between a matrix phase with HBM idle and a store phase with the pipes idle).
+    auto do_group = [&](int grp, auto fastTag) {
+        constexpr bool FAST = decltype(fastTag)::value;
+        const int64_t vbase = ((int64_t)grp * (kSharedThreads / 64) + wave) * (16 * TV);
+        // The two waves of a SIMD (w, w + 4) take the higher issue priority in turn, group by group: left to the
+        // default (oldest first) waves 0..3 finish all their groups a quarter of the kernel early and the others run
+        // the rest with nobody to fill their stalls.
+        if ((((grp / (int)gridDim.x) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        const GroupRaw cur = nxt;
+        // this lane's own vertex in the epilogue is (vt = g, j): one of the four it has loaded
+        auto pick = [&](float a0, float a1, float a2, float a3) {        // two levels of v_cndmask, no branches
+            const float lo = (g & 1) ? a1 : a0, hi = (g & 1) ? a3 : a2;
+            return (g & 2) ? hi : lo;
+        };
+        const float pos[3] = {pick(cur.p[0][0], cur.p[1][0], cur.p[2][0], cur.p[3][0]), pick(cur.p[0][1], cur.p[1][1], cur.p[2][1], cur.p[3][1]),
+                              pick(cur.p[0][2], cur.p[1][2], cur.p[2][2], cur.p[3][2])};
+        const float own_d2 = pick(cur.d2[0], cur.d2[1], cur.d2[2], cur.d2[3]);
+        // every lane group holds vertex (vt, j): the d2 operand needs one coordinate of it per lane
+        // group, the polynomial operand all of them
+        f16x4 bop[TV];
+        f32x4 acc[NT][TV];
+        bool lane_live = false;
+#pragma unroll
+        for (int t = 0; t < TV; ++t) {
+            const int64_t vi = vbase + 16 * t + j;
+            const float x = (cur.p[t][0] - n0) * inv_s, y = (cur.p[t][1] - n1) * inv_s, z = (cur.p[t][2] - n2) * inv_s;
+            const float d2v = cur.d2[t];
+            if constexpr (FAST) lane_live = true; else lane_live |= (vi < p.N) && !(d2v > p.radius2);
+            const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+            const float v2 = g == 0 ? -2.f * x : (g == 1 ? -2.f * y : (g == 2 ? -2.f * z : xx));
+            const _Float16 h = (_Float16)v2;
+            const _Float16 l = (_Float16)(v2 - (float)h);
+            const _Float16 one = (_Float16)1.0f;
+            bop[t] = g < 3 ? (f16x4){h, l, h, l} : (f16x4){one, one, h, l};
+            // polynomial operand: k-slots {1, x', y', z', |x'|^2}: hi pieces in lane groups 0 and 2,
+            // lo pieces in group 1 (against the coefficients' hi), nothing in group 3
+            unsigned xyh, xyl, zxh, zxl;
+            split_pair_f16(x, y, xyh, xyl);
+            split_pair_f16(z, xx, zxh, zxl);
+            u32x4 pb;
+            if (g == 1) pb = (u32x4){xyl << 16, (xyl >> 16) | (zxl << 16), zxl >> 16, 0u};                  // {0, xl, yl, zl, xxl}
+            else pb = (u32x4){0x3c00u | (xyh << 16), (xyh >> 16) | (zxh << 16), zxh >> 16, 0u};            // {1, xh, yh, zh, xxh}
+            if (g == 3) pb = (u32x4){0u, 0u, 0u, 0u};
+            const f16x8 pbv = __builtin_bit_cast(f16x8, pb);
+#pragma unroll
+            for (int T = 0; T < NT; ++T)
+                acc[T][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s_poly[T * 64 + lane]), pbv, zero4, 0, 0, 0);
+        }
+        const bool wave_work = FAST ? true : __any(lane_live);
+        if constexpr (FAST) {
+            // The next group's positions are requested HERE, a whole K loop before the stores of this group: a wave
+            // has at most 63 vector-memory operations in flight and they retire in order, so loads requested just
+            // before the epilogue's stores would hold up the last of them until their own data (queued behind a
+            // chip-wide burst of stores) has come back -- every epilogue then lasts one loaded-memory round trip.
+            const int gn = grp + (int)gridDim.x;
+            nxt = load_raw(gn < ngroups ? gn : grp, fastTag);
+        }
+        FD_SSTAMP(0)
+
+        // phi of K block kb (32 centres) for the wave's four vertex tiles, split into fp16 pieces: the B operands
+        auto phi_block = [&](int kb, u32x4 (&xh)[TV], u32x4 (&xl)[TV]) {
+            const f16x4 aopA = *reinterpret_cast<const f16x4 *>(&s_ct[2 * kb].a[lane][0]);
+            const f16x4 aopB = *reinterpret_cast<const f16x4 *>(&s_ct[2 * kb + 1].a[lane][0]);
+#pragma unroll
+            for (int t = 0; t < TV; ++t) {
+                const f32x4 da = __builtin_amdgcn_mfma_f32_16x16x16f16(aopA, bop[t], zero4, 0, 0, 0);
+                const f32x4 db = __builtin_amdgcn_mfma_f32_16x16x16f16(aopB, bop[t], zero4, 0, 0, 0);
+                unsigned h, l;
+                split_pair_f16(d2_log_d2(da[0]), d2_log_d2(da[1]), h, l); xh[t][0] = h; xl[t][0] = l;
+                split_pair_f16(d2_log_d2(da[2]), d2_log_d2(da[3]), h, l); xh[t][1] = h; xl[t][1] = l;
+                split_pair_f16(d2_log_d2(db[0]), d2_log_d2(db[1]), h, l); xh[t][2] = h; xl[t][2] = l;
+                split_pair_f16(d2_log_d2(db[2]), d2_log_d2(db[3]), h, l); xh[t][3] = h; xl[t][3] = l;
+            }
+        };
+        // acc += W(kb) x phi(kb): three split products per output tile and vertex tile
+        auto contract = [&](int kb, const u32x4 (&xh)[TV], const u32x4 (&xl)[TV]) {
+            const uint4 *wk = s_w + (size_t)kb * NT * 128 + lane;
+#pragma unroll
+            for (int T = 0; T < NT; ++T) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, wk[T * 128]), al = __builtin_bit_cast(f16x8, wk[T * 128 + 64]);
+#pragma unroll
+                for (int t = 0; t < TV; ++t) {
+                    const f16x8 vh = __builtin_bit_cast(f16x8, xh[t]), vl = __builtin_bit_cast(f16x8, xl[t]);
+                    acc[T][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vh, acc[T][t], 0, 0, 0);
+                    acc[T][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, vh, acc[T][t], 0, 0, 0);
+                    acc[T][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, vl, acc[T][t], 0, 0, 0);
+                }
+            }
+        };
+        for (int kb0 = 0; kb0 < p.nkb; kb0 += p.kchunk) {
+            const int nk = p.nkb - kb0 < p.kchunk ? p.nkb - kb0 : p.kchunk;
+            if (!resident) stage(kb0, nk);
+            if ((!FAST && !wave_work) || (p.dbg & 2)) continue;
+            // Software pipeline over the K blocks: while the matrix pipe contracts block kb with the weights, the
+            // vector unit forms phi of block kb + 1 (two d2 instructions per vertex tile, 8 logarithms, 8 multiplies
+            // and the fp16 split per lane).  Inside one wave the two would otherwise run back to back -- the
+            // logarithms with the matrix pipe idle, then 72 matrix instructions with the vector unit idle -- and two
+            // waves per SIMD running the same program do not interleave well enough to hide either.
+            u32x4 bh[TV], bl[TV];
+            phi_block(0, bh, bl);
+            for (int kb = 0; kb + 1 < nk; ++kb) {
+                u32x4 nbh[TV], nbl[TV];
+                phi_block(kb + 1, nbh, nbl);
+                contract(kb, bh, bl);
+                // issue order inside this block: one matrix instruction, then the vector work that fits under it
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);      // transcendental
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // VALU
+                }
+#pragma unroll
+                for (int q = 32; q < 8 + NT * TV * 3; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+                // (unrolling by two with the buffers swapped instead of these 32 copies spills: 109 registers)
+#pragma unroll
+                for (int t = 0; t < TV; ++t) { bh[t] = nbh[t]; bl[t] = nbl[t]; }
+            }
+            contract(nk - 1, bh, bl);
+        }
+
+        FD_SSTAMP(1)
+        // ---- epilogue.  The accumulators hold, in lane group g, frame 4 T + g for the four vertex
+        // tiles; a 4 x 4 transpose across the lane groups (two v_permlane32_swap + two
+        // v_permlane16_swap per four registers) turns that into vertex tile g for the four frames
+        // of the tile: every lane then owns ONE vertex (vbase + lane), does the per-vertex work
+        // (gate, fall-off, tangent axes) once, and a frame's 64 positions leave as one contiguous
+        // 768-byte store.  All transposes first, in place (acc[T][k][c] becomes row 4 k + c of tile T for
+        // this lane's vertex: padded layout frame 4 T + k, component c; dense layout component T % 3 of
+        // frame 16 (T / 3) + 4 k + c), while the wave is still converged.
+#pragma unroll
+        for (int T = 0; T < NT; ++T) {
+#pragma unroll
+            for (int c = 0; c < (DENSE ? 4 : 3); ++c) {
+                // X_k[g] = (rows 4 g .., vertex tile k)  ->  Y_k[g] = (rows 4 k .., vertex tile g)
+                const u32x2 s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[T][0][c]), __float_as_uint(acc[T][2][c]), false, false);
+                const u32x2 s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[T][1][c]), __float_as_uint(acc[T][3][c]), false, false);
+                const u32x2 y01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                const u32x2 y23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                acc[T][0][c] = __uint_as_float(y01[0]); acc[T][1][c] = __uint_as_float(y01[1]);
+                acc[T][2][c] = __uint_as_float(y23[0]); acc[T][3][c] = __uint_as_float(y23[1]);
+            }
+        }
+        // the reference's order: gate -> tangent projection -> fall-off -> add (src/SOP_FaceDeform.cpp:405-438)
+        const int64_t i = vbase + lane;
+        const bool inb = i < p.N;
+        const int64_t ic = inb ? i : p.N - 1;
+        const bool gated = own_d2 > p.radius2;
+        const unsigned off12 = 12u * (unsigned)lane, off4 = 4u * (unsigned)lane;   // byte offsets inside the wave's 64-vertex window
+        if constexpr (!FAST) {
+            const int gn = grp + (int)gridDim.x;
+            nxt = load_raw(gn < ngroups ? gn : grp, fastTag);
+        }
+        FD_SSTAMP(2)
+        if constexpr (FAST) {
+            // gate open, fall-off 1 (pow(1 - 0, rate): no dist2 attribute), no tangent frames: P + d * 1.  The sum the
+            // matrix pipe holds is 2^k d: one fma with the exact 2^-k gives the same bits as (d * 1) + P.
+            // 32 position stores + 16 fall-off stores (two frames each) = 48 operations per group: with the
+            // next group's loads they fit the 63 a wave may have in flight, so the epilogue never waits for an
+            // acknowledgement.  fd_falloff of frames (fs, fs + 1): lanes 0..31 write vertices 2 l, 2 l + 1 of frame
+            // fs, lanes 32..63 the same of frame fs + 1 (8 bytes each: two 256-byte rows per instruction).
+            const f32x2 ones = {1.f, 1.f};
+            const unsigned off8 = 8u * (unsigned)(lane & 31);
+#pragma unroll
+            for (int fs = 0; fs < kSlots; ++fs) {
+                const float inv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs) / 64], (8 * fs) % 64));
+                const uint64_t pout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 5) / 64], (8 * fs + 5) % 64) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 4) / 64], (8 * fs + 4) % 64);
+                float d0, d1, d2c;
+                if constexpr (DENSE) {
+                    const int B = fs / 16, k = (fs % 16) / 4, r = fs % 4;
+                    d0 = acc[3 * B][k][r]; d1 = acc[3 * B + 1][k][r]; d2c = acc[3 * B + 2][k][r];
+                } else {
+                    const int T = fs / 4, k = fs % 4;
+                    d0 = acc[T][k][0]; d1 = acc[T][k][1]; d2c = acc[T][k][2];
+                }
+                Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)((char FD_GLOBAL *)(pout + 12ull * (uint64_t)vbase) + off12);
+                if (fs % 2 == 0) {
+                    const uint64_t fa = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 7) / 64], (8 * fs + 7) % 64) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 6) / 64], (8 * fs + 6) % 64);
+                    const int fs1 = fs + 1 < kSlots ? fs + 1 : fs;
+                    const uint64_t fb = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs1 + 7) / 64], (8 * fs1 + 7) % 64) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs1 + 6) / 64], (8 * fs1 + 6) % 64);
+                    const uint64_t fo = (lane < 32 ? fa : fb) + 4ull * (uint64_t)vbase;
+                    *(f32x2 FD_GLOBAL *)((char FD_GLOBAL *)fo + off8) = ones;
+                }
+                store_pos3(dstP, __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]), __builtin_fmaf(d2c, inv, pos[2]));
+            }
+            settle(nxt);
+            FD_SSTAMP(3)
+            return;
+        }
+        if (inb && gated) {
+            // B2: a gated vertex keeps its position (and no fd_falloff entry is written)
+            for (int f = 0; f < p.nF; ++f) {
+                float *dstp = s_frames[f].P_out;
+                if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
+            }
+        }
+        float fall = 1.f;
+        float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+        const bool doit = inb && !gated;
+        if (doit) {
+            if (p.dist2 != nullptr || !(p.radius2 != 0.f)) {
+                const float q = fminf(own_d2 / p.radius2, 1.f);
+                fall = powf(1.f - q, p.falloffrate);
+            }
+            if (p.tu) {
+                // project_to_tangents (src/SOP_FaceDeform.hpp:28-41): the two axes depend on the vertex only
+                float u[3] = {p.tu[3 * ic], p.tu[3 * ic + 1], p.tu[3 * ic + 2]};
+                float v[3] = {p.tv[3 * ic], p.tv[3 * ic + 1], p.tv[3 * ic + 2]};
+                float n[3] = {p.nrm[3 * ic], p.nrm[3 * ic + 1], p.nrm[3 * ic + 2]};
+                normalize3(u[0], u[1], u[2]);
+                normalize3(v[0], v[1], v[2]);
+                normalize3(n[0], n[1], n[2]);
+                float gm[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gm[r][c] = u[r] * u[c] + v[r] * v[c] + n[r] * n[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    a1[c] = u[0] * gm[0][c] + u[1] * gm[1][c] + u[2] * gm[2][c];
+                    a2[c] = v[0] * gm[0][c] + v[1] * gm[1][c] + v[2] * gm[2][c];
+                }
+                normalize3(a1[0], a1[1], a1[2]);
+                normalize3(a2[0], a2[1], a2[2]);
+            }
+        }
+#pragma unroll
+        for (int fs = 0; fs < kSlots; ++fs) {
+            {
+                const int f = fs;                    // wave-uniform, compile-time after unrolling
+                if (f >= p.nF) continue;
+                // word w of frame f sits in lane (8 f + w) % 64 of tab[(8 f + w) / 64]
+                const float inv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f) / 64], (8 * f) % 64));
+                const bool built = __builtin_amdgcn_readlane((int)tab[(8 * f + 1) / 64], (8 * f + 1) % 64) != 0;
+                const uint64_t pout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 5) / 64], (8 * f + 5) % 64) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 4) / 64], (8 * f + 4) % 64);
+                const uint64_t fout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 7) / 64], (8 * f + 7) % 64) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 6) / 64], (8 * f + 6) % 64);
+                if (!doit) continue;
+                // scalar base (the wave's window of the frame's arrays) + a 32-bit lane offset
+                Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)((char FD_GLOBAL *)(pout + 12ull * (uint64_t)vbase) + off12);
+                if (!built) {
+                    if (pout != (uint64_t)p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
+                    continue;
+                }
+                // 2^-k is exact: disp is the sum the matrix pipe accumulated, polynomial included
+                float disp[3];
+                if constexpr (DENSE) {
+                    const int B = fs / 16, k = (fs % 16) / 4, r = fs % 4;
+                    disp[0] = acc[3 * B][k][r] * inv; disp[1] = acc[3 * B + 1][k][r] * inv; disp[2] = acc[3 * B + 2][k][r] * inv;
+                } else {
+                    const int T = fs / 4, k = fs % 4;
+                    disp[0] = acc[T][k][0] * inv; disp[1] = acc[T][k][1] * inv; disp[2] = acc[T][k][2] * inv;
+                }
+                if (p.dbg & 1) continue;         // diagnostics: everything but the stores
+                if (p.tu) {
+                    const float da1 = disp[0] * a1[0] + disp[1] * a1[1] + disp[2] * a1[2];
+                    const float da2 = disp[0] * a2[0] + disp[1] * a2[1] + disp[2] * a2[2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
+                }
+                if (fout) *(float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4) = fall;
+                store_pos3(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+            }
+        }
+        FD_SSTAMP(3)
+    };
+    int grp = blockIdx.x;
+    // a frame whose build failed passes the mesh through: general path (the status words sit in the frame table)
+    bool built_here = true;
+#pragma unroll
+    for (int q = 0; q < kTabRegs; ++q) {
+        const int idx = 64 * q + lane;
+        if (idx < kSlots * 8 && (idx & 7) == 1) built_here = built_here && tab[q] != 0u;
+    }
+    if (p.fast && __all(built_here)) {
+        const int nfull = (int)(p.N / kSharedThreads);       // groups in which every wave's 64 vertices exist
+        for (; grp < nfull; grp += gridDim.x) do_group(grp, std::true_type{});
+    }
+    for (; grp < ngroups; grp += gridDim.x) do_group(grp, std::false_type{});
+    if (stamp && lane == 0) {
+        for (int q = 0; q < 4; ++q) p.stamps[wave * 8 + q] = st_acc[q];
+    }
+#undef FD_SSTAMP
+}
+
+}  // namespace
+
+// Frames of one mesh and one rest rig (SharedDeformArgs): pack the weight tiles, then one launch.
+hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
+{
+    if (a.N <= 0 || a.nF <= 0) return hipSuccess;
+    if (a.nF > kMaxBatch || a.Mpad % 16 != 0) return hipErrorInvalidValue;
+    const int ntiles = a.Mpad / 16, nkb = (ntiles + 1) / 2;
+    const bool dense = shared_dense(a.nF);
+    const int nT = shared_tiles(a.nF);
+    SharedSlots slots{};
+    SharedOut out{};
+    for (int f = 0; f < kMaxBatch; ++f) {
+        const int q = f < a.nF ? f : 0;
+        slots.rec32[f] = a.rec32[q]; slots.model[f] = a.model[q];
+        out.P_out[f] = a.P_out[q]; out.falloff_out[f] = a.falloff_out ? a.falloff_out[q] : nullptr;
+    }
+    hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
+                       (SharedFrame *)a.frames, a.ctiles);
+    if (a.packed_ev) {
+        hipError_t e = hipEventRecord(a.packed_ev, stream);
+        if (e != hipSuccess) return e;
+    }
+    SharedParams p{};
+    p.N = a.N; p.P_in = a.P_in; p.dist2 = a.dist2; p.tu = a.tu; p.tv = a.tv; p.nrm = a.nrm;
+    p.radius2 = a.radius2; p.falloffrate = a.falloffrate;
+    p.ntiles = ntiles; p.nkb = nkb; p.nF = a.nF; p.nT = nT;
+    {
+        const uint4 *copy = (const uint4 *)a.wtiles + (size_t)nkb * nT * 128 + (size_t)nT * 64;
+        p.ctiles = reinterpret_cast<const MfmaTileH *>(copy);
+        p.norm = reinterpret_cast<const float *>(copy + (size_t)2 * nkb * (sizeof(MfmaTileH) / 16));
+    }
+    p.wtiles = (const uint4 *)a.wtiles; p.frames = (const SharedFrame *)a.frames;
+    { static const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
+    {
+        static const bool no_fast = getenv("FD_SHARED_NO_FAST") != nullptr;       // A/B: general epilogue everywhere
+        bool fast = !no_fast && (p.dbg & 1) == 0 && a.dist2 == nullptr && a.tu == nullptr && a.radius2 > 0.f && a.falloff_out != nullptr &&
+                    a.nF == shared_slots(nT, dense);
+        for (int f = 0; fast && f < a.nF; ++f) fast = a.falloff_out[f] != nullptr && a.P_out[f] != nullptr;
+        p.fast = fast ? 1 : 0;
+    }
+    { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+    static unsigned long long *d_stamps = nullptr;
+    static const bool want_stamps = getenv("FD_SHARED_STAMPS") != nullptr;
+    if (want_stamps && !d_stamps) (void)hipMalloc((void **)&d_stamps, 64 * sizeof(unsigned long long));
+    p.stamps = want_stamps ? d_stamps : nullptr;
+    { static const bool e = getenv("FD_SHARED_STAMPS_GENERAL") != nullptr; if (want_stamps && e) p.fast = 0; }
+    const size_t fixed = sizeof(SharedFrame) * (size_t)shared_slots(nT, dense) + (size_t)nT * 64 * 16;
+    const size_t per_kb = 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
+    int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);
+    if (kchunk < 1) return hipErrorInvalidValue;
+    if (kchunk > nkb) kchunk = nkb;
+    p.kchunk = kchunk;
+    const size_t lds = fixed + per_kb * (size_t)kchunk;
+    const int64_t per = kSharedThreads / 64 * 64;          // vertices per workgroup and group
+    const int64_t ngroups = (a.N + per - 1) / per;
+    // One persistent workgroup per CU (150 KiB of LDS, two 240-register waves per SIMD: nothing else
+    // fits beside it).  FD_SHARED_CUS < 256 leaves the other CUs to whatever runs on other streams --
+    // the builds of the next frames in a pipeline (bench.py).
+    static const int64_t max_wgs = [] {
+        const char *e = getenv("FD_SHARED_CUS");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v > 0 && v < (long)kNumCU ? v : (long)kNumCU);
+    }();
+    const unsigned grid = (unsigned)(ngroups < max_wgs ? ngroups : max_wgs);
+#define FD_SHARED_CASE(NTV, DNS)                                                                                     \
+    {                                                                                                                \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared<NTV, DNS>,                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+            if (e != hipSuccess) return e;                                                                           \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_deform32_tps_shared<NTV, DNS>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
+    }
+    if (dense) {
+        if (nT == 3) FD_SHARED_CASE(3, true)
+        else if (nT == 6) FD_SHARED_CASE(6, true)
+        else return hipErrorInvalidValue;
+    } else {
+        if (nT == 1) FD_SHARED_CASE(1, false)
+        else if (nT == 2) FD_SHARED_CASE(2, false)
+        else if (nT == 3) FD_SHARED_CASE(3, false)
+        else return hipErrorInvalidValue;
+    }
+#undef FD_SHARED_CASE
+    if (want_stamps && d_stamps) {
+        unsigned long long h[64];
+        if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[shared stamps, shader cycles per wave of workgroup 0: load+poly | K loop | transposes | per-vertex + frames]\n");
+            for (int w = 0; w < 8; ++w)
+                fprintf(stderr, "   wave %d: %8llu %8llu %8llu %8llu\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3]);
+        }
+    }
+    return hipGetLastError();
+}
+
+size_t shared_wtile_bytes(int Mpad, int nF)
+{
+    const int nkb = (Mpad / 16 + 1) / 2, nT = shared_tiles(nF);
+    // weight tiles + polynomial tiles + the rest rig's centre tiles (2 nkb) and normalisation (16 B)
+    return (size_t)nkb * nT * 128 * 16 + (size_t)nT * 64 * 16 + (size_t)2 * nkb * sizeof(MfmaTileH) + 16;
+}
+size_t shared_frame_bytes(int nF)
+{
+    return sizeof(SharedFrame) * (size_t)shared_slots(shared_tiles(nF), shared_dense(nF));
+}
+
+}  // namespace fd

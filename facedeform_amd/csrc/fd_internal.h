@@ -216,6 +216,8 @@ struct SharedDeformArgs {
     float *P_out[kMaxBatch];
     float *const *falloff_out;            // nF entries or nullptr
     void *wtiles, *frames;                // scratch of shared_wtile_bytes / shared_frame_bytes
+    hipEvent_t packed_ev;                 // recorded once the pack kernel has read the models (may be null): from then on the
+                                          // launch reads nothing of the contexts -- their next build may start
 };
 hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream);
 size_t shared_wtile_bytes(int Mpad, int nF);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 4   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo (additions only) */
+#define FD_ABI_VERSION 5   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed (additions only) */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -321,6 +321,14 @@ int fd_batch_deform_shared_dev(fd_batch *batch, void *hip_stream, int64_t N, con
                                float *const *d_P_out, const float *d_dist2, float *const *d_falloff_out,
                                const float *d_tu, const float *d_tv, const float *d_nrm, float radius2,
                                float falloffrate);
+/* Makes hip_stream (NULL: context 0's) wait until the batch's last fd_batch_deform_shared_dev no longer reads the
+ * contexts' models: that launch copies what it needs of them (weights as fp16 tiles, the rest rig's centre tiles)
+ * into the batch's own scratch with a first small kernel, and the evaluation proper reads only that copy.  A pipeline
+ * that cooks group after group on the same contexts puts this in front of the next fd_batch_set_points_dev /
+ * fd_batch_build_async instead of waiting for the evaluation itself: the next models are assembled and solved while
+ * the current ones are still being evaluated.  (The output arrays ARE still being written: they stay the caller's to
+ * order.)  No-op when no shared-rig evaluation has been enqueued on the batch. */
+int fd_batch_wait_consumed(fd_batch *batch, void *hip_stream);
 
 /* ---- dist2 producer (next row N2) ---------------------------------------------
  * The per-point body of ProximityCapture::capture (src/capture.cpp:58-97) on the

@@ -137,3 +137,49 @@ def test_shared_needs_one_rest_rig_and_falls_back_for_other_kernels(hip_lib):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     _close(engines, batch)
+
+
+def test_contexts_may_be_rebuilt_once_the_launch_has_its_copy(hip_lib, oracle):
+    """fd_batch_wait_consumed: the shared-rig launch reads the contexts' models only in its first small kernel (weights,
+    centre tiles and normalisation go into the batch's scratch).  A lane that waits for that point -- not for the
+    evaluation -- and then builds the NEXT group's models on the same contexts must leave the evaluation in flight
+    untouched: its frames still match the oracle for the FIRST group's deltas, and the second evaluation the second's."""
+    N, M, F = 400_000, 256, 16
+    dev = torch.device("cuda", 0)
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    d_P = torch.from_numpy(P).to(dev)
+    d_rest = torch.from_numpy(rest).to(dev)
+    groups = [np.stack([synth.smooth_deltas(rest, f % 8) * np.float32(1.0 + 0.25 * (f // 8)) for f in range(g * F, (g + 1) * F)])
+              for g in range(2)]
+    d_del = [torch.from_numpy(d).to(dev) for d in groups]
+    lane, es = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    engines = []
+    for _ in range(F):
+        e = capi.Engine(); e.set_stream(lane.cuda_stream); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
+        engines.append(e)
+    batch = capi.Batch(engines)
+    outs = [[torch.empty_like(d_P) for _ in range(F)] for _ in range(2)]
+    falls = [[torch.zeros(N, device=dev) for _ in range(F)] for _ in range(2)]
+    torch.cuda.synchronize()
+    built = torch.cuda.Event()
+    for g in range(2):
+        batch.wait_consumed(lane.cuda_stream)                      # no-op the first time
+        batch.set_points_dev([d_rest.data_ptr()] * F, [d_del[g].data_ptr() + f * M * 12 for f in range(F)], M)
+        batch.build_async(lane.cuda_stream)
+        built.record(lane)
+        es.wait_event(built)
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs[g]], d_falloff=[x.data_ptr() for x in falls[g]],
+                                stream_ptr=es.cuda_stream)
+    torch.cuda.synchronize()
+    idx = np.unique(np.concatenate([np.arange(0, N, 397), [0, 63, 64, N - 1]]))
+    for g in range(2):
+        for f in (0, 5, F - 1):
+            table = oracle.control_table(rest, (rest + groups[g][f]).astype(np.float32))
+            rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], fo.TERM_LINEAR)
+            ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P[idx])
+            out = outs[g][f].cpu().numpy()[idx]
+            assert parity_ratio(out, ref, P[idx], 1e-5) <= 1.0, (g, f)
+    batch.close()
+    for e in engines:
+        e.set_stream(None); e.close()
