@@ -41,6 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc_path()
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(_ROOT, "include")]
+    common += os.environ.get("FD_EXTRA_HIPCC_FLAGS", "").split()       # experiments (-DFD_...): python -m facedeform_amd._build
     objs = []
     procs = []
     for src in SOURCES:

@@ -1573,7 +1573,8 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     int rc = use_device(c0);
     if (rc) { batch_err(b, "%s", c0->err); return rc; }
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(c0);
-    bool fast = c0->kind == FD_KERNEL_THIN_PLATE && round_up(c0->M, kRecPad) >= 32;
+    const int ek = eval_kind(c0);
+    bool fast = (ek == FD_KERNEL_THIN_PLATE || ek == FD_KERNEL_GAUSSIAN || ek == FD_KERNEL_GAUSSIAN_QNN) && round_up(c0->M, kRecPad) >= 32;
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];
         if (!d_P_out[i]) { batch_err(b, "fd_batch_deform_shared_dev: NULL output array for context %d", i); return FD_E_INVALID; }
@@ -1608,6 +1609,7 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     a.radius2 = radius2; a.falloffrate = falloffrate;
     a.Mpad = round_up(c0->M, kRecPad); a.nF = b->n;
     a.ctiles = c0->d_tiles16;
+    a.kind = ek;
     a.falloff_out = d_falloff_out;
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];

@@ -55,6 +55,7 @@ constexpr size_t kSharedLdsBudget = 158 * 1024;   // of 160 KiB (one workgroup p
 //     unused rows at F = 16, 32 (6 tiles instead of 8 at 32 frames: a quarter fewer matrix instructions).
 // Either way the 4 x 4 transpose across lane groups in the epilogue leaves every lane with all rows of
 // every tile for ONE vertex.
+constexpr int kGaussShift = 10;      // Gaussian kinds: phi (<= 1) enters the matrix pipe as 2^10 phi, clear of the fp16 subnormals
 constexpr bool shared_dense(int nF) { return nF > 12; }
 constexpr int shared_tiles(int nF) { return shared_dense(nF) ? 3 * ((nF + 15) / 16) : (nF + 3) / 4; }
 constexpr int shared_slots(int nT, bool dense) { return dense ? nT / 3 * 16 : nT * 4; }     // frame records
@@ -105,10 +106,24 @@ struct SharedSlots {              // the models of the frames (kernel argument o
 // instruction per output tile and vertex tile holds all three split products -- lane group 0
 // pairs hi x hi, group 1 lo(vertex) x hi(coefficient), group 2 hi(vertex) x lo(coefficient).
 __global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, const SharedOut out, int nF, int Mpad, int dense,
-                                                      uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles)
+                                                      uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles, int gauss)
 {
     const int kb = blockIdx.x, T = blockIdx.y, nT = gridDim.y, nkb = gridDim.x;
-    if (T == 0) {
+    if (T == 0 && gauss) {
+        // Gaussian kinds: the slot of a K block's two centre tiles holds its 32 centre records instead
+        // ({c'x, c'y, c'z, -log2(e) s^2 / R_j^2}: the first half of Rec32), read by direct differences
+        constexpr int per = (int)(sizeof(MfmaTileH) / 16);
+        uint4 *dst = wtiles + (size_t)nkb * nT * 128 + (size_t)nT * 64;
+        if (threadIdx.x < 32) {
+            const int centre = 32 * kb + (int)threadIdx.x;
+            dst[(size_t)2 * kb * per + threadIdx.x] =
+                centre < Mpad ? *reinterpret_cast<const uint4 *>(&slots.rec32[0][centre]) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (kb == 0 && threadIdx.x == 255) {
+            const float *nn = slots.model[0]->norm32;
+            dst[(size_t)2 * nkb * per] = make_uint4(__float_as_uint(nn[0]), __float_as_uint(nn[1]), __float_as_uint(nn[2]), __float_as_uint(nn[3]));
+        }
+    } else if (T == 0) {
         // everything else the evaluation reads of the contexts: the rest rig's centre tiles and normalisation.  With
         // these in the batch's scratch the contexts are free for their next build as soon as THIS kernel has run.
         constexpr int per = (int)(sizeof(MfmaTileH) / 16);
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, co
             s_scale[q] = ldexpf(1.f, k);
             if (kb == 0 && (!dense || T % 3 == 0)) {
                 SharedFrame fr;
-                fr.inv_scale = ldexpf(1.f, -k);
+                fr.inv_scale = ldexpf(1.f, -k - (gauss ? kGaussShift : 0));
                 fr.built = (f < nF && slots.model[f]->terminationtype == 1) ? 1 : 0;
                 fr.pad[0] = fr.pad[1] = 0;
                 fr.P_out = f < nF ? out.P_out[f] : nullptr;
@@ -196,13 +211,28 @@ __global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, co
 // two mixed-precision fmas that subtract the fp16 piece from the fp32 value and round the
 // remainder to fp16 in the same instruction (v_fma_mixlo/hi_f16 write one half of the destination
 // and keep the other) -- three instructions for two values, no unpacking, no repacking.
+// PLAIN: the same two pieces from instructions the compiler sees (conversions and a subtraction: about twice as
+// many).  The Gaussian kinds take this form: there the inputs come straight from v_exp_f32, and a vector
+// instruction hidden in an asm string that reads a transcendental's result gets none of the wait states the
+// compiler pads that pair with.
+template <bool PLAIN = false>
 __device__ __forceinline__ void split_pair_f16(float v0, float v1, unsigned &hi, unsigned &lo)
 {
+    if constexpr (PLAIN) {
+        const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+        const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+        hi = __builtin_bit_cast(unsigned, (f16x2){h0, h1});
+        lo = __builtin_bit_cast(unsigned, (f16x2){l0, l1});
+        return;
+    }
     const f16x2 hh = __builtin_convertvector((f32x2){v0, v1}, f16x2);
     hi = __builtin_bit_cast(unsigned, hh);
     unsigned l;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(v0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(v1));
+    // (s_nop 1 inside the string: a register written by a vector instruction needs two wait states before a matrix
+    // instruction reads it as an operand, and the compiler pads only producers it can see; no measurable cost:
+    // 218-229 us per C2 x 32 launch with it, 210-237 without, same box)
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(hi), "v"(v1));
     lo = l;
 }
 
@@ -215,7 +245,7 @@ __device__ __forceinline__ void store_pos3(Pos3 FD_GLOBAL *dst, float x, float y
     dst->x = x; dst->y = y; dst->z = z;      // member-wise: a struct assignment through an address-space pointer does not compile on the host pass
 }
 
-template <int NT, bool DENSE>
+template <int NT, bool DENSE, bool GAUSS>
 __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_deform32_tps_shared(const SharedParams p, int ngroups)
 {
@@ -344,12 +374,14 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
         // every lane group holds vertex (vt, j): the d2 operand needs one coordinate of it per lane
         // group, the polynomial operand all of them
         f16x4 bop[TV];
+        float xn[TV], yn[TV], zn[TV];            // GAUSS: the normalised coordinates, for the direct differences
         f32x4 acc[NT][TV];
         bool lane_live = false;
 #pragma unroll
         for (int t = 0; t < TV; ++t) {
             const int64_t vi = vbase + 16 * t + j;
             const float x = (cur.p[t][0] - n0) * inv_s, y = (cur.p[t][1] - n1) * inv_s, z = (cur.p[t][2] - n2) * inv_s;
+            xn[t] = x; yn[t] = y; zn[t] = z;
             const float d2v = cur.d2[t];
             if constexpr (FAST) lane_live = true; else lane_live |= (vi < p.N) && !(d2v > p.radius2);
             const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
@@ -360,12 +392,15 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
             bop[t] = g < 3 ? (f16x4){h, l, h, l} : (f16x4){one, one, h, l};
             // polynomial operand: k-slots {1, x', y', z', |x'|^2}: hi pieces in lane groups 0 and 2,
             // lo pieces in group 1 (against the coefficients' hi), nothing in group 3
+            // (GAUSS: everything times 2^10, the factor phi carries; undone with the frame's scale)
+            constexpr float ps = GAUSS ? (float)(1 << kGaussShift) : 1.f;
+            constexpr unsigned one16 = GAUSS ? 0x6400u : 0x3c00u;         // fp16 1024 / 1
             unsigned xyh, xyl, zxh, zxl;
-            split_pair_f16(x, y, xyh, xyl);
-            split_pair_f16(z, xx, zxh, zxl);
+            split_pair_f16(x * ps, y * ps, xyh, xyl);
+            split_pair_f16(z * ps, xx * ps, zxh, zxl);
             u32x4 pb;
             if (g == 1) pb = (u32x4){xyl << 16, (xyl >> 16) | (zxl << 16), zxl >> 16, 0u};                  // {0, xl, yl, zl, xxl}
-            else pb = (u32x4){0x3c00u | (xyh << 16), (xyh >> 16) | (zxh << 16), zxh >> 16, 0u};            // {1, xh, yh, zh, xxh}
+            else pb = (u32x4){one16 | (xyh << 16), (xyh >> 16) | (zxh << 16), zxh >> 16, 0u};              // {1, xh, yh, zh, xxh}
             if (g == 3) pb = (u32x4){0u, 0u, 0u, 0u};
             const f16x8 pbv = __builtin_bit_cast(f16x8, pb);
 #pragma unroll
@@ -385,6 +420,50 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 
         // phi of K block kb (32 centres) for the wave's four vertex tiles, split into fp16 pieces: the B operands
         auto phi_block = [&](int kb, u32x4 (&xh)[TV], u32x4 (&xl)[TV]) {
+            if constexpr (GAUSS) {
+                // exp(-d2 / R_j^2) from direct coordinate differences (the expanded form of the matrix-pipe d2 has
+                // an absolute error the exponent multiplies by 1 / R^2: DESIGN.md 4.1), two vertex tiles per packed
+                // instruction; this lane's 8 centres of the block come from LDS once for the four vertex tiles
+                const float4 *cr = reinterpret_cast<const float4 *>(&s_ct[2 * kb]);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {         // centres 4 g .. 4 g + 3 of each 16-centre half of the block
+                    float4 c[4];
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) c[sl] = cr[16 * hf + 4 * g + sl];
+#pragma unroll
+                    for (int tp = 0; tp < TV; tp += 2) {
+                        const f32x2 X = {xn[tp], xn[tp + 1]}, Y = {yn[tp], yn[tp + 1]}, Z = {zn[tp], zn[tp + 1]};
+                        f32x2 ph[4], ee[4];
+#pragma unroll
+                        for (int sl = 0; sl < 4; ++sl) {
+                            const f32x2 dx = X - (f32x2){c[sl].x, c[sl].x}, dy = Y - (f32x2){c[sl].y, c[sl].y}, dz = Z - (f32x2){c[sl].z, c[sl].z};
+                            f32x2 d2 = dx * dx;
+                            d2 = __builtin_elementwise_fma(dy, dy, d2);
+                            d2 = __builtin_elementwise_fma(dz, dz, d2);
+                            ee[sl] = __builtin_elementwise_fma(d2, (f32x2){c[sl].w, c[sl].w}, (f32x2){(float)kGaussShift, (float)kGaussShift});
+                            ph[sl] = (f32x2){__builtin_amdgcn_exp2f(ee[sl].x), __builtin_amdgcn_exp2f(ee[sl].y)};
+                        }
+
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            unsigned h, l;
+                            split_pair_f16<true>(ph[2 * q].x, ph[2 * q + 1].x, h, l); xh[tp][2 * hf + q] = h; xl[tp][2 * hf + q] = l;
+                            split_pair_f16<true>(ph[2 * q].y, ph[2 * q + 1].y, h, l); xh[tp + 1][2 * hf + q] = h; xl[tp + 1][2 * hf + q] = l;
+                        }
+                        // The exponentials' SOURCE registers stay alive until the pieces above exist.  Measured on gfx950
+                        // (ROCm 7.2): a vector instruction that overwrites the source of a v_exp_f32 issued just before it
+                        // can win the race against the transcendental unit reading that source -- which the compiler allows
+                        // (write-after-read on a dead temporary) and the hardware does not interlock: phi wrong on a few
+                        // vertices per launch, different ones from launch to launch (it depends on what the SIMD's other
+                        // wave issues in between); no fault.  With the sources held: 0 failures in 20 test runs, without:
+                        // 5 of 5 (tests/test_gpu_shared.py::test_shared_frames_of_the_gaussian_models).  The thin-plate
+                        // path is not exposed: its logarithms read matrix-instruction results that live a whole block.
+                        asm volatile("" :: "v"(ee[0].x), "v"(ee[0].y), "v"(ee[1].x), "v"(ee[1].y), "v"(ee[2].x), "v"(ee[2].y), "v"(ee[3].x), "v"(ee[3].y),
+                                           "v"(xh[tp][2 * hf]), "v"(xh[tp + 1][2 * hf + 1]), "v"(xl[tp][2 * hf]), "v"(xl[tp + 1][2 * hf + 1]));
+                    }
+                }
+                return;
+            }
             const f16x4 aopA = *reinterpret_cast<const f16x4 *>(&s_ct[2 * kb].a[lane][0]);
             const f16x4 aopB = *reinterpret_cast<const f16x4 *>(&s_ct[2 * kb + 1].a[lane][0]);
 #pragma unroll
@@ -429,16 +508,19 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
                 phi_block(kb + 1, nbh, nbl);
                 contract(kb, bh, bl);
                 // issue order inside this block: one matrix instruction, then the vector work that fits under it
+                // (thin-plate only; the Gaussian block is left to the scheduler's own order)
+                if constexpr (!GAUSS) {
 #pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);      // transcendental
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // VALU
-                }
+                    for (int q = 0; q < 32; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);      // transcendental
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // VALU
+                    }
 #pragma unroll
-                for (int q = 32; q < 8 + NT * TV * 3; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    for (int q = 32; q < 8 + NT * TV * 3; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    }
                 }
                 // (unrolling by two with the buffers swapped instead of these 32 copies spills: 109 registers)
 #pragma unroll
@@ -625,6 +707,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     const int ntiles = a.Mpad / 16, nkb = (ntiles + 1) / 2;
     const bool dense = shared_dense(a.nF);
     const int nT = shared_tiles(a.nF);
+    const bool gauss = a.kind != FD_KERNEL_THIN_PLATE;       // FD_KERNEL_GAUSSIAN / _QNN: per-record scale, direct differences
     SharedSlots slots{};
     SharedOut out{};
     for (int f = 0; f < kMaxBatch; ++f) {
@@ -633,7 +716,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         out.P_out[f] = a.P_out[q]; out.falloff_out[f] = a.falloff_out ? a.falloff_out[q] : nullptr;
     }
     hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
-                       (SharedFrame *)a.frames, a.ctiles);
+                       (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
     if (a.packed_ev) {
         hipError_t e = hipEventRecord(a.packed_ev, stream);
         if (e != hipSuccess) return e;
@@ -680,27 +763,29 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         return (int64_t)(v > 0 && v < (long)kNumCU ? v : (long)kNumCU);
     }();
     const unsigned grid = (unsigned)(ngroups < max_wgs ? ngroups : max_wgs);
-#define FD_SHARED_CASE(NTV, DNS)                                                                                     \
+#define FD_SHARED_CASE(NTV, DNS, GSS)                                                                                \
     {                                                                                                                \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
-            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared<NTV, DNS>,                       \
+            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared<NTV, DNS, GSS>,                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
             if (e != hipSuccess) return e;                                                                           \
             attr_set = true;                                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_deform32_tps_shared<NTV, DNS>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
+        hipLaunchKernelGGL((k_deform32_tps_shared<NTV, DNS, GSS>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
     }
+#define FD_SHARED_KIND(NTV, DNS) { if (gauss) FD_SHARED_CASE(NTV, DNS, true) else FD_SHARED_CASE(NTV, DNS, false) }
     if (dense) {
-        if (nT == 3) FD_SHARED_CASE(3, true)
-        else if (nT == 6) FD_SHARED_CASE(6, true)
+        if (nT == 3) FD_SHARED_KIND(3, true)
+        else if (nT == 6) FD_SHARED_KIND(6, true)
         else return hipErrorInvalidValue;
     } else {
-        if (nT == 1) FD_SHARED_CASE(1, false)
-        else if (nT == 2) FD_SHARED_CASE(2, false)
-        else if (nT == 3) FD_SHARED_CASE(3, false)
+        if (nT == 1) FD_SHARED_KIND(1, false)
+        else if (nT == 2) FD_SHARED_KIND(2, false)
+        else if (nT == 3) FD_SHARED_KIND(3, false)
         else return hipErrorInvalidValue;
     }
+#undef FD_SHARED_KIND
 #undef FD_SHARED_CASE
     if (want_stamps && d_stamps) {
         unsigned long long h[64];

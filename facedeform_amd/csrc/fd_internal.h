@@ -210,7 +210,8 @@ struct SharedDeformArgs {
     const float *tu, *tv, *nrm;
     float radius2, falloffrate;
     int Mpad, nF;
-    const MfmaTileH *ctiles;              // centre tiles of the shared rest rig
+    int kind;                             // FD_KERNEL_THIN_PLATE, or a Gaussian kind (FD_KERNEL_GAUSSIAN / _QNN records)
+    const MfmaTileH *ctiles;              // centre tiles of the shared rest rig (thin-plate; the Gaussian kinds read rec32[0])
     const Rec32 *rec32[kMaxBatch];        // per frame: the solved model's records (weights)
     const DevModel *model[kMaxBatch];
     float *P_out[kMaxBatch];

@@ -314,9 +314,11 @@ int fd_batch_deform_dev(fd_batch *batch, void *hip_stream, int64_t N, const floa
  * (N x M) x (M x 3F) product on the matrix pipe (fp16 x 2 split operands, 22 bits, fp32
  * accumulation).  Every frame still has its own model, built by its own assemble + solve.  The
  * contexts must have read their rest points from ONE device array (fd_batch_set_points_dev with
- * the same d_rest_xyz for all; FD_E_INVALID otherwise); thin-plate kernel, fp32 evaluation, 32 or
- * more centres -- anything else takes fd_batch_deform_dev on the shared arrays.  Parity with the
- * oracle as for fd_deform (1e-5); NOT bit-identical to the one-frame kernels. */
+ * the same d_rest_xyz for all; FD_E_INVALID otherwise); thin-plate or Gaussian kernel
+ * (FD_KERNEL_GAUSSIAN, FD_KERNEL_GAUSSIAN_QNN -- the SOP's default model: exp(-d2 / R_j^2) from direct
+ * coordinate differences, formed once for all frames), fp32 evaluation, 32 or more centres -- anything else
+ * (biharmonic, cubic, the multilayer model, fp64) takes fd_batch_deform_dev on the shared arrays.  Parity
+ * with the oracle as for fd_deform (1e-5); NOT bit-identical to the one-frame kernels. */
 int fd_batch_deform_shared_dev(fd_batch *batch, void *hip_stream, int64_t N, const float *d_P_in,
                                float *const *d_P_out, const float *d_dist2, float *const *d_falloff_out,
                                const float *d_tu, const float *d_tv, const float *d_nrm, float radius2,

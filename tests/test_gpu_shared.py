@@ -127,8 +127,9 @@ def test_shared_needs_one_rest_rig_and_falls_back_for_other_kernels(hip_lib):
         batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])
     assert ei.value.code == capi.FD_E_INVALID and "one rest rig" in ei.value.text
     _close(engines, batch)
-    # the SOP's default model on shared arrays: the per-frame kernels, bit for bit
-    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F, kind=capi.KERNEL_GAUSSIAN_QNN, params=[1.0, 5.0])
+    # a kernel the shared launch does not take (biharmonic: sqrt(d2) needs more of d2 near a centre than the
+    # expanded form keeps) on shared arrays: the per-frame kernels, bit for bit
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F, kind=capi.KERNEL_BIHARMONIC, params=[])
     a = [torch.empty_like(d_P) for _ in range(F)]
     b = [torch.empty_like(d_P) for _ in range(F)]
     batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in a])
@@ -183,3 +184,49 @@ def test_contexts_may_be_rebuilt_once_the_launch_has_its_copy(hip_lib, oracle):
     batch.close()
     for e in engines:
         e.set_stream(None); e.close()
+
+
+@pytest.mark.parametrize("kind,okind,params,M,N,F", [
+    (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0), 256, 30_011, 32),      # the SOP's default model, dense layout
+    (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0), 100, 4_099, 5),        # padded layout, ragged sizes
+    (capi.KERNEL_GAUSSIAN, fo.KERNEL_GAUSSIAN, (0.15,), 256, 10_000, 16),                 # one radius for all centres
+    (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0), 256, 10_000, 16),      # 16 frames: three tiles, the mix that exposed a scheduling hazard
+    (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (2.0, 5.0), 512, 6_000, 24),
+])
+def test_shared_frames_of_the_gaussian_models(hip_lib, oracle, kind, okind, params, M, N, F):
+    """The SOP's default model (QNN radii) and the fixed-radius Gaussian through the shared-rig launch: exp(-d2 / R_j^2)
+    from direct coordinate differences, formed once per (vertex, centre) for all frames, contracted on the matrix
+    pipe like the thin-plate phi.  Against the oracle (1e-5) with the gate and the fall-off in play, and against
+    the one-frame kernel on the same models."""
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F, kind=kind, params=params)
+    rng = np.random.default_rng(7 * M + F)
+    r2 = np.float32(0.36)
+    dist2 = (rng.random(N) * 0.5).astype(np.float32)
+    dist2[::11] = -1.0
+    d_d2 = torch.from_numpy(dist2).to(dev)
+    outs = [torch.empty_like(d_P) for _ in range(F)]
+    single = [torch.empty_like(d_P) for _ in range(F)]
+    falls = [torch.full((N,), 7.0, device=dev) for _ in range(F)]
+    for mode in ("plain", "gate"):
+        kw, okw = {}, {}
+        if mode == "gate":
+            kw.update(d_dist2=d_d2.data_ptr(), radius2=r2, falloffrate=2.0)
+            okw.update(dist2=dist2, radius2=r2, falloffrate=2.0)
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], d_falloff=[f.data_ptr() for f in falls], **kw)
+        torch.cuda.synchronize()
+        for f in sorted(set([0, 1, F // 2, F - 1])):
+            table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
+            rc, tt, W, radii = oracle.build(table, okind, list(params), fo.TERM_LINEAR)
+            assert rc == 0
+            ref, ref_fall = oracle.deform(table, okind, radii, W, P, **okw)
+            out = outs[f].cpu().numpy()
+            assert parity_ratio(out, ref, P, TOL) <= 1.0, (mode, f, parity_ratio(out, ref, P, TOL))
+            gated = dist2 > r2 if mode == "gate" else np.zeros(N, bool)
+            assert np.array_equal(out[gated], P[gated])
+            assert np.allclose(falls[f].cpu().numpy()[~gated], ref_fall[~gated], rtol=2e-6, atol=1e-7)
+    batch.deform_dev(N, [d_P.data_ptr()] * F, [o.data_ptr() for o in single], d_dist2=[d_d2.data_ptr()] * F, radius2=r2, falloffrate=2.0)
+    torch.cuda.synchronize()
+    for f in (0, F - 1):
+        a, b = outs[f].cpu().numpy(), single[f].cpu().numpy()
+        assert parity_ratio(a, b, P, TOL) <= 1.0, f
+    _close(engines, batch)

@@ -1,6 +1,6 @@
 """Time the shared-rig evaluation (fd_batch_deform_shared_dev) against the per-frame batched launch
 (fd_batch_deform_dev) at C2 / C3 sizes, HIP events on the launch stream, and report each frame's
-parity against the oracle on a vertex sample.   python tests/tools/shared_eval_timing.py [c2|c3] [frames,...]"""
+parity against the oracle on a vertex sample.   python tests/tools/shared_eval_timing.py [c2|c3] [frames,...] [tps|qnn]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -12,6 +12,9 @@ def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
     N, M = {"c2": (1_000_000, 256), "c3": (1_000_000, 2048), "c5": (10_000_000, 512)}[cfg]
     frames = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "4,8,16,32".split(","))]
+    model = sys.argv[3] if len(sys.argv) > 3 else "tps"
+    kind, okind, params = ((capi.KERNEL_THIN_PLATE, fo.KERNEL_THIN_PLATE, []) if model == "tps" else
+                           (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, [1.0, 5.0]))
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     P = synth.head_mesh(N); rest = synth.control_points(M, "head")
@@ -23,7 +26,7 @@ def main():
         d_del = torch.from_numpy(deltas).to(dev)
         engines = []
         for _ in range(F):
-            e = capi.Engine(); e.set_stream(stream.cuda_stream); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(0); engines.append(e)
+            e = capi.Engine(); e.set_stream(stream.cuda_stream); e.set_kernel(kind, params); e.set_term(0); engines.append(e)
         batch = capi.Batch(engines)
         batch.set_points_dev([d_rest.data_ptr()] * F, [d_del.data_ptr() + f * M * 12 for f in range(F)], M)
         batch.build_async(stream.cuda_stream); batch.build_result()
@@ -43,14 +46,14 @@ def main():
             worst = 0.0
             for f in range(0, F, max(1, F // 4)):
                 table = orc.control_table(rest, (rest + deltas[f]).astype(np.float32))
-                _, _, W, radii = orc.build(table, fo.KERNEL_THIN_PLATE, [], 0)
-                ref, _ = orc.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P[idx])
+                _, _, W, radii = orc.build(table, okind, params, 0)
+                ref, _ = orc.deform(table, okind, radii, W, P[idx])
                 out = outs[f].cpu().numpy()[idx]
                 worst = max(worst, synth.parity_error(out.astype(np.float64) - P[idx], ref.astype(np.float64) - P[idx]).max())
             res[name] = ts[len(ts) // 2]
             us = ts[len(ts) // 2] * 1e3
             gb = (12.0 * N + F * 16.0 * N) / (us * 1e-6) / 1e9 if name == "shared" else F * 28.0 * N / (us * 1e-6) / 1e9
-            print(f"{cfg} N={N} M={M} F={F:2d} {name:9s}: launch {us:9.1f} us = {us / F:7.2f} us/frame  {N / (us / F) :9.0f} Mverts/s  "
+            print(f"{cfg} {model} N={N} M={M} F={F:2d} {name:9s}: launch {us:9.1f} us = {us / F:7.2f} us/frame  {N / (us / F) :9.0f} Mverts/s  "
                   f"HBM (algorithmic) {gb:7.0f} GB/s  parity(raw, sample) {worst:.2e}", flush=True)
         batch.close()
         for e in engines:
