@@ -24,5 +24,8 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_
 python3 tests/tools/scaled_delta_parity.py > $OUT/scaled_delta_parity.txt 2>&1
 python3 tests/tools/shared_eval_timing.py c2 8,16,24,32 > $OUT/shared_timing_c2.txt 2>&1
 python3 tests/tools/shared_eval_timing.py c3 32 >> $OUT/shared_timing_c2.txt 2>&1
+python3 tests/tools/shared_eval_timing.py c2 8,32 qnn >> $OUT/shared_timing_c2.txt 2>&1
+python3 tests/tools/hbm_write_rate.py > $OUT/hbm_write_rate.txt 2>&1
+tools/ubench_mfma16 > $OUT/ubench_mfma16.txt 2>&1
 python3 tools/build_latency.py 256,512,2048 11 > $OUT/solver_latency.txt 2>&1
 find $OUT -name "*.csv" | wc -l
