@@ -43,6 +43,7 @@ CONFIGS = {
 METRIC = "deformed Mverts/sec at 256 ctrl pts, 1/2/4/8 MI355X vs host-CPU ref"
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA dense peak
 PEAK_FP16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X_MICROARCH.md: dense fp64 MFMA
 PEAK_HBM_GBS = 8000.0      # HBM3E spec
 FLOPS_PER_PAIR = 17        # thin-plate: SURVEY.md 8d
 FLOPS_PER_VERTEX_AFFINE = 24
@@ -535,6 +536,17 @@ def main():
         eng.synchronize()
         lat.append(time.perf_counter() - t1)
     latency_ms = float(np.median(lat)) * 1e3
+    # the solve alone, one model at a time (fd_build: assemble + factorise + substitute + pack, host-synchronised)
+    bl = []
+    for i in range(10):
+        eng = ln0["engines"][0]
+        eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr() + (i % N_FRAMES) * delta_stride, n_ctrl)
+        eng.synchronize()
+        t1 = time.perf_counter()
+        eng.build_async()
+        eng.build_result()
+        bl.append(time.perf_counter() - t1)
+    single_build_ms = float(np.median(bl)) * 1e3
 
     t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
     if world > 1:
@@ -673,9 +685,18 @@ def main():
                                "stream), no collective",
             },
             "roofline": roof,
+            # the dense solve of ONE model against the fp64 matrix peak ((1/3) n1^3 for the Cholesky of the
+            # projected block, n1 = M - 4; batched, 32 models share a launch chain: build_batch / 32 per model)
+            "roofline_solve": {"bound": "mfma_fp64", "flops_per_model": (n_ctrl - 4) ** 3 / 3.0, "peak": PEAK_FP64_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "single_build_ms": single_build_ms,
+                               "achieved_single": (n_ctrl - 4) ** 3 / 3.0 / (single_build_ms * 1e-3) / 1e12,
+                               "frac_single": (n_ctrl - 4) ** 3 / 3.0 / (single_build_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                               "achieved_batched": (n_ctrl - 4) ** 3 / 3.0 / (build_ms * 1e-3) / 1e12,
+                               "frac_batched": (n_ctrl - 4) ** 3 / 3.0 / (build_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                               "note": "a chain of dependent launches on a small matrix: latency, not flops, bounds it (DESIGN.md 4.2b/4.2c)"},
             "ranks": ranks,
             "phases_ms": {"build_per_frame_batched": build_ms, "build_batch": build_group_ms,
-                          "evaluate": eval_ms, "single_cook_latency": latency_ms},
+                          "evaluate": eval_ms, "single_cook_latency": latency_ms, "single_build": single_build_ms},
             "eval_only_mverts_s": n_verts / (eval_ms * 1e-3) / 1e6,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -31,7 +31,12 @@ def main():
             stream.synchronize()
             ts = sorted(a.elapsed_time(b) for a, b in evs[2:])
             t = ts[len(ts) // 2]
-            print(f"N={N} T={tris.shape[0]}: {t*1e3:8.1f} us  ({N*tris.shape[0]/t/1e6:7.1f} G point-triangle pairs/s)  [{label}; "
+            # roofline: the kernel is fp32-vector-bound: ~45 flop per point-triangle pair (two dot products, region
+            # selection, distance) against 157.3 TFLOP/s; with a radius the wave-level cull skips pairs, so the
+            # "no radius" line is the one that prices every pair
+            tf = 45.0 * N * tris.shape[0] / (t * 1e-3) / 1e12
+            print(f"N={N} T={tris.shape[0]}: {t*1e3:8.1f} us  ({N*tris.shape[0]/t/1e6:7.1f} G point-triangle pairs/s, {tf:6.1f} TFLOP/s = "
+                  f"{tf / 157.3:5.3f} of the fp32 vector peak at 45 flop/pair)  [{label}; "
                   f"Fibonacci vertex order: neighbouring lanes are not neighbouring points]", flush=True)
     e.set_stream(None); e.close()
 
