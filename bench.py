@@ -440,6 +440,11 @@ def main():
         if ev:
             ev[first][1].record(stream)
         es = eval_stream if args.eval_stream == "shared" else stream
+        if shared_eval:
+            # the weights become fp16 tiles right here, on the build stream (fd_batch_prepare_shared): the evaluation
+            # stream then runs evaluation launches back to back
+            batch.prepare_shared([o.data_ptr() for o in ln["out"][:count]], d_falloff=[f.data_ptr() for f in ln["fall"][:count]],
+                                 stream_ptr=stream.cuda_stream)
         if batched_eval:
             # ONE launch evaluates the group's frames (grid y = frame).  The evaluation stream is
             # made to wait for the build here, so that the event pair holds the launch alone.

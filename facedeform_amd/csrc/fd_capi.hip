@@ -123,10 +123,22 @@ struct fd_batch {
     hipStream_t waited_stream = nullptr;
     hipEvent_t status_ev = nullptr;     // behind the kernel that posts every context's status after a batched build
     // scratch of the shared-rig evaluation (fd_batch_deform_shared_dev): weight tiles + frame records
-    void *d_wtiles = nullptr, *d_frames = nullptr;
-    size_t cap_wtiles = 0, cap_frames = 0;
-    hipEvent_t packed_ev = nullptr;      // behind the pack kernel of the last shared-rig evaluation (fd_batch_wait_consumed)
-    bool packed_valid = false;
+    // Two sets: the set a launch reads must not be rewritten by the pack kernel of the NEXT models before that launch
+    // has finished -- with fd_batch_prepare_shared the next pack runs on the build stream, under the previous evaluation.
+    struct SharedSet {
+        void *d_wtiles = nullptr, *d_frames = nullptr;
+        size_t cap_wtiles = 0, cap_frames = 0;
+        hipEvent_t packed_ev = nullptr;  // behind the pack kernel that filled the set
+        hipEvent_t eval_ev = nullptr;    // behind the last evaluation that read it
+        bool eval_pending = false;
+    } sets[2];
+    int cur_set = 0;                     // the set packed last
+    bool packed_valid = false;           // sets[cur_set].packed_ev is recorded (fd_batch_wait_consumed)
+    bool prepared = false;               // sets[cur_set] holds the contexts' CURRENT models and prep_* outputs
+    float *prep_P_out[kMaxBatch] = {nullptr};
+    float *prep_fall[kMaxBatch] = {nullptr};
+    bool prep_has_fall = false;
+    hipEvent_t fallback_ev = nullptr;    // behind the per-frame launches when the shared launch does not apply
     char err[512] = {0};
 };
 
@@ -1325,9 +1337,13 @@ void fd_batch_destroy(fd_batch *b)
     for (hipEvent_t e : b->lu_events) if (e) (void)hipEventDestroy(e);
     if (b->lu_stream) (void)hipStreamDestroy(b->lu_stream);
     if (b->d_slots) (void)hipFree(b->d_slots);
-    if (b->d_wtiles) (void)hipFree(b->d_wtiles);
-    if (b->d_frames) (void)hipFree(b->d_frames);
-    if (b->packed_ev) (void)hipEventDestroy(b->packed_ev);
+    for (auto &st : b->sets) {
+        if (st.d_wtiles) (void)hipFree(st.d_wtiles);
+        if (st.d_frames) (void)hipFree(st.d_frames);
+        if (st.packed_ev) (void)hipEventDestroy(st.packed_ev);
+        if (st.eval_ev) (void)hipEventDestroy(st.eval_ev);
+    }
+    if (b->fallback_ev) (void)hipEventDestroy(b->fallback_ev);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -1340,6 +1356,7 @@ int fd_batch_set_points_dev(fd_batch *b, const float *const *d_rest_xyz, const f
 {
     if (!b || !d_rest_xyz || !d_delta_xyz) return FD_E_INVALID;
     if (M <= 0 || M + 4 > kMaxOrder) { batch_err(b, "fd_batch_set_points_dev: M = %d outside 1..%d", M, kMaxOrder - 4); return FD_E_INVALID; }
+    b->prepared = false;
     for (int i = 0; i < b->n; ++i)
         if (!d_rest_xyz[i] || !d_delta_xyz[i]) { batch_err(b, "fd_batch_set_points_dev: null array for context %d", i); return FD_E_INVALID; }
     for (int i = 0; i < b->n; ++i) {
@@ -1364,6 +1381,7 @@ int fd_batch_set_points_dev(fd_batch *b, const float *const *d_rest_xyz, const f
 int fd_batch_build_async(fd_batch *b, void *hip_stream)
 {
     if (!b) return FD_E_INVALID;
+    b->prepared = false;
     fd_ctx *c0 = b->ctxs[0];
     int rc = use_device(c0);
     if (rc) { batch_err(b, "%s", c0->err); return rc; }
@@ -1497,7 +1515,9 @@ static int batch_poll(fd_batch *b)
         if (q == hipErrorNotReady) { (void)hipGetLastError(); return FD_OK; }
     }
     for (int i = 0; i < b->n; ++i) {
+        const bool lu_before = b->ctxs[i]->prefer_lu;
         const int rc = poll_status(b->ctxs[i]);
+        if (b->ctxs[i]->prefer_lu != lu_before) b->prepared = false;     // a model was rebuilt: a set packed from the old one is stale
         if (rc) { batch_err(b, "context %d: %s", i, b->ctxs[i]->err); return rc; }
     }
     return FD_OK;
@@ -1560,6 +1580,98 @@ int fd_batch_deform_dev(fd_batch *b, void *hip_stream, int64_t N, const float *c
 
 // Frames of ONE mesh and ONE rest rig: phi(|x - c|^2) is formed once per (vertex, centre) for all of
 // them and the weight contraction runs on the matrix pipe (fd_eval.hip, k_deform32_tps_shared).
+// ---- frames of one mesh and one rest rig (fd_batch_deform_shared_dev, fd_batch_prepare_shared) ----
+// 1: the shared-rig launch applies; 0: the per-frame launches do; < 0: error
+static int shared_applies(fd_batch *b, const char *who, float *const *d_P_out, int *ek_out)
+{
+    fd_ctx *c0 = b->ctxs[0];
+    const int ek = eval_kind(c0);
+    *ek_out = ek;
+    bool fast = (ek == FD_KERNEL_THIN_PLATE || ek == FD_KERNEL_GAUSSIAN || ek == FD_KERNEL_GAUSSIAN_QNN) && round_up(c0->M, kRecPad) >= 32;
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        if (!d_P_out[i]) { batch_err(b, "%s: NULL output array for context %d", who, i); return FD_E_INVALID; }
+        if (!c->built && !c->build_pending) { batch_err(b, "%s: context %d has no built model", who, i); return FD_E_NOT_BUILT; }
+        // one rest rig: every context read its rest points in place from the SAME device array
+        if (!c->rest_src || c->rest_src != c0->rest_src || c->M != c0->M || c->kind != c0->kind || c->term != c0->term) {
+            batch_err(b, "%s: the contexts must share one rest rig (fd_batch_set_points_dev with the "
+                         "same rest array for all), kernel and term; context %d does not", who, i);
+            return FD_E_INVALID;
+        }
+        if (c->eval_precision != FD_EVAL_FP32 || c->eval_variant > 0 || record_layers(c) != 0) fast = false;
+    }
+    return fast ? 1 : 0;
+}
+
+static bool make_event(hipEvent_t *ev)
+{
+    if (*ev) return true;
+    if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); *ev = nullptr; return false; }
+    return true;
+}
+
+// the pack kernel of the contexts' current models into the set NOT read by the evaluation before; on `stream`
+static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_P_out, float *const *d_falloff_out)
+{
+    fd_ctx *c0 = b->ctxs[0];
+    const int si = b->packed_valid ? (b->cur_set ^ 1) : 0;
+    fd_batch::SharedSet &st = b->sets[si];
+    SharedDeformArgs a{};
+    a.N = 1; a.Mpad = round_up(c0->M, kRecPad); a.nF = b->n; a.kind = ek; a.ctiles = c0->d_tiles16;
+    a.falloff_out = d_falloff_out;
+    int rc;
+    for (int i = 0; i < b->n; ++i) {
+        fd_ctx *c = b->ctxs[i];
+        a.rec32[i] = c->d_rec32; a.model[i] = c->d_model; a.P_out[i] = d_P_out[i];
+        if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
+    }
+    if ((rc = batch_poll(b))) return rc;
+    const size_t wb = shared_wtile_bytes(a.Mpad, a.nF), fb = shared_frame_bytes(a.nF);
+    if (wb > st.cap_wtiles || fb > st.cap_frames) {
+        // (hipFree drains the device: no launch still reads the old scratch)
+        if (st.d_wtiles) (void)hipFree(st.d_wtiles);
+        if (st.d_frames) (void)hipFree(st.d_frames);
+        st.d_wtiles = st.d_frames = nullptr; st.cap_wtiles = st.cap_frames = 0; st.eval_pending = false;
+        if (hipMalloc(&st.d_wtiles, wb) != hipSuccess || hipMalloc(&st.d_frames, fb) != hipSuccess) {
+            (void)hipGetLastError();
+            batch_err(b, "shared-rig evaluation: scratch allocation (%zu bytes) failed", wb + fb);
+            return FD_E_NOMEM;
+        }
+        st.cap_wtiles = wb; st.cap_frames = fb;
+    }
+    // the evaluation that last read this set must be through with it
+    if (st.eval_pending && st.eval_ev && hipStreamWaitEvent(stream, st.eval_ev, 0) != hipSuccess) {
+        batch_err(b, "shared-rig evaluation: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
+        return FD_E_DEVICE;
+    }
+    st.eval_pending = false;
+    a.wtiles = st.d_wtiles; a.frames = st.d_frames;
+    a.packed_ev = make_event(&st.packed_ev) ? st.packed_ev : nullptr;
+    a.mode = 1;
+    hipError_t e = launch_deform_shared(a, stream);
+    if (e != hipSuccess) { batch_err(b, "launch_deform_shared (pack) failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    b->cur_set = si;
+    b->packed_valid = st.packed_ev != nullptr;
+    b->prepared = true;
+    for (int i = 0; i < b->n; ++i) { b->prep_P_out[i] = d_P_out[i]; b->prep_fall[i] = d_falloff_out ? d_falloff_out[i] : nullptr; }
+    b->prep_has_fall = d_falloff_out != nullptr;
+    return FD_OK;
+}
+
+int fd_batch_prepare_shared(fd_batch *b, void *hip_stream, float *const *d_P_out, float *const *d_falloff_out)
+{
+    if (!b || !d_P_out) return FD_E_INVALID;
+    fd_ctx *c0 = b->ctxs[0];
+    int rc = use_device(c0);
+    if (rc) { batch_err(b, "%s", c0->err); return rc; }
+    hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(c0);
+    int ek = 0;
+    const int applies = shared_applies(b, "fd_batch_prepare_shared", d_P_out, &ek);
+    if (applies < 0) return applies;
+    if (applies == 0) return FD_OK;              // the per-frame launches read the models themselves: nothing to prepare
+    return shared_pack(b, stream, ek, d_P_out, d_falloff_out);
+}
+
 int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const float *d_P_in, float *const *d_P_out,
                                const float *d_dist2, float *const *d_falloff_out, const float *d_tu,
                                const float *d_tv, const float *d_nrm, float radius2, float falloffrate)
@@ -1573,37 +1685,42 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     int rc = use_device(c0);
     if (rc) { batch_err(b, "%s", c0->err); return rc; }
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(c0);
-    const int ek = eval_kind(c0);
-    bool fast = (ek == FD_KERNEL_THIN_PLATE || ek == FD_KERNEL_GAUSSIAN || ek == FD_KERNEL_GAUSSIAN_QNN) && round_up(c0->M, kRecPad) >= 32;
-    for (int i = 0; i < b->n; ++i) {
-        fd_ctx *c = b->ctxs[i];
-        if (!d_P_out[i]) { batch_err(b, "fd_batch_deform_shared_dev: NULL output array for context %d", i); return FD_E_INVALID; }
-        if (!c->built && !c->build_pending) { batch_err(b, "fd_batch_deform_shared_dev: context %d has no built model", i); return FD_E_NOT_BUILT; }
-        // one rest rig: every context read its rest points in place from the SAME device array
-        if (!c->rest_src || c->rest_src != c0->rest_src || c->M != c0->M || c->kind != c0->kind || c->term != c0->term) {
-            batch_err(b, "fd_batch_deform_shared_dev: the contexts must share one rest rig (fd_batch_set_points_dev with the "
-                         "same rest array for all), kernel and term; context %d does not", i);
-            return FD_E_INVALID;
-        }
-        if (c->eval_precision != FD_EVAL_FP32 || c->eval_variant > 0 || record_layers(c) != 0) fast = false;
-    }
-    if (!fast) {
+    int ek = 0;
+    const int applies = shared_applies(b, "fd_batch_deform_shared_dev", d_P_out, &ek);
+    if (applies < 0) return applies;
+    if (applies == 0) {
         // any other kernel / precision: the per-frame launches on the shared arrays (same results as fd_deform_dev)
         const float *pin[kMaxBatch], *pd2[kMaxBatch], *ptu[kMaxBatch], *ptv[kMaxBatch], *pnr[kMaxBatch];
         for (int i = 0; i < b->n; ++i) { pin[i] = d_P_in; pd2[i] = d_dist2; ptu[i] = d_tu; ptv[i] = d_tv; pnr[i] = d_nrm; }
         rc = fd_batch_deform_dev(b, hip_stream, N, pin, d_P_out, d_dist2 ? pd2 : nullptr, d_falloff_out, d_tu ? ptu : nullptr,
                                  d_tu ? ptv : nullptr, d_tu ? pnr : nullptr, radius2, falloffrate);
         // these launches read the models to their end: fd_batch_wait_consumed waits for all of them
-        if (!b->packed_ev && hipEventCreateWithFlags(&b->packed_ev, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            b->packed_ev = nullptr;
-        }
-        if (rc == FD_OK && b->packed_ev) {
-            if (hipEventRecord(b->packed_ev, stream) != hipSuccess) { (void)hipGetLastError(); if (!rc) rc = FD_E_DEVICE; }
-            b->packed_valid = true;
+        if (rc == FD_OK && make_event(&b->fallback_ev)) {
+            if (hipEventRecord(b->fallback_ev, stream) != hipSuccess) { (void)hipGetLastError(); rc = FD_E_DEVICE; }
+            b->packed_valid = false;
         }
         return rc;
     }
+    // the prepared set, if it was packed from these models for these outputs; else pack now, on this stream
+    bool reuse = b->prepared && b->prep_has_fall == (d_falloff_out != nullptr);
+    for (int i = 0; reuse && i < b->n; ++i)
+        reuse = b->prep_P_out[i] == d_P_out[i] && (!d_falloff_out || b->prep_fall[i] == d_falloff_out[i]);
+    if (reuse) {
+        for (int i = 0; i < b->n; ++i)
+            if ((rc = order_after_batch(b->ctxs[i], stream))) { batch_err(b, "context %d: %s", i, b->ctxs[i]->err); return rc; }
+        if ((rc = batch_poll(b))) return rc;
+        if (!b->prepared) reuse = false;         // the poll repaired a model: pack again
+    }
+    if (reuse) {
+        fd_batch::SharedSet &ps = b->sets[b->cur_set];
+        if (ps.packed_ev && hipStreamWaitEvent(stream, ps.packed_ev, 0) != hipSuccess) {
+            batch_err(b, "fd_batch_deform_shared_dev: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
+            return FD_E_DEVICE;
+        }
+    } else if ((rc = shared_pack(b, stream, ek, d_P_out, d_falloff_out))) {
+        return rc;
+    }
+    fd_batch::SharedSet &st = b->sets[b->cur_set];
     SharedDeformArgs a{};
     a.N = N; a.P_in = d_P_in; a.dist2 = d_dist2; a.tu = d_tu; a.tv = d_tv; a.nrm = d_nrm;
     a.radius2 = radius2; a.falloffrate = falloffrate;
@@ -1611,47 +1728,32 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     a.ctiles = c0->d_tiles16;
     a.kind = ek;
     a.falloff_out = d_falloff_out;
-    for (int i = 0; i < b->n; ++i) {
-        fd_ctx *c = b->ctxs[i];
-        a.rec32[i] = c->d_rec32; a.model[i] = c->d_model; a.P_out[i] = d_P_out[i];
-        if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
-    }
-    if ((rc = batch_poll(b))) return rc;
-    const size_t wb = shared_wtile_bytes(a.Mpad, a.nF), fb = shared_frame_bytes(a.nF);
-    if (wb > b->cap_wtiles || fb > b->cap_frames) {
-        // (hipFree drains the device: no launch still reads the old scratch)
-        if (b->d_wtiles) (void)hipFree(b->d_wtiles);
-        if (b->d_frames) (void)hipFree(b->d_frames);
-    if (b->packed_ev) (void)hipEventDestroy(b->packed_ev);
-        b->d_wtiles = b->d_frames = nullptr; b->cap_wtiles = b->cap_frames = 0;
-        if (hipMalloc(&b->d_wtiles, wb) != hipSuccess || hipMalloc(&b->d_frames, fb) != hipSuccess) {
-            (void)hipGetLastError();
-            batch_err(b, "fd_batch_deform_shared_dev: scratch allocation (%zu bytes) failed", wb + fb);
-            return FD_E_NOMEM;
-        }
-        b->cap_wtiles = wb; b->cap_frames = fb;
-    }
-    a.wtiles = b->d_wtiles; a.frames = b->d_frames;
-    if (!b->packed_ev && hipEventCreateWithFlags(&b->packed_ev, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        b->packed_ev = nullptr;
-    }
-    a.packed_ev = b->packed_ev;
-    b->packed_valid = b->packed_ev != nullptr;
+    for (int i = 0; i < b->n; ++i) { a.rec32[i] = b->ctxs[i]->d_rec32; a.model[i] = b->ctxs[i]->d_model; a.P_out[i] = d_P_out[i]; }
+    a.wtiles = st.d_wtiles; a.frames = st.d_frames;
+    a.packed_ev = nullptr;
+    a.mode = 2;
     hipError_t e = launch_deform_shared(a, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_shared failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
+    if (make_event(&st.eval_ev)) {
+        if (hipEventRecord(st.eval_ev, stream) != hipSuccess) { (void)hipGetLastError(); st.eval_pending = false; }
+        else st.eval_pending = true;
+    } else {
+        // no event to order the next pack of this set by: be safe
+        (void)hipStreamSynchronize(stream);
+    }
     return FD_OK;
 }
 
 int fd_batch_wait_consumed(fd_batch *b, void *hip_stream)
 {
     if (!b) return FD_E_INVALID;
-    if (!b->packed_valid) return FD_OK;          // no shared-rig evaluation enqueued: nothing reads the models beyond stream order
+    hipEvent_t ev = b->packed_valid ? b->sets[b->cur_set].packed_ev : b->fallback_ev;
+    if (!ev) return FD_OK;          // no shared-rig evaluation enqueued: nothing reads the models beyond stream order
     fd_ctx *c0 = b->ctxs[0];
     int rc = use_device(c0);
     if (rc) { batch_err(b, "%s", c0->err); return rc; }
     hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : cur_stream(c0);
-    if (hipStreamWaitEvent(stream, b->packed_ev, 0) != hipSuccess) {
+    if (hipStreamWaitEvent(stream, ev, 0) != hipSuccess) {
         batch_err(b, "fd_batch_wait_consumed: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
         return FD_E_DEVICE;
     }

@@ -715,11 +715,14 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         slots.rec32[f] = a.rec32[q]; slots.model[f] = a.model[q];
         out.P_out[f] = a.P_out[q]; out.falloff_out[f] = a.falloff_out ? a.falloff_out[q] : nullptr;
     }
-    hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
-                       (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
-    if (a.packed_ev) {
-        hipError_t e = hipEventRecord(a.packed_ev, stream);
-        if (e != hipSuccess) return e;
+    if (a.mode != 2) {
+        hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
+                           (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
+        if (a.packed_ev) {
+            hipError_t e = hipEventRecord(a.packed_ev, stream);
+            if (e != hipSuccess) return e;
+        }
+        if (a.mode == 1) return hipGetLastError();
     }
     SharedParams p{};
     p.N = a.N; p.P_in = a.P_in; p.dist2 = a.dist2; p.tu = a.tu; p.tv = a.tv; p.nrm = a.nrm;

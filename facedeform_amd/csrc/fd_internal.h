@@ -219,6 +219,8 @@ struct SharedDeformArgs {
     void *wtiles, *frames;                // scratch of shared_wtile_bytes / shared_frame_bytes
     hipEvent_t packed_ev;                 // recorded once the pack kernel has read the models (may be null): from then on the
                                           // launch reads nothing of the contexts -- their next build may start
+    int mode;                             // 0: pack kernel + evaluation; 1: pack kernel only (fd_batch_prepare_shared);
+                                          // 2: evaluation only, on a scratch set packed earlier
 };
 hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream);
 size_t shared_wtile_bytes(int Mpad, int nF);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 5   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed (additions only) */
+#define FD_ABI_VERSION 5   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared (additions only) */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -331,6 +331,15 @@ int fd_batch_deform_shared_dev(fd_batch *batch, void *hip_stream, int64_t N, con
  * the current ones are still being evaluated.  (The output arrays ARE still being written: they stay the caller's to
  * order.)  No-op when no shared-rig evaluation has been enqueued on the batch. */
 int fd_batch_wait_consumed(fd_batch *batch, void *hip_stream);
+/* The first, small part of fd_batch_deform_shared_dev on its own, on a stream of the caller's choice (NULL: context
+ * 0's) -- typically the build stream, right behind fd_batch_build_async: the models' weights become fp16 tiles in
+ * the batch's scratch (two sets, used in turn) together with the frames' output addresses.  A following
+ * fd_batch_deform_shared_dev with the SAME output tables then launches the evaluation alone (its stream waits for
+ * this kernel), so an evaluation stream runs evaluations back to back while packing happens beside the builds.
+ * Invalidated by the next fd_batch_set_points_dev / fd_batch_build_async (and by a model the library had to
+ * rebuild); without it, or with other outputs, fd_batch_deform_shared_dev packs by itself as before.  A no-op when
+ * the shared-rig launch does not apply to the batch (other kernels). */
+int fd_batch_prepare_shared(fd_batch *batch, void *hip_stream, float *const *d_P_out, float *const *d_falloff_out);
 
 /* ---- dist2 producer (next row N2) ---------------------------------------------
  * The per-point body of ProximityCapture::capture (src/capture.cpp:58-97) on the

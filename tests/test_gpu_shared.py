@@ -230,3 +230,54 @@ def test_shared_frames_of_the_gaussian_models(hip_lib, oracle, kind, okind, para
         a, b = outs[f].cpu().numpy(), single[f].cpu().numpy()
         assert parity_ratio(a, b, P, TOL) <= 1.0, f
     _close(engines, batch)
+
+
+def test_prepared_sets_give_the_same_bits_and_survive_a_pipeline(hip_lib):
+    """fd_batch_prepare_shared packs the models on the build stream; the evaluation that follows with the same
+    outputs launches alone.  Three groups cooked back to back on ONE batch, as a lane of bench.py cooks them (build,
+    prepare on the lane stream; evaluate on another stream that only waits for the lane), must equal the same
+    groups cooked one at a time with the launch packing for itself -- bit for bit: the two scratch sets are used in
+    turn and a set is not rewritten while the evaluation that reads it is still running."""
+    N, M, F, G = 300_000, 256, 16, 3
+    dev = torch.device("cuda", 0)
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    d_P = torch.from_numpy(P).to(dev)
+    d_rest = torch.from_numpy(rest).to(dev)
+    groups = [np.stack([synth.smooth_deltas(rest, (g * F + f) % 8) * np.float32(1.0 + 0.125 * ((g * F + f) // 8)) for f in range(F)])
+              for g in range(G)]
+    d_del = [torch.from_numpy(d).to(dev) for d in groups]
+    lane, es = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    engines = []
+    for _ in range(F):
+        e = capi.Engine(); e.set_stream(lane.cuda_stream); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
+        engines.append(e)
+    batch = capi.Batch(engines)
+    outs = [[torch.empty_like(d_P) for _ in range(F)] for _ in range(G)]
+    falls = [[torch.zeros(N, device=dev) for _ in range(F)] for _ in range(G)]
+    ref_out = [torch.empty_like(d_P) for _ in range(F)]
+    ref_fall = [torch.zeros(N, device=dev) for _ in range(F)]
+    torch.cuda.synchronize()
+    built = torch.cuda.Event()
+    for g in range(G):                                   # pipelined: nothing waits for an evaluation
+        batch.set_points_dev([d_rest.data_ptr()] * F, [d_del[g].data_ptr() + f * M * 12 for f in range(F)], M)
+        batch.build_async(lane.cuda_stream)
+        batch.prepare_shared([o.data_ptr() for o in outs[g]], d_falloff=[x.data_ptr() for x in falls[g]], stream_ptr=lane.cuda_stream)
+        built.record(lane)
+        es.wait_event(built)
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs[g]], d_falloff=[x.data_ptr() for x in falls[g]],
+                                stream_ptr=es.cuda_stream)
+    torch.cuda.synchronize()
+    assert [r.terminationtype for r in batch.build_result()] == [1] * F
+    for g in range(G):                                   # one at a time, the launch packs for itself
+        batch.set_points_dev([d_rest.data_ptr()] * F, [d_del[g].data_ptr() + f * M * 12 for f in range(F)], M)
+        batch.build_async(lane.cuda_stream)
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in ref_out], d_falloff=[x.data_ptr() for x in ref_fall],
+                                stream_ptr=lane.cuda_stream)
+        torch.cuda.synchronize()
+        for f in range(F):
+            assert torch.equal(outs[g][f], ref_out[f]), (g, f)
+            assert torch.equal(falls[g][f], ref_fall[f]), (g, f)
+    batch.close()
+    for e in engines:
+        e.set_stream(None); e.close()
