@@ -501,14 +501,9 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
             // and the fp16 split per lane).  Inside one wave the two would otherwise run back to back -- the
             // logarithms with the matrix pipe idle, then 72 matrix instructions with the vector unit idle -- and two
             // waves per SIMD running the same program do not interleave well enough to hide either.
-            u32x4 bh[TV], bl[TV];
-            phi_block(0, bh, bl);
-            for (int kb = 0; kb + 1 < nk; ++kb) {
-                u32x4 nbh[TV], nbl[TV];
-                phi_block(kb + 1, nbh, nbl);
-                contract(kb, bh, bl);
-                // issue order inside this block: one matrix instruction, then the vector work that fits under it
-                // (thin-plate only; the Gaussian block is left to the scheduler's own order)
+            auto interleave = [&]() {
+                // issue order inside the block just written: one matrix instruction, then the vector work that fits
+                // under it (thin-plate only; the Gaussian block is left to the scheduler's own order)
                 if constexpr (!GAUSS) {
 #pragma unroll
                     for (int q = 0; q < 32; ++q) {
@@ -522,11 +517,46 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
                         __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
                     }
                 }
-                // (unrolling by two with the buffers swapped instead of these 32 copies spills: 109 registers)
+            };
+#ifdef FD_KLOOP_UNROLL2
+            // Two operand buffers in turn: the loop is unrolled by two so that neither is ever copied; a full scheduling
+            // barrier between the halves keeps the second half's operand loads out of the first (unfenced: 109 spills)
+            u32x4 bhA[TV], blA[TV], bhB[TV], blB[TV];
+            phi_block(0, bhA, blA);
+            int kb = 0;
+            for (; kb + 2 < nk; kb += 2) {
+                phi_block(kb + 1, bhB, blB);
+                contract(kb, bhA, blA);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                phi_block(kb + 2, bhA, blA);
+                contract(kb + 1, bhB, blB);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kb + 1 < nk) {
+                phi_block(kb + 1, bhB, blB);
+                contract(kb, bhA, blA);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                contract(kb + 1, bhB, blB);
+            } else {
+                contract(kb, bhA, blA);
+            }
+#else
+            u32x4 bh[TV], bl[TV];
+            phi_block(0, bh, bl);
+            for (int kb = 0; kb + 1 < nk; ++kb) {
+                u32x4 nbh[TV], nbl[TV];
+                phi_block(kb + 1, nbh, nbl);
+                contract(kb, bh, bl);
+                interleave();
+                // (32 register copies per block; FD_KLOOP_UNROLL2 is the variant without them)
 #pragma unroll
                 for (int t = 0; t < TV; ++t) { bh[t] = nbh[t]; bl[t] = nbl[t]; }
             }
             contract(nk - 1, bh, bl);
+#endif
         }
 
         FD_SSTAMP(1)

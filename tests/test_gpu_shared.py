@@ -281,3 +281,30 @@ def test_prepared_sets_give_the_same_bits_and_survive_a_pipeline(hip_lib):
     batch.close()
     for e in engines:
         e.set_stream(None); e.close()
+
+
+@pytest.mark.parametrize("kind,params", [(capi.KERNEL_GAUSSIAN_QNN, (1.0, 5.0)), (capi.KERNEL_THIN_PLATE, ())])
+def test_repeated_launches_give_the_same_bits_at_full_size(hip_lib, kind, params):
+    """A guard against the class of fault found while bringing up the Gaussian kinds (a vector instruction racing an
+    in-flight transcendental for its source register: wrong values on a few vertices, different ones per launch, no
+    fault).  Any such race shows as a difference between two launches of the same work: 1M vertices x 32 frames through
+    the shared-rig launch and 1M vertices through the one-frame kernel, five times each, must agree bit for bit."""
+    N, M, F = 1_000_000, 256, 32
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F, kind=kind, params=params)
+    first = [torch.empty_like(d_P) for _ in range(F)]
+    again = [torch.empty_like(d_P) for _ in range(F)]
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in first])
+    torch.cuda.synchronize()
+    for rep in range(4):
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in again])
+        torch.cuda.synchronize()
+        for f in range(F):
+            assert torch.equal(first[f], again[f]), (rep, f, int((first[f] != again[f]).any(dim=1).sum()))
+    one, two = torch.empty_like(d_P), torch.empty_like(d_P)
+    engines[3].deform_dev(N, d_P.data_ptr(), one.data_ptr())
+    engines[3].synchronize()
+    for rep in range(4):
+        engines[3].deform_dev(N, d_P.data_ptr(), two.data_ptr())
+        engines[3].synchronize()
+        assert torch.equal(one, two), (rep, int((one != two).any(dim=1).sum()))
+    _close(engines, batch)
