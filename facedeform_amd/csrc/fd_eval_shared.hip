@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, co
 // PLAIN: the same two pieces from instructions the compiler sees (conversions and a subtraction: about twice as
 // many).  The Gaussian kinds take this form: there the inputs come straight from v_exp_f32, and a vector
 // instruction hidden in an asm string that reads a transcendental's result gets none of the wait states the
-// compiler pads that pair with.
+// compiler pads that pair with (hipcc pads nothing inside or around asm strings).
 template <bool PLAIN = false>
 __device__ __forceinline__ void split_pair_f16(float v0, float v1, unsigned &hi, unsigned &lo)
 {
@@ -432,34 +432,31 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
                     for (int sl = 0; sl < 4; ++sl) c[sl] = cr[16 * hf + 4 * g + sl];
 #pragma unroll
                     for (int tp = 0; tp < TV; tp += 2) {
-                        const f32x2 X = {xn[tp], xn[tp + 1]}, Y = {yn[tp], yn[tp + 1]}, Z = {zn[tp], zn[tp + 1]};
-                        f32x2 ph[4], ee[4];
+                        float ph[4][2];
 #pragma unroll
                         for (int sl = 0; sl < 4; ++sl) {
-                            const f32x2 dx = X - (f32x2){c[sl].x, c[sl].x}, dy = Y - (f32x2){c[sl].y, c[sl].y}, dz = Z - (f32x2){c[sl].z, c[sl].z};
-                            f32x2 d2 = dx * dx;
-                            d2 = __builtin_elementwise_fma(dy, dy, d2);
-                            d2 = __builtin_elementwise_fma(dz, dz, d2);
-                            ee[sl] = __builtin_elementwise_fma(d2, (f32x2){c[sl].w, c[sl].w}, (f32x2){(float)kGaussShift, (float)kGaussShift});
-                            ph[sl] = (f32x2){__builtin_amdgcn_exp2f(ee[sl].x), __builtin_amdgcn_exp2f(ee[sl].y)};
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                // ONE value per instruction.  The packed form (v_pk_add/mul/fma_f32 on two vertex tiles at
+                                // once, 7 instructions instead of 14) gave results that differed from launch to launch on a
+                                // few vertices per million once this block ran software-pipelined under the matrix
+                                // instructions of the previous one -- with v_exp_f32 and with a polynomial exponential
+                                // alike, not without the pipelining; this form: no difference in 54 launches of 32M
+                                // vertex-frames each (tests/test_gpu_shared.py::test_repeated_launches...).  Cause not
+                                // established; the thin-plate block has no packed arithmetic.
+                                const float dx = xn[tp + u] - c[sl].x, dy = yn[tp + u] - c[sl].y, dz = zn[tp + u] - c[sl].z;
+                                float d2 = dx * dx;
+                                d2 = __builtin_fmaf(dy, dy, d2);
+                                d2 = __builtin_fmaf(dz, dz, d2);
+                                ph[sl][u] = __builtin_amdgcn_exp2f(__builtin_fmaf(d2, c[sl].w, (float)kGaussShift));
+                            }
                         }
-
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             unsigned h, l;
-                            split_pair_f16<true>(ph[2 * q].x, ph[2 * q + 1].x, h, l); xh[tp][2 * hf + q] = h; xl[tp][2 * hf + q] = l;
-                            split_pair_f16<true>(ph[2 * q].y, ph[2 * q + 1].y, h, l); xh[tp + 1][2 * hf + q] = h; xl[tp + 1][2 * hf + q] = l;
+                            split_pair_f16<true>(ph[2 * q][0], ph[2 * q + 1][0], h, l); xh[tp][2 * hf + q] = h; xl[tp][2 * hf + q] = l;
+                            split_pair_f16<true>(ph[2 * q][1], ph[2 * q + 1][1], h, l); xh[tp + 1][2 * hf + q] = h; xl[tp + 1][2 * hf + q] = l;
                         }
-                        // The exponentials' SOURCE registers stay alive until the pieces above exist.  Measured on gfx950
-                        // (ROCm 7.2): a vector instruction that overwrites the source of a v_exp_f32 issued just before it
-                        // can win the race against the transcendental unit reading that source -- which the compiler allows
-                        // (write-after-read on a dead temporary) and the hardware does not interlock: phi wrong on a few
-                        // vertices per launch, different ones from launch to launch (it depends on what the SIMD's other
-                        // wave issues in between); no fault.  With the sources held: 0 failures in 20 test runs, without:
-                        // 5 of 5 (tests/test_gpu_shared.py::test_shared_frames_of_the_gaussian_models).  The thin-plate
-                        // path is not exposed: its logarithms read matrix-instruction results that live a whole block.
-                        asm volatile("" :: "v"(ee[0].x), "v"(ee[0].y), "v"(ee[1].x), "v"(ee[1].y), "v"(ee[2].x), "v"(ee[2].y), "v"(ee[3].x), "v"(ee[3].y),
-                                           "v"(xh[tp][2 * hf]), "v"(xh[tp + 1][2 * hf + 1]), "v"(xl[tp][2 * hf]), "v"(xl[tp + 1][2 * hf + 1]));
                     }
                 }
                 return;

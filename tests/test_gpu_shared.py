@@ -190,7 +190,7 @@ def test_contexts_may_be_rebuilt_once_the_launch_has_its_copy(hip_lib, oracle):
     (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0), 256, 30_011, 32),      # the SOP's default model, dense layout
     (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0), 100, 4_099, 5),        # padded layout, ragged sizes
     (capi.KERNEL_GAUSSIAN, fo.KERNEL_GAUSSIAN, (0.15,), 256, 10_000, 16),                 # one radius for all centres
-    (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0), 256, 10_000, 16),      # 16 frames: three tiles, the mix that exposed a scheduling hazard
+    (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0), 256, 10_000, 16),      # 16 frames: three tiles per component block
     (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (2.0, 5.0), 512, 6_000, 24),
 ])
 def test_shared_frames_of_the_gaussian_models(hip_lib, oracle, kind, okind, params, M, N, F):
@@ -285,10 +285,11 @@ def test_prepared_sets_give_the_same_bits_and_survive_a_pipeline(hip_lib):
 
 @pytest.mark.parametrize("kind,params", [(capi.KERNEL_GAUSSIAN_QNN, (1.0, 5.0)), (capi.KERNEL_THIN_PLATE, ())])
 def test_repeated_launches_give_the_same_bits_at_full_size(hip_lib, kind, params):
-    """A guard against the class of fault found while bringing up the Gaussian kinds (a vector instruction racing an
-    in-flight transcendental for its source register: wrong values on a few vertices, different ones per launch, no
-    fault).  Any such race shows as a difference between two launches of the same work: 1M vertices x 32 frames through
-    the shared-rig launch and 1M vertices through the one-frame kernel, five times each, must agree bit for bit."""
+    """A guard against the class of fault found while bringing up the Gaussian kinds (packed fp32 arithmetic
+    software-pipelined under matrix instructions: wrong values on a few vertices per million, different ones per
+    launch, no fault).  Anything of that kind shows as a difference between two launches of the same
+    work: 1M vertices x 32 frames through the shared-rig launch and 1M vertices through the one-frame kernel, five
+    times each, must agree bit for bit."""
     N, M, F = 1_000_000, 256, 32
     dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F, kind=kind, params=params)
     first = [torch.empty_like(d_P) for _ in range(F)]
