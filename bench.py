@@ -204,7 +204,12 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
                         for k, eng in enumerate(engines):
                             eng.import_model_dev(blob[k].data_ptr(), nbytes, n_ctrl)
                 if e: e[2].record(stream)
-                if n_mine > 0:
+                if n_mine > 0 and args.eval_launch == "shared" and B > 1:
+                    # the frames of a group share the mesh and the rest rig (imported models carry the rig's identity):
+                    # phi once per (vertex, centre) for all of them, on this rank's vertex range
+                    batch.deform_shared_dev(n_mine, d_P.data_ptr(), [o.data_ptr() for o in ln["out"]],
+                                            d_falloff=[f.data_ptr() for f in ln["fall"]], stream_ptr=stream.cuda_stream)
+                elif n_mine > 0:
                     batch.deform_dev(n_mine, [d_P.data_ptr()] * B, [o.data_ptr() for o in ln["out"]],
                                      d_falloff=[f.data_ptr() for f in ln["fall"]], stream_ptr=stream.cuda_stream)
                 if e: e[3].record(stream)
@@ -244,7 +249,10 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_r["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc + ", thin-plate kernel, linear term, d2 on fp16x2-split MFMA with fp32 accumulation, models rebuilt " +
+            "config": {"workload": desc + ", thin-plate kernel, linear term, " +
+                                   ("the frames of a group share mesh and rest rig: phi once per (vertex, centre), weight contraction on the "
+                                    "fp16 matrix pipe (fp16 x 2 split, fp32 accumulate), " if args.eval_launch == "shared" and B > 1 else
+                                    "d2 on fp16x2-split MFMA with fp32 accumulation, ") + "models rebuilt " +
                                    ("on every rank every step " if redundant else "on rank 0 every step ") +
                                    f"({B} per batched build)" + ("" if redundant else f", one broadcast per {B} frames"),
                        "n_verts": n_verts,
@@ -253,10 +261,7 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
                        "parallelism": (f"vertex ranges over {world} GPU(s), every rank solves the models itself, {n_lanes} lanes" if redundant else
                                        f"vertex ranges over {world} GPU(s), 1 broadcast per {B} frames, {n_lanes} lanes")},
             "ranks": ranks,
-            "roofline": {"bound": "valu_fp32", "kernel": "k_deform32_tps_mfma_batch" if B > 1 else "k_deform32_tps_mfma",
-                         "achieved": tf, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": None,
-                         "flops_per_launch": flops, "avg_launch_ms": main_r["eval_ms"], "frames_per_launch": B},
+            "roofline": c5_roofline(args, B, n_ctrl, n_mine, main_r["eval_ms"], flops, tf),
             "phases_ms": {"build_group_rank0": main_r["build_ms"], "broadcast_and_import": main_r["bcast_ms"],
                           "evaluate_group": main_r["eval_ms"]},
             # the other way of getting the model to every rank, same run, same sizes
@@ -272,6 +277,26 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
             e.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def c5_roofline(args, B, n_ctrl, n_mine, eval_ms, flops_frames, tf_frames):
+    """Roofline block of the C5 line: the shared-rig launch on this rank's vertex range (bound by the roofline model at
+    its algorithmic intensity, as in the C2 line), or the one-frame kernels when asked for."""
+    if args.eval_launch == "shared" and B > 1:
+        secs = eval_ms * 1e-3
+        fl = ((8 + 6 * B) * n_ctrl + FLOPS_PER_VERTEX_AFFINE * B) * n_mine
+        by = (12 + 16 * B) * n_mine
+        ridge = PEAK_FP16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        hbm = {"achieved": by / secs / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / secs / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": by}
+        mfma = {"achieved": fl / secs / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+                "flops_per_launch": fl}
+        first = hbm if fl / by < ridge else mfma
+        return {"bound": "hbm" if fl / by < ridge else "mfma", "kernel": "k_deform32_tps_shared", "achieved": first["achieved"],
+                "peak": first["peak"], "unit": first["unit"], "frac": first["frac"], "traffic": None, "avg_launch_ms": eval_ms,
+                "frames_per_launch": B, "intensity_flop_per_byte": fl / by, "ridge_flop_per_byte": ridge, "hbm": hbm, "mfma": mfma}
+    return {"bound": "valu_fp32", "kernel": "k_deform32_tps_mfma_batch" if B > 1 else "k_deform32_tps_mfma",
+            "achieved": tf_frames, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf_frames / PEAK_FP32_TFLOPS, "traffic": None,
+            "flops_per_launch": flops_frames, "avg_launch_ms": eval_ms, "frames_per_launch": B}
 
 
 def shared_rows(frames):

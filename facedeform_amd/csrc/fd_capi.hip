@@ -1214,6 +1214,7 @@ int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device)
     h->terminationtype = 1;
     h->layers = record_layers(ctx);
     memcpy(h->params, ctx->params, sizeof(h->params));
+    h->rig_token = (uint64_t)(uintptr_t)ctx->rest_src;
     char *p = (char *)buf;
     const hipMemcpyKind kh = on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
     const hipMemcpyKind kd = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -1268,6 +1269,9 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     ctx->have_factor = false;
     ctx->deltas_only = false;
     ctx->points_set = false;   // no rest/delta on this context: it can deform, not rebuild
+    // never dereferenced, only compared: bit 0 marks an imported identity (arrays are at least 4-byte aligned), so that it
+    // can only ever equal another imported model's
+    ctx->rest_src = h.rig_token ? (const float *)(uintptr_t)(h.rig_token | 1u) : nullptr;
     ctx->build_pending = false;
     ctx->built = true;
     fd_report r{};

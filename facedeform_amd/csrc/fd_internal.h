@@ -79,14 +79,18 @@ struct DevModel {
 
 // Blob header for fd_export_model / fd_import_model.
 struct ModelHeader {
-    uint32_t magic;        // 'FDM1'
+    uint32_t magic;        // 'FDM2'
     int32_t M, kind, term, nparams;
     int32_t terminationtype;
     int32_t layers;        // multilayer Gaussian model: records per centre (the blob's arrays are layer-major); 0 otherwise
     int32_t reserved;
     double params[4];
+    // Identity of the rest rig the model was built on: the exporter's in-place rest array (fd_batch_set_points_dev), 0 when
+    // it had none.  Models imported with the same non-zero token came from ONE rest rig -- frames of a shot that one rank
+    // solved and the others received -- which is what fd_batch_deform_shared_dev needs to know about them.
+    uint64_t rig_token;
 };
-constexpr uint32_t kModelMagic = 0x314D4446u;
+constexpr uint32_t kModelMagic = 0x324D4446u;
 
 static inline int term_cols(int term) { return term == FD_TERM_LINEAR ? 4 : (term == FD_TERM_CONST ? 1 : 0); }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

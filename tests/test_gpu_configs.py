@@ -189,3 +189,61 @@ def test_c5_ten_million_vertices_in_eight_ranges(hip_lib, oracle):
     idx = np.unique(np.concatenate([np.arange(0, N, 2003), np.asarray(bounds)]))
     _check_sample(oracle, _oracle_model(oracle, rest, delta), P, whole, idx, "c5", raw_holds=False)
     root.close()
+
+
+def test_c5_frames_of_a_group_through_the_shared_rig_launch(hip_lib, oracle):
+    """Config 5 as bench.py --config c5 evaluates it: the solving rank builds a group of frames on one rest rig and
+    exports the models; a peer imports them (the blobs carry the rig's identity, so the peer's batch knows its models
+    share a rest rig) and evaluates ITS vertex range for all frames with one shared-rig launch.  Ranges against the
+    whole mesh bit for bit; a sample against the oracle; a batch mixing rigs is refused."""
+    N, M, F, G = 2_000_000, 512, 8, 4
+    dev = torch.device("cuda", 0)
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    deltas = np.stack([synth.smooth_deltas(rest, f) for f in range(F)])
+    d_P = torch.from_numpy(P).to(dev)
+    d_rest = torch.from_numpy(rest).to(dev)
+    d_del = torch.from_numpy(deltas).to(dev)
+    root = []
+    for _ in range(F):
+        e = capi.Engine(); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR); root.append(e)
+    rb = capi.Batch(root)
+    rb.set_points_dev([d_rest.data_ptr()] * F, [d_del.data_ptr() + f * M * 12 for f in range(F)], M)
+    rb.build_async()
+    assert [r.terminationtype for r in rb.build_result()] == [1] * F
+    whole = [torch.empty_like(d_P) for _ in range(F)]
+    rb.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in whole])
+    nbytes = root[0].model_bytes()
+    blob = torch.zeros((F, nbytes), dtype=torch.uint8, device=dev)
+    for k, e in enumerate(root):
+        e.export_model_dev(blob[k].data_ptr(), nbytes)
+        e.synchronize()
+    peers = []
+    for k in range(F):
+        e = capi.Engine(); e.import_model_dev(blob[k].data_ptr(), nbytes, M); peers.append(e)
+    pb = capi.Batch(peers)
+    parts = [torch.empty_like(d_P) for _ in range(F)]
+    for r in range(G):
+        lo, hi = fdist.vertex_range(N, r, G)
+        pb.deform_shared_dev(hi - lo, d_P.data_ptr() + 12 * lo, [o.data_ptr() + 12 * lo for o in parts])
+    torch.cuda.synchronize()
+    idx = np.unique(np.concatenate([np.arange(0, N, 1999), [0, N - 1]]))
+    for f in range(F):
+        assert torch.equal(parts[f], whole[f]), f
+        if f in (0, 5):
+            _check_sample(oracle, _oracle_model(oracle, rest, deltas[f]), P, whole[f].cpu().numpy(), idx, f"c5 shared frame {f}", raw_holds=False)
+    # a model from another rig among them: the shared launch must refuse, not evaluate on the wrong centres
+    other = capi.Engine(); other.set_kernel(capi.KERNEL_THIN_PLATE); other.set_term(capi.TERM_LINEAR)
+    rest2 = (rest * np.float32(1.01)).astype(np.float32)
+    other.set_points(rest2, deltas[0]); other.build()
+    ob = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    other.export_model_dev(ob.data_ptr(), nbytes); other.synchronize()
+    stranger = capi.Engine(); stranger.import_model_dev(ob.data_ptr(), nbytes, M)
+    mixed = capi.Batch(peers[:3] + [stranger])
+    with pytest.raises(capi.FdError) as ei:
+        mixed.deform_shared_dev(1000, d_P.data_ptr(), [o.data_ptr() for o in parts[:4]])
+    assert ei.value.code == capi.FD_E_INVALID and "one rest rig" in ei.value.text
+    for b in (mixed, pb, rb):
+        b.close()
+    for e in peers + root + [other, stranger]:
+        e.close()
