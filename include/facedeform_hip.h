@@ -244,7 +244,10 @@ int fd_get_weights(fd_ctx *ctx, double *W, double *radii);
 /* Solved model as one relocatable blob (header + centres + radii + weights):
  * what a vertex-range split broadcasts from the solving GPU (RCCL over xGMI,
  * or any other transport).  on_device != 0: buf is a device pointer and the
- * copy is enqueued on the context's stream. */
+ * copy is enqueued on the context's stream.  The header carries the identity of the rest rig the
+ * model was built on (the array fd_batch_set_points_dev read it from): contexts that imported
+ * models with the same identity form a batch fd_batch_deform_shared_dev accepts -- the frames of a
+ * shot, solved on one GPU, evaluated on every GPU's vertex range with one launch per group. */
 size_t fd_model_bytes(const fd_ctx *ctx);
 int fd_export_model(fd_ctx *ctx, void *buf, size_t capacity, int on_device);
 int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device);
