@@ -21,6 +21,8 @@ struct fd_ctx {
     int imported_layers = 0;         // a multilayer model that came in through fd_import_model
     const float *rest_src = nullptr; // caller's device array the rest points were last read from in place (fd_batch_set_points_dev), else null
     bool prefer_lu = false;          // the Cholesky path lost definiteness on this rig: LU until kernel, term or M change
+    unsigned long long model_gen = 0; // counts the models this context has held (every enqueued build, every import): what a
+                                     // batch's packed copy of the weights is checked against before it is reused
     bool last_spd = false;           // the build in flight / last finished took the Cholesky path
 
     // model configuration
@@ -135,6 +137,7 @@ struct fd_batch {
     int cur_set = 0;                     // the set packed last
     bool packed_valid = false;           // sets[cur_set].packed_ev is recorded (fd_batch_wait_consumed)
     bool prepared = false;               // sets[cur_set] holds the contexts' CURRENT models and prep_* outputs
+    unsigned long long prep_gen[kMaxBatch] = {0};   // the contexts' model_gen when the set was packed
     float *prep_P_out[kMaxBatch] = {nullptr};
     float *prep_fall[kMaxBatch] = {nullptr};
     bool prep_has_fall = false;
@@ -643,6 +646,7 @@ int fd_build_async(fd_ctx *ctx)
         ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
         ctx->last_spd = b.spd != 0;
         ctx->build_pending = true;
+        ++ctx->model_gen;
         ctx->built = false;
         ctx->have_report = false;
         ctx->sticky_rc = FD_OK;
@@ -697,6 +701,7 @@ int fd_build_async(fd_ctx *ctx)
     ctx->factor_grouped = false;
     ctx->deltas_only = false;
     ctx->build_pending = true;
+    ++ctx->model_gen;
     ctx->built = false;
     ctx->have_report = false;
     ctx->sticky_rc = FD_OK;
@@ -1268,6 +1273,7 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     ctx->have_factor = false;
     ctx->deltas_only = false;
+    ++ctx->model_gen;
     ctx->points_set = false;   // no rest/delta on this context: it can deform, not rebuild
     // never dereferenced, only compared: bit 0 marks an imported identity (arrays are at least 4-byte aligned), so that it
     // can only ever equal another imported model's
@@ -1481,6 +1487,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         c->last_spd = bb.spd != 0;
         c->deltas_only = false;
         c->build_pending = true;
+        ++c->model_gen;
         c->built = false;
         c->have_report = false;
         c->sticky_rc = FD_OK;
@@ -1657,7 +1664,10 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
     b->cur_set = si;
     b->packed_valid = st.packed_ev != nullptr;
     b->prepared = true;
-    for (int i = 0; i < b->n; ++i) { b->prep_P_out[i] = d_P_out[i]; b->prep_fall[i] = d_falloff_out ? d_falloff_out[i] : nullptr; }
+    for (int i = 0; i < b->n; ++i) {
+        b->prep_P_out[i] = d_P_out[i]; b->prep_fall[i] = d_falloff_out ? d_falloff_out[i] : nullptr;
+        b->prep_gen[i] = b->ctxs[i]->model_gen;
+    }
     b->prep_has_fall = d_falloff_out != nullptr;
     return FD_OK;
 }
@@ -1708,7 +1718,8 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     // the prepared set, if it was packed from these models for these outputs; else pack now, on this stream
     bool reuse = b->prepared && b->prep_has_fall == (d_falloff_out != nullptr);
     for (int i = 0; reuse && i < b->n; ++i)
-        reuse = b->prep_P_out[i] == d_P_out[i] && (!d_falloff_out || b->prep_fall[i] == d_falloff_out[i]);
+        reuse = b->prep_P_out[i] == d_P_out[i] && (!d_falloff_out || b->prep_fall[i] == d_falloff_out[i]) &&
+                b->prep_gen[i] == b->ctxs[i]->model_gen;          // a context rebuilt or re-imported on its own since: pack again
     if (reuse) {
         for (int i = 0; i < b->n; ++i)
             if ((rc = order_after_batch(b->ctxs[i], stream))) { batch_err(b, "context %d: %s", i, b->ctxs[i]->err); return rc; }

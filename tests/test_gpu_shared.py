@@ -309,3 +309,32 @@ def test_repeated_launches_give_the_same_bits_at_full_size(hip_lib, kind, params
         engines[3].synchronize()
         assert torch.equal(one, two), (rep, int((one != two).any(dim=1).sum()))
     _close(engines, batch)
+
+
+def test_a_member_rebuilt_on_its_own_is_not_evaluated_from_a_stale_copy(hip_lib, oracle):
+    """The launch evaluates from the batch's packed copy of the weights and reuses that copy when nothing changed.
+    A context rebuilt on its own (not through the batch) between two launches -- new deltas for one frame -- must be
+    seen: the second launch gives that frame its NEW displacement, the others unchanged bits."""
+    M, N, F = 256, 20_000, 8
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F)
+    outs = [torch.empty_like(d_P) for _ in range(F)]
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])
+    torch.cuda.synchronize()
+    before = [o.clone() for o in outs]
+    new_delta = (deltas[2] * np.float32(-0.5)).astype(np.float32)
+    d_new = torch.from_numpy(new_delta).to(dev)
+    single = capi.Batch([engines[2]])                      # the same context, rebuilt through a batch of one (in-place rest array)
+    single.set_points_dev([keep[0].data_ptr()], [d_new.data_ptr()], M)
+    single.build_async(); assert single.build_result()[0].terminationtype == 1
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])
+    torch.cuda.synchronize()
+    for f in range(F):
+        if f != 2:
+            assert torch.equal(outs[f], before[f]), f
+    table = oracle.control_table(rest, (rest + new_delta).astype(np.float32))
+    rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+    ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    assert parity_ratio(outs[2].cpu().numpy(), ref, P, TOL) <= 1.0
+    assert not torch.equal(outs[2], before[2])
+    single.close()
+    _close(engines, batch)
