@@ -28,4 +28,7 @@ python3 tests/tools/shared_eval_timing.py c2 8,32 qnn >> $OUT/shared_timing_c2.t
 python3 tests/tools/hbm_write_rate.py > $OUT/hbm_write_rate.txt 2>&1
 tools/ubench_mfma16 > $OUT/ubench_mfma16.txt 2>&1
 python3 tools/build_latency.py 256,512,2048 11 > $OUT/solver_latency.txt 2>&1
+python3 bench.py --config c3 --no-cpu-baseline > $OUT/bench_c3_line.json 2>/dev/null
+python3 bench.py --config c5 --no-cpu-baseline > $OUT/bench_c5_line.json 2>/dev/null
+python3 tools/capture_bench.py > $OUT/capture_bench.txt 2>&1
 find $OUT -name "*.csv" | wc -l

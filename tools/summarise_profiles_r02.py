@@ -20,8 +20,10 @@ def clean(path):
 
 def main():
     for a, b in (("bench_c2_line.json", "r02_bench_c2_line.json"), ("bench_c2_profiled.json", "r02_bench_c2_profiled_line.json"),
-                 ("bench_c2_independent_line.json", "r02_bench_c2_independent_line.json")):
-        json.dump(last_json(f"{SRC}/{a}"), open(f"{DST}/{b}", "w"), indent=1)
+                 ("bench_c2_independent_line.json", "r02_bench_c2_independent_line.json"), ("bench_c3_line.json", "r02_bench_c3_line.json"),
+                 ("bench_c5_line.json", "r02_bench_c5_line.json")):
+        if os.path.exists(f"{SRC}/{a}"):
+            json.dump(last_json(f"{SRC}/{a}"), open(f"{DST}/{b}", "w"), indent=1)
     shutil.copy(glob.glob(f"{SRC}/bench/**/*kernel_stats.csv", recursive=True)[0], f"{DST}/r02_bench_c2_kernel_stats.csv")
     shutil.copy(glob.glob(f"{SRC}/shared/**/*kernel_stats.csv", recursive=True)[0], f"{DST}/r02_shared_c2_kernel_stats.csv")
     for a, b in (("scaled_delta_parity.txt", "r02_scaled_delta_parity.txt"), ("shared_timing_c2.txt", "r02_shared_timing.txt"),
