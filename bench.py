@@ -74,6 +74,11 @@ def parse_args():
                     help="shared evaluation: CUs it occupies (one persistent workgroup each, all of a CU's LDS); the rest stay "
                          "free for the builds of the next groups, which otherwise only run in the gaps between evaluation "
                          "launches (measured: 224 -> 113k Mverts/s, 256 -> 101k, 192 -> 109k; 0 = all 256)")
+    ap.add_argument("--cu-split", choices=["mask", "none"], default="none",
+                    help="mask: the evaluation stream and the build streams are created with complementary CU masks "
+                         "(hipExtStreamCreateWithCUMask): --eval-cus CUs for the evaluation, the others for the builds.  Measured "
+                         "worse (68k against 112k Mverts/s: confined to 32 CUs a batched build takes 1.37 ms instead of 0.8 -- "
+                         "unconfined, the builds also use the evaluation's CUs between its launches); kept for the record")
     ap.add_argument("--c5-solve", choices=["broadcast", "redundant"], default="broadcast",
                     help="config c5: rank 0 solves and broadcasts the models (default), or every rank solves them itself")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
@@ -299,6 +304,48 @@ def c5_roofline(args, B, n_ctrl, n_mine, eval_ms, flops_frames, tf_frames):
             "flops_per_launch": flops_frames, "avg_launch_ms": eval_ms, "frames_per_launch": B}
 
 
+def masked_streams(torch, dev, n_build_streams, eval_cus, total_cus=256):
+    """One evaluation stream and n build streams on complementary CU masks (hipExtStreamCreateWithCUMask), wrapped as
+    torch ExternalStreams.  The build CUs are spread evenly whichever way the mask's bits map onto the XCDs (bit i of
+    block i // 32 with i % 8 == block: four per XCD under an XCD-major as under an XCD-interleaved numbering, 32 in all;
+    more or fewer are taken in the same pattern).  Returns None where the runtime lacks the call."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        create = hip.hipExtStreamCreateWithCUMask
+    except (OSError, AttributeError):
+        return None
+    create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    create.restype = ctypes.c_int
+    n_build = total_cus - eval_cus
+    if n_build <= 0 or n_build >= total_cus:
+        return None
+    order = sorted(range(total_cus), key=lambda i: ((i % 8 - i // 32) % 8, i // 8 % 4, i))     # the pattern above first
+    build_bits = set(order[:n_build])
+    words = total_cus // 32
+
+    def mask(bits):
+        arr = (ctypes.c_uint32 * words)()
+        for i in bits:
+            arr[i // 32] |= 1 << (i % 32)
+        return arr
+
+    def make(bits):
+        h = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = create(ctypes.byref(h), words, mask(bits))
+        if rc != 0 or not h.value:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        return torch.cuda.ExternalStream(h.value, device=dev)
+
+    try:
+        ev = make(set(range(total_cus)) - build_bits)
+        builds = [make(build_bits) for _ in range(n_build_streams)]
+    except RuntimeError:
+        return None
+    return ev, builds
+
+
 def shared_rows(frames):
     """Rows of the weight operand the shared-rig launch runs for `frames` frames (16 per output tile; mirrors
     launch_deform_shared in csrc/fd_eval.hip: 13 frames and more in blocks of 16, one tile per component;
@@ -419,9 +466,16 @@ def main():
     B = max(1, min(args.inflight, capi.MAX_BATCH))
     n_lanes = max(1, args.lanes)
     eval_stream = torch.cuda.Stream(device=dev)
+    build_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
+    cu_split = "none"
+    if args.cu_split == "mask" and args.eval_launch == "shared" and B > 1 and 0 < args.eval_cus < 256 and not rehearse:
+        ms = masked_streams(torch, dev, n_lanes, args.eval_cus)
+        if ms is not None:
+            eval_stream, build_streams = ms
+            cu_split = "mask"
     lanes = []
-    for _ in range(n_lanes):
-        stream = torch.cuda.Stream(device=dev)
+    for li in range(n_lanes):
+        stream = build_streams[li]
         engines = []
         for _ in range(B):
             eng = capi.Engine(device=local_rank, precision=precision, variant=args.variant)
@@ -709,6 +763,7 @@ def main():
                 "frames_per_batched_build": B, "frames_per_evaluation_launch": frames_per_launch,
                 "evaluation": args.eval_launch if B > 1 else "single",
                 "evaluation_cus": args.eval_cus or 256,
+                "cu_split": cu_split,
                 "lanes_per_gpu": n_lanes,
                 "parallelism": f"independent frames: {world} GPU(s) x {n_lanes} lanes x {B} frames per batched "
                                "build and per evaluation launch (one build stream per lane, one evaluation "
