@@ -70,10 +70,17 @@ def parse_args():
                          "configuration): phi once per (vertex, centre), weight contraction on the matrix pipe "
                          "(fd_batch_deform_shared_dev); batched: one launch, every frame evaluated on its own "
                          "(fd_batch_deform_dev); single: one launch per frame")
-    ap.add_argument("--eval-cus", type=int, default=224,
+    ap.add_argument("--eval-cus", type=int, default=0,
                     help="shared evaluation: CUs it occupies (one persistent workgroup each, all of a CU's LDS); the rest stay "
                          "free for the builds of the next groups, which otherwise only run in the gaps between evaluation "
-                         "launches (measured: 224 -> 113k Mverts/s, 256 -> 101k, 192 -> 109k; 0 = all 256)")
+                         "launches.  0 = the measured best for the build style: 192 with --build one-workgroup (its 3 x 32 persistent "
+                         "workgroups want 64 CUs to themselves; 120-122k Mverts/s, 208: 110k), 224 with --build chain (113k; 256: 101k, 192: 109k)")
+    ap.add_argument("--build", choices=["one-workgroup", "chain"], default="one-workgroup",
+                    help="batched builds of the frame pipeline (config c2): one-workgroup = fd_config.solver FD_SOLVER_ONE_WORKGROUP "
+                         "(one launch, one workgroup per model: 32 workgroups on 32 CUs per batch, nothing else on the device -- "
+                         "the evaluation keeps the other CUs undisturbed; 120-122k Mverts/s); chain = the default solver's launch "
+                         "chain (faster for a lone build; 112k in this pipeline).  The single-cook latency is measured with the "
+                         "default solver either way")
     ap.add_argument("--cu-split", choices=["mask", "none"], default="none",
                     help="mask: the evaluation stream and the build streams are created with complementary CU masks "
                          "(hipExtStreamCreateWithCUMask): --eval-cus CUs for the evaluation, the others for the builds.  Measured "
@@ -412,7 +419,9 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
-    if args.eval_cus > 0:
+    if args.eval_cus <= 0:
+        args.eval_cus = 192 if (args.build == "one-workgroup" and args.config == "c2") else 224
+    if 0 < args.eval_cus < 256:
         os.environ["FD_SHARED_CUS"] = str(args.eval_cus)       # read once by the library at its first shared launch
     import torch
     import torch.distributed as dist
@@ -473,12 +482,14 @@ def main():
         if ms is not None:
             eval_stream, build_streams = ms
             cu_split = "mask"
+    # the pipeline's models: one workgroup per model where that applies (M <= 512; config c3 takes the chain either way)
+    lane_solver = capi.SOLVER_ONE_WORKGROUP if (args.build == "one-workgroup" and B > 1) else capi.SOLVER_AUTO
     lanes = []
     for li in range(n_lanes):
         stream = build_streams[li]
         engines = []
         for _ in range(B):
-            eng = capi.Engine(device=local_rank, precision=precision, variant=args.variant)
+            eng = capi.Engine(device=local_rank, precision=precision, variant=args.variant, solver=lane_solver)
             eng.set_stream(stream.cuda_stream)
             eng.set_kernel(capi.KERNEL_THIN_PLATE)
             eng.set_term(capi.TERM_LINEAR)
@@ -609,10 +620,14 @@ def main():
     # (unbatched fd_set_points_dev + fd_build_async + fd_deform_dev on one context)
     lat = []
     ln0 = lanes[0]
+    solo = capi.Engine(device=local_rank, precision=precision, variant=args.variant)       # default solver: what a lone cook takes
+    solo.set_stream(ln0["stream"].cuda_stream)
+    solo.set_kernel(capi.KERNEL_THIN_PLATE)
+    solo.set_term(capi.TERM_LINEAR)
     for i in range(10):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        eng = ln0["engines"][0]
+        eng = solo
         eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr() + (i % N_FRAMES) * delta_stride, n_ctrl)
         eng.build_async()
         eng.deform_dev(n_verts, d_P.data_ptr(), ln0["out"][0].data_ptr(), d_falloff=ln0["fall"][0].data_ptr())
@@ -623,7 +638,7 @@ def main():
     # the solve alone, one model at a time (fd_build: assemble + factorise + substitute + pack, host-synchronised)
     bl = []
     for i in range(10):
-        eng = ln0["engines"][0]
+        eng = solo
         eng.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr() + (i % N_FRAMES) * delta_stride, n_ctrl)
         eng.synchronize()
         t1 = time.perf_counter()
@@ -764,6 +779,8 @@ def main():
                 "evaluation": args.eval_launch if B > 1 else "single",
                 "evaluation_cus": args.eval_cus or 256,
                 "cu_split": cu_split,
+                "pipeline_build": ("one workgroup per model (FD_SOLVER_ONE_WORKGROUP)" if lane_solver == capi.SOLVER_ONE_WORKGROUP
+                                   else "launch chain (FD_SOLVER_AUTO)"),
                 "lanes_per_gpu": n_lanes,
                 "parallelism": f"independent frames: {world} GPU(s) x {n_lanes} lanes x {B} frames per batched "
                                "build and per evaluation launch (one build stream per lane, one evaluation "
@@ -790,6 +807,8 @@ def main():
         print(json.dumps(line), flush=True)
 
     torch.cuda.synchronize()
+    solo.set_stream(None)
+    solo.close()
     for ln in lanes:
         for batch in ln["batches"].values():
             batch.close()

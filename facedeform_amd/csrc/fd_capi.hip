@@ -362,7 +362,7 @@ fd_ctx *fd_create(const fd_config *cfg)
     if (cfg) {
         ctx->eval_precision = cfg->eval_precision == FD_EVAL_FP64 ? FD_EVAL_FP64 : FD_EVAL_FP32;
         ctx->eval_variant = cfg->eval_variant;
-        ctx->solver = cfg->solver == FD_SOLVER_LU ? FD_SOLVER_LU : FD_SOLVER_AUTO;
+        ctx->solver = (cfg->solver == FD_SOLVER_LU || cfg->solver == FD_SOLVER_ONE_WORKGROUP) ? cfg->solver : FD_SOLVER_AUTO;
     }
     hipDeviceProp_t prop;
     if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
@@ -596,6 +596,7 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.nbatch = 1;
     b.group_panels = 0;
     b.spd = use_spd(ctx) ? 1 : 0;
+    b.small = ctx->solver == FD_SOLVER_ONE_WORKGROUP ? 1 : 0;
     b.aux_stream = nullptr;
     for (hipEvent_t &e : b.aux_events) e = nullptr;
 }
@@ -1435,6 +1436,8 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     bb.nbatch = b->n;
     for (int i = 0; i < b->n; ++i)
         if (!use_spd(b->ctxs[i])) bb.spd = 0;        // one context that fell back to the LU takes the batch with it
+    for (int i = 0; i < b->n; ++i)
+        if (b->ctxs[i]->solver != FD_SOLVER_ONE_WORKGROUP) bb.small = 0;      // ... and the one-workgroup build is everybody's choice or nobody's
     static const bool no_groups = getenv("FD_NO_PANEL_PAIRS") != nullptr;
     bb.group_panels = (b->n >= 4 && !no_groups && !getenv("FD_LOOKAHEAD")) ? 1 : 0;
     if (make_lookahead(&b->lu_stream, b->lu_events)) {
@@ -1443,7 +1446,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     }
 
     fd_batch::Key key{};
-    key.M = c0->M; key.kind = c0->kind; key.term = c0->term | (bb.spd << 9); key.nparams = c0->nparams;
+    key.M = c0->M; key.kind = c0->kind; key.term = c0->term | (bb.spd << 9) | (bb.small << 10); key.nparams = c0->nparams;
     memcpy(key.params, c0->params, sizeof(key.params));
     if (b->use_graph && (!b->exec || memcmp(&key, &b->key, sizeof(key)) != 0)) {
         if (b->exec) { (void)hipGraphExecDestroy(b->exec); b->exec = nullptr; }

@@ -145,6 +145,7 @@ struct BuildBuffers {
     // Symmetric definite path (fd_nullspace.hip): the polynomial constraints are eliminated with
     // Householder reflectors and the projected kernel block, order M - T, is Cholesky-factorised
     // -- no pivot search, so the panel is no longer one workgroup's serial chain.
+    int small;                        // FD_SOLVER_ONE_WORKGROUP: k_build_small where it applies
     int spd;
     // Multilayer Gaussian model (FD_KERNEL_GAUSSIAN_ML, fd_nullspace.hip launch_build_ml): number of
     // layers, 0 for every other kind.  `kind` is then FD_KERNEL_GAUSSIAN (what the assembly evaluates).

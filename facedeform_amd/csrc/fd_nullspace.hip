@@ -1151,8 +1151,9 @@ __global__ __launch_bounds__(256) FD_FIT_BESIDE_EVAL void k_chol_step(const Batc
     for (int cc = 0; cc < kNB; ++cc) up[cc] = x[cc];
 }
 
-// ---- the whole build of a small system in ONE launch of ONE workgroup (opt-in: FD_SMALL_BUILD=1) --------------
-// NEGATIVE RESULT, kept selectable and tested: see launch_build_spd for the measurements.
+// ---- the whole build of a small system in ONE launch of ONE workgroup (FD_SOLVER_ONE_WORKGROUP; FD_SMALL_BUILD=1) ----
+// Slower than the chain for a lone build, the better citizen for batches solved beside a running evaluation: see
+// launch_build_spd for the measurements.
 // A lone order-256 system is 5.6 MFLOP of fp64 work that the chain above spreads over 18 dependent
 // launches: 0.24 ms, most of it launch floor and dispatch.  Up to order 512
 // everything after the assembly of K -- reflectors, Y = K V, W, the rotation, every Cholesky step,
@@ -1550,13 +1551,17 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
     const unsigned nb = (unsigned)b.nbatch;
     const int M = b.M, T = b.T;
     const int n1 = M - T, npc = round_up(n1, kNB), npa = round_up(M, 32);
-    // FD_SMALL_BUILD=1: the one-workgroup build (k_build_small) up to order 512.  OFF by default -- measured
+    // fd_config.solver = FD_SOLVER_ONE_WORKGROUP (or FD_SMALL_BUILD=1 for every context): the one-workgroup build
+    // (k_build_small) up to order 512.  Not what AUTO takes -- measured
     // on MI355X it LOSES to the chain: 0.37 vs 0.25 ms at M = 256, 1.19 vs 0.43 ms at M = 512, and no gain
     // for batches of 32 either (profiles/r02_build_small.txt).  With the matrix in L2 every phase is a
     // handful of dependent ~1 us round trips that four waves cannot hide, where the chain's kernels spread
-    // them over many CUs; what would win is the matrix in registers / LDS.
+    // them over many CUs; what would win is the matrix in registers / LDS.  In a pipeline that evaluates
+    // 32 frames on most of the device while the next 32 models are solved it is the other way round: 32 workgroups
+    // on 32 CUs for 0.65 ms disturb the evaluation less than 18 launches with grids all over the device (bench.py:
+    // 120-122k against 112k Mverts/s).
     static const bool use_small = [] { const char *e = getenv("FD_SMALL_BUILD"); return e && atoi(e) == 1; }();
-    if (npc <= kSmallMaxNpc && use_small) {
+    if (npc <= kSmallMaxNpc && (use_small || b.small)) {
         // one workgroup per model does everything after the assembly
         hipError_t e0 = launch_assemble_block(b, stream, npa);
         if (e0 != hipSuccess) return e0;

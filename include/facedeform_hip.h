@@ -105,7 +105,14 @@ enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
  * FD_E_DUPLICATE (sticky until the next fd_set_points / fd_set_deltas).  Both
  * are fp64 direct solves of the same system: their weights agree to rounding (~1e-12 relative
  * on the benchmark rigs), far inside the parity tolerance. */
-enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1 };
+/* ONE_WORKGROUP (thin-plate / Gaussian family as for AUTO's Cholesky path, up to 512 control points; anything else
+ * behaves as AUTO): everything after the assembly of K -- projection, Cholesky, substitution, packing -- in ONE
+ * launch of ONE workgroup per model.  A single build is slower that way (0.37 against 0.25 ms at 256 control
+ * points), but a batch of 32 costs what one does, as 32 workgroups on 32 CUs and nothing else on the device: the
+ * choice for a pipeline that keeps evaluating on the other CUs while the next frames' models are solved (bench.py).
+ * Same arithmetic within this choice for single and batched builds (bit-identical weights); against AUTO the
+ * weights agree to rounding (1e-12 relative). */
+enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1, FD_SOLVER_ONE_WORKGROUP = 2 };
 
 typedef struct fd_ctx fd_ctx;
 

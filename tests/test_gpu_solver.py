@@ -319,3 +319,49 @@ def test_one_workgroup_build_matches_the_chain(hip_lib):
     for k in res["0"].files:
         a, b = res["0"][k], res["1"][k]
         assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max(), k
+
+
+def test_one_workgroup_solver_as_a_context_choice(hip_lib, oracle):
+    """fd_config.solver = FD_SOLVER_ONE_WORKGROUP (what bench.py's frame pipeline builds with): per context, no
+    environment switch.  Weights against the default solver's (rounding: the same system, another elimination order; the
+    default solver's against the oracle: test_cholesky_and_lu_agree_with_each_other_and_the_oracle); a batch of such
+    contexts equals the same models built one at a time bit for bit; a batch that mixes solvers takes the chain."""
+    import torch
+    M, F = 256, 6
+    dev = torch.device("cuda", 0)
+    rest = synth.control_points(M, "head")
+    deltas = np.stack([synth.smooth_deltas(rest, f) for f in range(F)]).astype(np.float32)
+    d_rest = torch.from_numpy(rest).to(dev); d_del = torch.from_numpy(deltas).to(dev)
+    torch.cuda.synchronize()
+
+    def engines(solver, n):
+        out = []
+        for _ in range(n):
+            e = capi.Engine(solver=solver); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR); out.append(e)
+        return out
+
+    ow = engines(capi.SOLVER_ONE_WORKGROUP, F)
+    batch = capi.Batch(ow)
+    batch.set_points_dev([d_rest.data_ptr()] * F, [d_del.data_ptr() + f * M * 12 for f in range(F)], M)
+    batch.build_async()
+    assert [r.terminationtype for r in batch.build_result()] == [1] * F
+    Wb = [e.get_weights()[0] for e in ow]
+    alone = engines(capi.SOLVER_ONE_WORKGROUP, 1)[0]
+    auto = engines(capi.SOLVER_AUTO, 1)[0]
+    for f in (0, 3, 5):
+        alone.set_points(rest, deltas[f]); assert alone.build().terminationtype == 1
+        assert np.array_equal(alone.get_weights()[0], Wb[f]), f                     # batch == single, same solver
+        auto.set_points(rest, deltas[f]); assert auto.build().terminationtype == 1
+        Wa = auto.get_weights()[0]
+        assert np.abs(Wa - Wb[f]).max() <= 1e-9 * np.abs(Wa).max(), f                # same system, another elimination order
+    mixed = capi.Batch([ow[0], auto])
+    mixed.set_points_dev([d_rest.data_ptr()] * 2, [d_del.data_ptr(), d_del.data_ptr() + M * 12], M)
+    mixed.build_async()
+    assert [r.terminationtype for r in mixed.build_result()] == [1, 1]
+    auto2 = engines(capi.SOLVER_AUTO, 1)[0]
+    auto2.set_points(rest, deltas[0]); auto2.build()
+    assert np.array_equal(ow[0].get_weights()[0], auto2.get_weights()[0])               # the chain's bits
+    for b in (mixed, batch):
+        b.close()
+    for e in ow + [alone, auto, auto2]:
+        e.close()
