@@ -338,3 +338,55 @@ def test_a_member_rebuilt_on_its_own_is_not_evaluated_from_a_stale_copy(hip_lib,
     assert not torch.equal(outs[2], before[2])
     single.close()
     _close(engines, batch)
+
+
+@pytest.mark.parametrize("kind,okind,params", [(capi.KERNEL_THIN_PLATE, fo.KERNEL_THIN_PLATE, ()),
+                                               (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0))])
+@pytest.mark.parametrize("N,F", [(1, 16), (5, 32), (63, 32), (64, 16), (65, 32), (511, 16), (513, 4), (1025, 32)])
+def test_shared_launch_at_the_edges_of_its_vertex_groups(hip_lib, oracle, kind, okind, params, N, F):
+    """Vertex counts around the wave's 64 and the workgroup's 512, with the frame counts that take the branch-free
+    epilogue (16, 32) and the general one (4): every vertex against the oracle, tangent frames and the gate on; and an
+    empty mesh is a no-op."""
+    M = 64
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(N * 131 + F)
+    P = synth.head_mesh(4096)[rng.permutation(4096)[:N]].copy()
+    rest = synth.control_points(M, "head")
+    deltas = np.stack([synth.smooth_deltas(rest, f % 8) * np.float32(1.0 + 0.25 * (f // 8)) for f in range(F)]).astype(np.float32)
+    d_P, d_rest, d_del = (torch.from_numpy(a).to(dev) for a in (P, rest, deltas))
+    engines = []
+    for _ in range(F):
+        e = capi.Engine(); e.set_kernel(kind, params); e.set_term(capi.TERM_LINEAR); engines.append(e)
+    batch = capi.Batch(engines)
+    batch.set_points_dev([d_rest.data_ptr()] * F, [d_del.data_ptr() + f * M * 12 for f in range(F)], M)
+    batch.build_async()
+    assert [r.terminationtype for r in batch.build_result()] == [1] * F
+    outs = [torch.full_like(d_P, 9.0) for _ in range(F)]
+    falls = [torch.full((N,), 7.0, device=dev) for _ in range(F)]
+    batch.deform_shared_dev(0, d_P.data_ptr(), [o.data_ptr() for o in outs])                 # N = 0: nothing happens
+    torch.cuda.synchronize()
+    assert all(bool((o == 9.0).all()) for o in outs)
+    tu, tv, nn = synth.tangent_frames(P)
+    d_t = [torch.from_numpy(a).to(dev) for a in (tu, tv, nn)]
+    dist2 = (rng.random(N) * 0.5).astype(np.float32)
+    dist2[::3] = 0.45                                                                         # beyond radius2: gated
+    d_d2 = torch.from_numpy(dist2).to(dev)
+    r2 = np.float32(0.36)
+    for mode in ("plain", "all"):
+        kw, okw = {}, {}
+        if mode == "all":
+            kw = dict(d_dist2=d_d2.data_ptr(), radius2=r2, falloffrate=1.5, d_tangents=[t.data_ptr() for t in d_t])
+            okw = dict(dist2=dist2, radius2=r2, falloffrate=1.5, tangents=(tu, tv, nn))
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], d_falloff=[f.data_ptr() for f in falls], **kw)
+        torch.cuda.synchronize()
+        for f in sorted(set([0, F // 2, F - 1])):
+            table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
+            rc, tt, W, radii = oracle.build(table, okind, list(params), fo.TERM_LINEAR)
+            ref, _ = oracle.deform(table, okind, radii, W, P, **okw)
+            plain = None
+            if mode == "all":
+                plain, _ = oracle.deform(table, okind, radii, W, P, **{k: v for k, v in okw.items() if k != "tangents"})
+            assert parity_ratio(outs[f].cpu().numpy(), ref, P, TOL, scale_out=plain) <= 1.0, (mode, f)
+    batch.close()
+    for e in engines:
+        e.close()
