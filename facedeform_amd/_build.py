@@ -13,7 +13,11 @@ LIB_PATH = os.path.join(LIB_DIR, "libfacedeform_hip.so")
 SOURCES = ["fd_eval.hip", "fd_eval_shared.hip", "fd_build.hip", "fd_nullspace.hip", "fd_capi.hip", "fd_morph.hip", "fd_capture.hip", "fd_sop_host.cpp"]
 # per-file extras: keep the bf16 MFMA results of the evaluation kernel in VGPRs (the default puts
 # them in AGPRs and pays one v_accvgpr_read per value)
-EXTRA_FLAGS = {"fd_eval.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"fd_eval.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # no packed fp32 in the shared-rig kernel at all (the SLP vectoriser pairs scalar multiplies and adds into
+               # v_pk_* again): packed arithmetic under its matrix instructions is what gave launch-to-launch differences
+               # (DESIGN.md 4.1c); same speed, and the Gaussian instantiation loses its four spills
+               "fd_eval_shared.hip": ["-fno-slp-vectorize"]}
 HEADERS = [os.path.join(CSRC, "fd_internal.h"), os.path.join(CSRC, "fd_pack.h"), os.path.join(CSRC, "fd_eval_common.h"), os.path.join(_ROOT, "include", "facedeform_hip.h")]
 
 
