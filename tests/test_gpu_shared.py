@@ -304,10 +304,19 @@ def test_repeated_launches_give_the_same_bits_at_full_size(hip_lib, kind, params
     one, two = torch.empty_like(d_P), torch.empty_like(d_P)
     engines[3].deform_dev(N, d_P.data_ptr(), one.data_ptr())
     engines[3].synchronize()
-    for rep in range(4):
+    for rep in range(12):
         engines[3].deform_dev(N, d_P.data_ptr(), two.data_ptr())
         engines[3].synchronize()
         assert torch.equal(one, two), (rep, int((one != two).any(dim=1).sum()))
+    # and the one-frame kernels batched (grid y = frame): packed fmas beside d2 matrix instructions in the thin-plate one
+    batch.deform_dev(N, [d_P.data_ptr()] * F, [o.data_ptr() for o in first])
+    torch.cuda.synchronize()
+    assert torch.equal(first[3], one)
+    for rep in range(3):
+        batch.deform_dev(N, [d_P.data_ptr()] * F, [o.data_ptr() for o in again])
+        torch.cuda.synchronize()
+        for f in range(F):
+            assert torch.equal(first[f], again[f]), (rep, f)
     _close(engines, batch)
 
 
