@@ -86,6 +86,9 @@ def parse_args():
                          "(hipExtStreamCreateWithCUMask): --eval-cus CUs for the evaluation, the others for the builds.  Measured "
                          "worse (68k against 112k Mverts/s: confined to 32 CUs a batched build takes 1.37 ms instead of 0.8 -- "
                          "unconfined, the builds also use the evaluation's CUs between its launches); kept for the record")
+    ap.add_argument("--c5-group", type=int, default=16,
+                    help="config c5: frames per group (one batched build, one broadcast, one evaluation launch; 8: 55k, 16: 86k, 32: 86k "
+                         "Mverts/s on one GPU -- at 32 the 512-centre model no longer fits the LDS in one piece)")
     ap.add_argument("--c5-solve", choices=["broadcast", "redundant"], default="broadcast",
                     help="config c5: rank 0 solves and broadcasts the models (default), or every rank solves them itself")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
@@ -149,7 +152,7 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
     n_verts, n_ctrl, mesh_kind, desc = CONFIGS["c5"]
     lo, hi = fdist.vertex_range(n_verts, rank, world)
     n_mine = hi - lo
-    B = max(1, min(args.inflight, 8))                 # frames per group (10M-vertex frames are large)
+    B = max(1, min(args.inflight, args.c5_group))     # frames per group (a 10M-vertex frame is 160 MB of outputs; two lanes)
     n_lanes = 2
     P_host = synth.head_mesh(n_verts)
     rest_host = synth.control_points(n_ctrl, mesh_kind)
