@@ -1302,18 +1302,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         if (k0 <= 0) FD_BSTAMP()
         // (iii) L11 to the side store and into A, its inverse, and X L11^T = A21 on the rows below
         block_store(slot, M, lda, kb, sC, sInv, true);
-        for (int row = kb + kNB + tid; row < npc; row += 256) {
+        // Every thread takes ONE vector through the 32 dependent columns of L11 (solve_row: ~20 k cycles whatever the
+        // vector): a row of A21, or -- threads that have no row left at this step -- a row of the identity (-> the
+        // block's inverse, for the back-substitution) or one of the three right-hand sides.  Side by side, not one
+        // after the other: the same operations on the same operands, so the same bits, in half the time of a step.
+        const int nrows = npc - kb - kNB;
+        const bool spare = 256 - (nrows < 256 ? nrows : 256) >= kNB + 3;        // 35 idle threads in the (only) pass over the rows
+        for (int row0 = kb + kNB, pass = 0; row0 < npc || (pass == 0 && spare); row0 += 256, ++pass) {
+            const int row = row0 + tid;
+            const int extra = tid - nrows;                                      // >= 0: no row in the first pass
+            const bool is_row = row < npc;
+            const bool is_inv = pass == 0 && spare && extra >= 0 && extra < kNB;
+            const bool is_rhs = pass == 0 && spare && extra >= kNB && extra < kNB + 3;
+            if (!(is_row || is_inv || is_rhs)) continue;
+            gdouble *rowp = A + (size_t)(npad + (is_rhs ? extra - kNB : 0)) * lda + kb;
             double x[kNB];
 #pragma unroll
-            for (int cc = 0; cc < kNB; ++cc) x[cc] = *pinned_column(A + (size_t)(kb + cc) * lda, 8u * (unsigned)row);
+            for (int cc = 0; cc < kNB; ++cc)
+                x[cc] = is_row ? *pinned_column(A + (size_t)(kb + cc) * lda, 8u * (unsigned)row) : (is_inv ? (cc == extra ? 1.0 : 0.0) : rowp[cc]);
             solve_row(x, sR, sInv);
+            if (is_row) {
 #pragma unroll
-            for (int cc = 0; cc < kNB; ++cc) *pinned_column(A + (size_t)(kb + cc) * lda, 8u * (unsigned)row) = x[cc];
-            gdouble *up = A + (size_t)row * lda + kb;          // mirrored: U[kb + cc][row] = L[row][kb + cc]
+                for (int cc = 0; cc < kNB; ++cc) *pinned_column(A + (size_t)(kb + cc) * lda, 8u * (unsigned)row) = x[cc];
+                gdouble *up = A + (size_t)row * lda + kb;          // mirrored: U[kb + cc][row] = L[row][kb + cc]
 #pragma unroll
-            for (int cc = 0; cc < kNB; ++cc) up[cc] = x[cc];
+                for (int cc = 0; cc < kNB; ++cc) up[cc] = x[cc];
+            } else if (is_inv) {
+                gdouble *inv = ld_block(slot.ns, M, kb) + kLdInv;
+#pragma unroll
+                for (int cc = 0; cc < kNB; ++cc) inv[cc * kNB + extra] = x[cc];
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < kNB; ++cc) rowp[cc] = x[cc];
+            }
         }
-        {
+        if (!spare) {
             const int unit = tid - 64;                         // second wave: row `unit` of the identity -> inverse(L11)
             const bool rhsrow = tid < 3, invert = unit >= 0 && unit < kNB;
             if (rhsrow || invert) {
