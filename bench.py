@@ -722,8 +722,10 @@ def main():
             mfma_alg = {"achieved": flops_launch / secs / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops_launch / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS, "flops_per_launch": flops_launch,
                         "executed": {"achieved": mfma_exec / secs / 1e12, "frac": mfma_exec / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS,
-                                     "note": "what the pipe runs: fp16 x 2 split = three products; C2 PMC: pipe busy 0.42 of "
-                                             "SIMD-cycles (profiles/r02_pmc_shared_c2.txt)"}}
+                                     "note": "what the pipe runs: fp16 x 2 split = three products"},
+                        # from the committed PMC passes of this kernel (profiles/r02_pmc_shared_c2.txt): share of SIMD-cycles the
+                        # matrix pipe is busy, share of wave-cycles spent waiting for an instruction to issue
+                        "pmc": {k: tj.get(kern, {}).get(k) for k in ("mfma_busy_frac", "wait_inst_frac")}}
             hbm_alg = {"achieved": bytes_launch / secs / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": bytes_launch / secs / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": bytes_launch}
             # Which roof binds is the roofline model's answer at the launch's ALGORITHMIC intensity: below the

@@ -55,7 +55,10 @@ def main():
     tj = json.load(open(f"{DST}/traffic_c2.json"))
     k = tj["kernels"]["k_deform32_tps_shared"]
     k.update({"FETCH_SIZE_KiB_raw": m["FETCH_SIZE"], "WRITE_SIZE_KiB": m["WRITE_SIZE"], "hbm_bytes_per_launch": fetch + write,
-              "hbm_bytes_fixed_per_launch": fetch, "hbm_bytes_per_frame": write / 32})
+              "hbm_bytes_fixed_per_launch": fetch, "hbm_bytes_per_frame": write / 32,
+              "mfma_busy_frac": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024),
+              "valu_active_frac": m["SQ_ACTIVE_INST_VALU"] * 4 / m["SQ_WAVE_CYCLES"] / 4 if m.get("SQ_WAVE_CYCLES") else None,
+              "wait_inst_frac": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]})
     json.dump(tj, open(f"{DST}/traffic_c2.json", "w"), indent=1)
     print(open(f"{DST}/r02_pmc_shared_c2.txt").read())
     d = last_json(f"{SRC}/bench_c2_line.json")
