@@ -724,6 +724,501 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 #undef FD_SSTAMP
 }
 
+
+// ---- 17 to 32 frames, thin-plate: 32-row tiles ----------------------------------------------------------------------
+// The same contraction on v_mfma_f32_32x32x16_f16: an output tile is 32 frames x 32 vertices, one tile per component,
+// and a wave's 64 vertices are two vertex tiles.  The matrix pipe does the same flops in half the instructions, and what
+// bounds the K loop of the 16-row kernel above is the issue port, not the pipe (tools/ubench_mfma16.hip: a matrix
+// instruction costs the port ~10 cycles whatever its shape: 80 of them per K block and wave there, 40 here, beside the
+// same ~150 vector and 32 transcendental instructions).  d2 comes from two v_mfma_f32_32x32x8_f16 per vertex tile
+// (K = 16 as x, y | z, |.|^2) and lands as 16 values per lane -- centres 8 (r / 4) + 4 h + r % 4 of the block in register
+// r of lane half h -- which after the logarithm ARE the lane's B operands of the two K = 16 steps (registers 0..7 and
+// 8..15): the weight tiles are packed to that centre order.  The epilogue needs one v_permlane32_swap per register pair.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr bool shared_wide(int nF, int kind) { return nF > 16 && kind == FD_KERNEL_THIN_PLATE; }
+constexpr int kWideSlots = 32;                      // frame records
+constexpr int kWideW16 = 3 * 2 * 2 * 64;            // 16-byte words of weight tiles per K block: [component][K step][hi, lo][lane]
+
+// grid (nkb, 3 components), 256 threads.  Output regions as in k_pack_shared with nT = 6: weight tiles, 6 x 64 words of
+// polynomial tiles (the first 3 x 64 used), then the d2 operands of the centres ([kb][2 instructions][64 lanes] x 8 B
+// inside the 2 x 768 B per K block of the 16-row layout's centre tiles) and the normalisation.
+__global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slots, const SharedOut out, int nF, int Mpad,
+                                                           uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles)
+{
+    const int kb = blockIdx.x, c = blockIdx.y, nkb = gridDim.x;
+    const size_t poly_at = (size_t)nkb * kWideW16, copy_at = poly_at + 6 * 64;
+    if (c == 0) {
+        // lane (h, r) of instruction i: k-slots 4 h .. 4 h + 3 of centre r = coordinate group 2 i + h of the 16-row tile
+        constexpr int per = (int)(sizeof(MfmaTileH) / 16);
+        uint2 *dst = reinterpret_cast<uint2 *>(wtiles + copy_at) + (size_t)kb * 128;
+        if (threadIdx.x < 128) {
+            const int i = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
+            const int tile = 2 * kb + (r >> 4);
+            uint2 v = make_uint2(0u, 0u);
+            if (tile < Mpad / 16) { const unsigned *a = ctiles[tile].a[16 * (2 * i + h) + (r & 15)]; v = make_uint2(a[0], a[1]); }
+            dst[threadIdx.x] = v;
+        }
+        if (kb == 0 && threadIdx.x == 255) {
+            const float *nn = slots.model[0]->norm32;
+            wtiles[copy_at + (size_t)2 * nkb * per] = make_uint4(__float_as_uint(nn[0]), __float_as_uint(nn[1]), __float_as_uint(nn[2]), __float_as_uint(nn[3]));
+        }
+    }
+    // scale of each frame: largest |weight| or |polynomial coefficient| to [2^13, 2^14); 8 lanes per frame
+    __shared__ float s_scale[kWideSlots];
+    {
+        const int f = threadIdx.x >> 3, l = threadIdx.x & 7;
+        float m = 0.f;
+        if (f < nF) {
+            const Rec32 *r = slots.rec32[f];
+            for (int q = l; q < Mpad; q += 8) m = fmaxf(m, fmaxf(fabsf(r[q].wx), fmaxf(fabsf(r[q].wy), fabsf(r[q].wz))));
+            for (int q = l; q < 15; q += 8) m = fmaxf(m, fabsf(slots.model[f]->poly32[q]));
+        }
+        for (int off = 4; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (l == 0) {
+            int k = 0;
+            if (m > 0.f && m < INFINITY) k = 13 - (__builtin_amdgcn_frexp_expf(m) - 1);
+            k = k < -100 ? -100 : (k > 100 ? 100 : k);
+            s_scale[f] = ldexpf(1.f, k);
+            if (kb == 0 && c == 0) {
+                SharedFrame fr;
+                fr.inv_scale = ldexpf(1.f, -k);
+                fr.built = (f < nF && slots.model[f]->terminationtype == 1) ? 1 : 0;
+                fr.pad[0] = fr.pad[1] = 0;
+                fr.P_out = f < nF ? out.P_out[f] : nullptr;
+                fr.falloff_out = f < nF ? out.falloff_out[f] : nullptr;
+                frames[f] = fr;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 128) return;
+    const int s = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, f = lane & 31;        // row = frame
+    const float sc = s_scale[f];
+    f16x8 hi, lo;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int centre = 32 * kb + 8 * (2 * s + (m >> 2)) + 4 * h + (m & 3);
+        float w = 0.f;
+        if (f < nF && centre < Mpad) {
+            const Rec32 r = slots.rec32[f][centre];
+            w = (c == 0 ? r.wx : (c == 1 ? r.wy : r.wz)) * sc;
+        }
+        const _Float16 hh = (_Float16)w;
+        hi[m] = hh;
+        lo[m] = (_Float16)(w - (float)hh);
+    }
+    uint4 *dst = wtiles + (size_t)kb * kWideW16 + (size_t)((c * 2 + s) * 2) * 64;
+    dst[lane] = __builtin_bit_cast(uint4, hi);
+    dst[64 + lane] = __builtin_bit_cast(uint4, lo);
+    if (kb == 0 && s == 0) {
+        // polynomial tile of component c, K = 16: coefficients {C0, Lx, Ly, Lz, q} as (hi, lo) against the vertex
+        // operand's {1, x, y, z, |x|^2} as (hi, lo) -- lane half 0: hi[0..4] x hi, then hi[1..3] x lo(x, y, z);
+        // lane half 1: hi[4] x lo(|x|^2), lo[0..4] x hi, two unused
+        f16x8 pt;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int coef = h == 0 ? (m < 5 ? m : m - 4) : (m == 0 ? 4 : (m < 6 ? m - 1 : -1));
+            const bool want_lo = h == 1 && m >= 1;
+            float w = 0.f;
+            if (f < nF && coef >= 0) w = slots.model[f]->poly32[5 * c + coef] * sc;
+            const _Float16 hh = (_Float16)w;
+            pt[m] = want_lo ? (_Float16)(w - (float)hh) : hh;
+        }
+        wtiles[poly_at + (size_t)c * 64 + lane] = __builtin_bit_cast(uint4, pt);
+    }
+}
+
+#ifndef FD_WIDE_VPM
+#define FD_WIDE_VPM 3            // vector instructions placed after each matrix instruction of the K loop
+#endif
+#ifndef FD_WIDE_PATTERN
+#define FD_WIDE_PATTERN 1
+#endif
+#ifndef FD_WIDE_UNROLL2
+#define FD_WIDE_UNROLL2 0        // 1: two operand buffers in turn instead of 32 register copies per block (41 spills around the loop; no faster)
+#endif
+
+__global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
+{
+    constexpr int TV = 2;                        // vertex tiles (of 32) per wave
+    constexpr int kSlots = kWideSlots;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [frame records 32][polynomial tiles 3 x 64 x 16 B][d2 operands kchunk x 2 x 64 x 8 B][weight tiles kchunk x 12 KiB]
+    SharedFrame *s_frames = reinterpret_cast<SharedFrame *>(smem);
+    uint4 *s_poly = reinterpret_cast<uint4 *>(smem + sizeof(SharedFrame) * (size_t)kSlots);
+    uint2 *s_ct = reinterpret_cast<uint2 *>(s_poly + 3 * 64);
+    uint4 *s_w = reinterpret_cast<uint4 *>(s_ct + (size_t)128 * p.kchunk);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const float n0 = p.norm[0], n1 = p.norm[1], n2 = p.norm[2];
+    const float inv_s = p.norm[3];
+    const bool resident = p.nkb <= p.kchunk;
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    auto stage = [&](int kb0, int nk) {
+        __syncthreads();
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.ctiles) + (size_t)kb0 * 64;
+            uint4 *dst = reinterpret_cast<uint4 *>(s_ct);
+            for (int q = tid; q < nk * 64; q += kSharedThreads) dst[q] = src[q];
+        }
+        {
+            const uint4 *src = p.wtiles + (size_t)kb0 * kWideW16;
+            const int n16 = nk * kWideW16;
+            for (int q = tid; q < n16; q += kSharedThreads) s_w[q] = src[q];
+        }
+        __syncthreads();
+    };
+
+    // frame records across the lanes of four registers (see k_deform32_tps_shared)
+    constexpr int kTabRegs = (kSlots * 8 + 63) / 64;
+    unsigned tab[kTabRegs];
+#pragma unroll
+    for (int q = 0; q < kTabRegs; ++q) tab[q] = reinterpret_cast<const unsigned *>(p.frames)[64 * q + lane];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.frames);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_frames);
+        for (int q = tid; q < kSlots * (int)(sizeof(SharedFrame) / 16); q += kSharedThreads) dst[q] = src[q];
+        const uint4 *psrc = p.wtiles + (size_t)p.nkb * kWideW16;
+        for (int q = tid; q < 3 * 64; q += kSharedThreads) s_poly[q] = psrc[q];
+    }
+    if (resident) {
+        stage(0, p.nkb);
+        if (wave >= 4) {                         // the second wave of each SIMD starts out of phase (as above)
+            __builtin_amdgcn_s_sleep(12);
+            for (int q = 0; q < (p.stagger & 0xff); ++q) __builtin_amdgcn_s_sleep(127);
+        }
+    } else {
+        __syncthreads();
+    }
+
+    const bool stamp = p.stamps != nullptr && blockIdx.x == 0;
+    unsigned long long st_prev = 0, st_acc[5] = {0, 0, 0, 0, 0};
+#define FD_SSTAMP(K) if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[K] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+    unsigned long long st_t0 = 0, st_r0 = 0;
+    if (stamp) { st_prev = st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    // lane (h, j) holds the two vertices (vt, j) -- both lane halves the same two
+    struct GroupRaw { float p[TV][3]; float d2[TV]; };
+    auto load_raw = [&](int grp_, auto fastTag) {
+        constexpr bool FAST = decltype(fastTag)::value;
+        GroupRaw r;
+        const int64_t vb = ((int64_t)grp_ * (kSharedThreads / 64) + wave) * 64;
+#pragma unroll
+        for (int t = 0; t < TV; ++t) {
+            const int64_t vi = vb + 32 * t + j;
+            const int64_t vc = vi < p.N ? vi : p.N - 1;
+            r.p[t][0] = p.P_in[3 * vc]; r.p[t][1] = p.P_in[3 * vc + 1]; r.p[t][2] = p.P_in[3 * vc + 2];
+            if constexpr (FAST) r.d2[t] = 0.f; else r.d2[t] = p.dist2 ? p.dist2[vc] : 0.f;
+        }
+        return r;
+    };
+    auto settle = [&](const GroupRaw &r) {
+        asm volatile("" :: "v"(r.p[0][0]), "v"(r.p[0][1]), "v"(r.p[0][2]), "v"(r.p[1][0]), "v"(r.p[1][1]), "v"(r.p[1][2]));
+    };
+    GroupRaw nxt = load_raw(blockIdx.x < (unsigned)ngroups ? (int)blockIdx.x : 0, std::false_type{});
+    settle(nxt);
+    auto do_group = [&](int grp, auto fastTag) {
+        constexpr bool FAST = decltype(fastTag)::value;
+        const int64_t vbase = ((int64_t)grp * (kSharedThreads / 64) + wave) * 64;
+        if ((((grp / (int)gridDim.x) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        const GroupRaw cur = nxt;
+        // this lane's own vertex in the epilogue is (vt = h, j)
+        const float pos[3] = {h ? cur.p[1][0] : cur.p[0][0], h ? cur.p[1][1] : cur.p[0][1], h ? cur.p[1][2] : cur.p[0][2]};
+        const float own_d2 = h ? cur.d2[1] : cur.d2[0];
+        f16x4 bop0[TV], bop1[TV];
+        f32x16 acc[3][TV];
+        bool lane_live = false;
+#pragma unroll
+        for (int t = 0; t < TV; ++t) {
+            const int64_t vi = vbase + 32 * t + j;
+            const float x = (cur.p[t][0] - n0) * inv_s, y = (cur.p[t][1] - n1) * inv_s, z = (cur.p[t][2] - n2) * inv_s;
+            const float d2v = cur.d2[t];
+            if constexpr (FAST) lane_live = true; else lane_live |= (vi < p.N) && !(d2v > p.radius2);
+            const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+            // d2 operands: instruction 0 carries (x | y), instruction 1 (z | |x|^2) in the lane halves
+            const float va = h == 0 ? -2.f * x : -2.f * y, vb2 = h == 0 ? -2.f * z : xx;
+            const _Float16 ha = (_Float16)va, la = (_Float16)(va - (float)ha);
+            const _Float16 hb = (_Float16)vb2, lb = (_Float16)(vb2 - (float)hb);
+            const _Float16 one = (_Float16)1.0f;
+            bop0[t] = (f16x4){ha, la, ha, la};
+            bop1[t] = h == 0 ? (f16x4){hb, lb, hb, lb} : (f16x4){one, one, hb, lb};
+            // polynomial operand, K = 16 (k_pack_shared_wide): half 0 {1, xh, yh, zh, xxh, xl, yl, zl}, half 1 {xxl, 1, xh, yh, zh, xxh, 0, 0}
+            unsigned xyh, xyl, zxh, zxl;
+            split_pair_f16(x, y, xyh, xyl);
+            split_pair_f16(z, xx, zxh, zxl);
+            u32x4 pb;
+            if (h == 0) pb = (u32x4){0x3c00u | (xyh << 16), (xyh >> 16) | (zxh << 16), (zxh >> 16) | (xyl << 16), (xyl >> 16) | (zxl << 16)};
+            else pb = (u32x4){(zxl >> 16) | (0x3c00u << 16), xyh, zxh, 0u};
+            const f16x8 pbv = __builtin_bit_cast(f16x8, pb);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, s_poly[c * 64 + lane]), pbv, zero16, 0, 0, 0);
+        }
+        const bool wave_work = FAST ? true : __any(lane_live);
+        if constexpr (FAST) {
+            const int gn = grp + (int)gridDim.x;
+            nxt = load_raw(gn < ngroups ? gn : grp, fastTag);      // a whole K loop ahead of this group's stores (as above)
+        }
+        FD_SSTAMP(0)
+
+        // phi of K block kb for the two vertex tiles: 16 values per lane and tile, as fp16 pieces (8 + 8 registers)
+        auto phi_block = [&](int kb, u32x8 (&xh)[TV], u32x8 (&xl)[TV]) {
+            const f16x4 aop0 = __builtin_bit_cast(f16x4, s_ct[(size_t)kb * 128 + lane]);
+            const f16x4 aop1 = __builtin_bit_cast(f16x4, s_ct[(size_t)kb * 128 + 64 + lane]);
+#pragma unroll
+            for (int t = 0; t < TV; ++t) {
+                f32x16 d = __builtin_amdgcn_mfma_f32_32x32x8f16(aop0, bop0[t], zero16, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x8f16(aop1, bop1[t], d, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    unsigned hh, ll;
+                    split_pair_f16(d2_log_d2(d[2 * q]), d2_log_d2(d[2 * q + 1]), hh, ll);
+                    xh[t][q] = hh; xl[t][q] = ll;
+                }
+            }
+        };
+        // acc += W(kb) x phi(kb): per component and K step the three split products of both vertex tiles
+        auto contract = [&](int kb, const u32x8 (&xh)[TV], const u32x8 (&xl)[TV]) {
+            const uint4 *wk = s_w + (size_t)kb * kWideW16 + lane;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, wk[((c * 2 + s) * 2) * 64]), al = __builtin_bit_cast(f16x8, wk[((c * 2 + s) * 2 + 1) * 64]);
+                    f16x8 vh[TV], vl[TV];
+#pragma unroll
+                    for (int t = 0; t < TV; ++t) {
+                        vh[t] = __builtin_bit_cast(f16x8, (u32x4){xh[t][4 * s], xh[t][4 * s + 1], xh[t][4 * s + 2], xh[t][4 * s + 3]});
+                        vl[t] = __builtin_bit_cast(f16x8, (u32x4){xl[t][4 * s], xl[t][4 * s + 1], xl[t][4 * s + 2], xl[t][4 * s + 3]});
+                    }
+#pragma unroll
+                    for (int t = 0; t < TV; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, vh[t], acc[c][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TV; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, vh[t], acc[c][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TV; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, vl[t], acc[c][t], 0, 0, 0);
+                }
+            }
+        };
+        for (int kb0 = 0; kb0 < p.nkb; kb0 += p.kchunk) {
+            const int nk = p.nkb - kb0 < p.kchunk ? p.nkb - kb0 : p.kchunk;
+            if (!resident) stage(kb0, nk);
+            if ((!FAST && !wave_work) || (p.dbg & 2)) continue;
+            // software pipeline as above: phi of block kb + 1 under the matrix instructions of block kb
+            // issue order of one pipelined block: the four d2 instructions of block kb + 1 first, two of block kb's
+            // contraction to cover their latency, then one logarithm and FD_WIDE_VPM vector instructions under each
+            // matrix instruction; the weights of a (component, K step) pair are read from LDS one pair ahead
+            auto interleave = [&]() {
+#if FD_WIDE_PATTERN == 1
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // d2 operands, weights of the first pair
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 36; ++q) {
+                    if (q % 6 == 0 && q < 30) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (q >= 2 && q < 34) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                }
+#else
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);      // transcendental
+                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);      // VALU
+                }
+#pragma unroll
+                for (int q = 32; q < 4 + 36; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                }
+#endif
+            };
+#if FD_WIDE_UNROLL2
+            // two operand buffers in turn, no copies; a full scheduling barrier between the halves
+            u32x8 bhA[TV], blA[TV], bhB[TV], blB[TV];
+            phi_block(0, bhA, blA);
+            int kb = 0;
+            for (; kb + 2 < nk; kb += 2) {
+                phi_block(kb + 1, bhB, blB);
+                contract(kb, bhA, blA);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                phi_block(kb + 2, bhA, blA);
+                contract(kb + 1, bhB, blB);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kb + 1 < nk) {
+                phi_block(kb + 1, bhB, blB);
+                contract(kb, bhA, blA);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                contract(kb + 1, bhB, blB);
+            } else {
+                contract(kb, bhA, blA);
+            }
+#else
+            u32x8 bh[TV], bl[TV];
+            phi_block(0, bh, bl);
+            for (int kb = 0; kb + 1 < nk; ++kb) {
+                u32x8 nbh[TV], nbl[TV];
+                phi_block(kb + 1, nbh, nbl);
+                contract(kb, bh, bl);
+                interleave();
+#pragma unroll
+                for (int t = 0; t < TV; ++t) { bh[t] = nbh[t]; bl[t] = nbl[t]; }
+            }
+            contract(nk - 1, bh, bl);
+#endif
+        }
+
+        FD_SSTAMP(1)
+        // ---- epilogue.  Register r of acc[c][vt] holds frame 8 (r / 4) + 4 h + r % 4 for vertex (vt, j); swapping the
+        // upper half of tile 0's register with the lower half of tile 1's leaves every lane with its OWN vertex
+        // (vbase + lane): acc[c][0][r] = frame 8 (r / 4) + r % 4, acc[c][1][r] = frame 8 (r / 4) + 4 + r % 4.
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[c][0][r]), __float_as_uint(acc[c][1][r]), false, false);
+                acc[c][0][r] = __uint_as_float(sw[0]); acc[c][1][r] = __uint_as_float(sw[1]);
+            }
+        }
+        // the reference's order: gate -> tangent projection -> fall-off -> add (src/SOP_FaceDeform.cpp:405-438)
+        const int64_t i = vbase + lane;
+        const bool inb = i < p.N;
+        const int64_t ic = inb ? i : p.N - 1;
+        const bool gated = own_d2 > p.radius2;
+        const unsigned off12 = 12u * (unsigned)lane, off4 = 4u * (unsigned)lane;
+        if constexpr (!FAST) {
+            const int gn = grp + (int)gridDim.x;
+            nxt = load_raw(gn < ngroups ? gn : grp, fastTag);
+        }
+        FD_SSTAMP(2)
+        if constexpr (FAST) {
+            // straight-line stores (see k_deform32_tps_shared): 32 positions + 16 paired fall-off rows
+            const f32x2 ones = {1.f, 1.f};
+            const unsigned off8 = 8u * (unsigned)(lane & 31);
+#pragma unroll
+            for (int fs = 0; fs < kSlots; ++fs) {
+                const float inv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs) / 64], (8 * fs) % 64));
+                const uint64_t pout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 5) / 64], (8 * fs + 5) % 64) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 4) / 64], (8 * fs + 4) % 64);
+                const int t = (fs % 8) / 4, r = 4 * (fs / 8) + fs % 4;
+                const float d0 = acc[0][t][r], d1 = acc[1][t][r], d2c = acc[2][t][r];
+                Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)((char FD_GLOBAL *)(pout + 12ull * (uint64_t)vbase) + off12);
+                if (fs % 2 == 0) {
+                    const uint64_t fa = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 7) / 64], (8 * fs + 7) % 64) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 6) / 64], (8 * fs + 6) % 64);
+                    const int fs1 = fs + 1;
+                    const uint64_t fb = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs1 + 7) / 64], (8 * fs1 + 7) % 64) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs1 + 6) / 64], (8 * fs1 + 6) % 64);
+                    const uint64_t fo = (lane < 32 ? fa : fb) + 4ull * (uint64_t)vbase;
+                    *(f32x2 FD_GLOBAL *)((char FD_GLOBAL *)fo + off8) = ones;
+                }
+                store_pos3(dstP, __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]), __builtin_fmaf(d2c, inv, pos[2]));
+            }
+            settle(nxt);
+            FD_SSTAMP(3)
+            return;
+        }
+        if (inb && gated) {
+            // B2: a gated vertex keeps its position (and no fd_falloff entry is written)
+            for (int f = 0; f < p.nF; ++f) {
+                float *dstp = s_frames[f].P_out;
+                if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
+            }
+        }
+        float fall = 1.f;
+        float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+        const bool doit = inb && !gated;
+        if (doit) {
+            if (p.dist2 != nullptr || !(p.radius2 != 0.f)) {
+                const float q = fminf(own_d2 / p.radius2, 1.f);
+                fall = powf(1.f - q, p.falloffrate);
+            }
+            if (p.tu) {
+                // project_to_tangents (src/SOP_FaceDeform.hpp:28-41): the two axes depend on the vertex only
+                float u[3] = {p.tu[3 * ic], p.tu[3 * ic + 1], p.tu[3 * ic + 2]};
+                float v[3] = {p.tv[3 * ic], p.tv[3 * ic + 1], p.tv[3 * ic + 2]};
+                float n[3] = {p.nrm[3 * ic], p.nrm[3 * ic + 1], p.nrm[3 * ic + 2]};
+                normalize3(u[0], u[1], u[2]);
+                normalize3(v[0], v[1], v[2]);
+                normalize3(n[0], n[1], n[2]);
+                float gm[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gm[r][c] = u[r] * u[c] + v[r] * v[c] + n[r] * n[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    a1[c] = u[0] * gm[0][c] + u[1] * gm[1][c] + u[2] * gm[2][c];
+                    a2[c] = v[0] * gm[0][c] + v[1] * gm[1][c] + v[2] * gm[2][c];
+                }
+                normalize3(a1[0], a1[1], a1[2]);
+                normalize3(a2[0], a2[1], a2[2]);
+            }
+        }
+#pragma unroll
+        for (int fs = 0; fs < kSlots; ++fs) {
+            const int f = fs;
+            if (f >= p.nF) continue;
+            const float inv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f) / 64], (8 * f) % 64));
+            const bool built = __builtin_amdgcn_readlane((int)tab[(8 * f + 1) / 64], (8 * f + 1) % 64) != 0;
+            const uint64_t pout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 5) / 64], (8 * f + 5) % 64) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 4) / 64], (8 * f + 4) % 64);
+            const uint64_t fout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 7) / 64], (8 * f + 7) % 64) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f + 6) / 64], (8 * f + 6) % 64);
+            if (!doit) continue;
+            Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)((char FD_GLOBAL *)(pout + 12ull * (uint64_t)vbase) + off12);
+            if (!built) {
+                if (pout != (uint64_t)p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
+                continue;
+            }
+            const int t = (fs % 8) / 4, r = 4 * (fs / 8) + fs % 4;
+            float disp[3] = {acc[0][t][r] * inv, acc[1][t][r] * inv, acc[2][t][r] * inv};       // 2^-k is exact
+            if (p.dbg & 1) continue;
+            if (p.tu) {
+                const float da1 = disp[0] * a1[0] + disp[1] * a1[1] + disp[2] * a1[2];
+                const float da2 = disp[0] * a2[0] + disp[1] * a2[1] + disp[2] * a2[2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
+            }
+            if (fout) *(float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4) = fall;
+            store_pos3(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+        }
+        FD_SSTAMP(3)
+    };
+    int grp = blockIdx.x;
+    bool built_here = true;
+#pragma unroll
+    for (int q = 0; q < kTabRegs; ++q) {
+        const int idx = 64 * q + lane;
+        if ((idx & 7) == 1) built_here = built_here && tab[q] != 0u;
+    }
+    if (p.fast && __all(built_here)) {
+        const int nfull = (int)(p.N / kSharedThreads);
+        for (; grp < nfull; grp += gridDim.x) do_group(grp, std::true_type{});
+    }
+    for (; grp < ngroups; grp += gridDim.x) do_group(grp, std::false_type{});
+    if (stamp && lane == 0) {
+        for (int q = 0; q < 4; ++q) p.stamps[wave * 8 + q] = st_acc[q];
+        p.stamps[wave * 8 + 4] = __builtin_amdgcn_s_memtime() - st_t0;          // shader clock against the 100 MHz reference
+        p.stamps[wave * 8 + 5] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#undef FD_SSTAMP
+}
+
 }  // namespace
 
 // Frames of one mesh and one rest rig (SharedDeformArgs): pack the weight tiles, then one launch.
@@ -742,9 +1237,16 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         slots.rec32[f] = a.rec32[q]; slots.model[f] = a.model[q];
         out.P_out[f] = a.P_out[q]; out.falloff_out[f] = a.falloff_out ? a.falloff_out[q] : nullptr;
     }
+    // 17..32 thin-plate frames: 32-row tiles (FD_SHARED_WIDE=0: the 16-row kernel, for A/B runs)
+    const bool wide_on = [] { const char *e = getenv("FD_SHARED_WIDE"); return !(e && atoi(e) == 0); }();      // read per launch: A/B inside one process
+    const bool wide = wide_on && shared_wide(a.nF, a.kind);
     if (a.mode != 2) {
-        hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
-                           (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
+        if (wide)
+            hipLaunchKernelGGL(k_pack_shared_wide, dim3(nkb, 3), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, (uint4 *)a.wtiles,
+                               (SharedFrame *)a.frames, a.ctiles);
+        else
+            hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
+                               (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
         if (a.packed_ev) {
             hipError_t e = hipEventRecord(a.packed_ev, stream);
             if (e != hipSuccess) return e;
@@ -775,8 +1277,9 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (want_stamps && !d_stamps) (void)hipMalloc((void **)&d_stamps, 64 * sizeof(unsigned long long));
     p.stamps = want_stamps ? d_stamps : nullptr;
     { static const bool e = getenv("FD_SHARED_STAMPS_GENERAL") != nullptr; if (want_stamps && e) p.fast = 0; }
-    const size_t fixed = sizeof(SharedFrame) * (size_t)shared_slots(nT, dense) + (size_t)nT * 64 * 16;
-    const size_t per_kb = 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
+    const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)3 * 64 * 16
+                              : sizeof(SharedFrame) * (size_t)shared_slots(nT, dense) + (size_t)nT * 64 * 16;
+    const size_t per_kb = wide ? (size_t)1024 + (size_t)kWideW16 * 16 : 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
     int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);
     if (kchunk < 1) return hipErrorInvalidValue;
     if (kchunk > nkb) kchunk = nkb;
@@ -805,7 +1308,15 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((k_deform32_tps_shared<NTV, DNS, GSS>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
     }
 #define FD_SHARED_KIND(NTV, DNS) { if (gauss) FD_SHARED_CASE(NTV, DNS, true) else FD_SHARED_CASE(NTV, DNS, false) }
-    if (dense) {
+    if (wide) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_deform32_tps_shared_wide, dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups);
+    } else if (dense) {
         if (nT == 3) FD_SHARED_KIND(3, true)
         else if (nT == 6) FD_SHARED_KIND(6, true)
         else return hipErrorInvalidValue;
@@ -822,7 +1333,8 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[shared stamps, shader cycles per wave of workgroup 0: load+poly | K loop | transposes | per-vertex + frames]\n");
             for (int w = 0; w < 8; ++w)
-                fprintf(stderr, "   wave %d: %8llu %8llu %8llu %8llu\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3]);
+                fprintf(stderr, "   wave %d: %8llu %8llu %8llu %8llu   (whole: %llu counts in %llu reference ticks)\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3],
+                        h[w * 8 + 4], h[w * 8 + 5]);
         }
     }
     return hipGetLastError();

@@ -47,7 +47,7 @@ def _close(engines, batch):
         e.close()
 
 
-@pytest.mark.parametrize("M,N,F", [(48, 4_099, 3), (256, 20_011, 8), (256, 70_000, 32), (100, 1_000, 1), (800, 3_001, 13)])
+@pytest.mark.parametrize("M,N,F", [(48, 4_099, 3), (256, 20_011, 8), (256, 70_000, 32), (100, 1_000, 1), (800, 3_001, 13), (256, 9_001, 20), (1400, 2_500, 27)])
 def test_shared_frames_match_oracle(hip_lib, oracle, M, N, F):
     dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F)
     rng = np.random.default_rng(M + F)
@@ -351,7 +351,7 @@ def test_a_member_rebuilt_on_its_own_is_not_evaluated_from_a_stale_copy(hip_lib,
 
 @pytest.mark.parametrize("kind,okind,params", [(capi.KERNEL_THIN_PLATE, fo.KERNEL_THIN_PLATE, ()),
                                                (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0))])
-@pytest.mark.parametrize("N,F", [(1, 16), (5, 32), (63, 32), (64, 16), (65, 32), (511, 16), (513, 4), (1025, 32)])
+@pytest.mark.parametrize("N,F", [(1, 16), (5, 32), (63, 32), (64, 16), (65, 32), (511, 16), (513, 4), (1025, 32), (130, 24), (33, 17)])
 def test_shared_launch_at_the_edges_of_its_vertex_groups(hip_lib, oracle, kind, okind, params, N, F):
     """Vertex counts around the wave's 64 and the workgroup's 512, with the frame counts that take the branch-free
     epilogue (16, 32) and the general one (4): every vertex against the oracle, tangent frames and the gate on; and an
