@@ -306,7 +306,8 @@ def c5_roofline(args, B, n_ctrl, n_mine, eval_ms, flops_frames, tf_frames):
         mfma = {"achieved": fl / secs / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                 "flops_per_launch": fl}
         first = hbm if fl / by < ridge else mfma
-        return {"bound": "hbm" if fl / by < ridge else "mfma", "kernel": "k_deform32_tps_shared", "achieved": first["achieved"],
+        return {"bound": "hbm" if fl / by < ridge else "mfma", "kernel": "k_deform32_tps_shared_wide" if B > 16 else "k_deform32_tps_shared",
+                "achieved": first["achieved"],
                 "peak": first["peak"], "unit": first["unit"], "frac": first["frac"], "traffic": None, "avg_launch_ms": eval_ms,
                 "frames_per_launch": B, "intensity_flop_per_byte": fl / by, "ridge_flop_per_byte": ridge, "hbm": hbm, "mfma": mfma}
     return {"bound": "valu_fp32", "kernel": "k_deform32_tps_mfma_batch" if B > 1 else "k_deform32_tps_mfma",
@@ -715,7 +716,8 @@ def main():
             Fl = frames_per_launch
             flops_launch = ((8 + 6 * Fl) * n_ctrl + FLOPS_PER_VERTEX_AFFINE * Fl) * n_verts
             bytes_launch = (12 + 16 * Fl) * n_verts
-            kern = "k_deform32_tps_shared"
+            # 17..32 thin-plate frames take the 32-row tiles (csrc/fd_eval_shared.hip: k_deform32_tps_shared_wide)
+            kern = "k_deform32_tps_shared_wide" if Fl > 16 else "k_deform32_tps_shared"
             # executed on the matrix pipe: 3 split products over the rows of the output tiles + the d2 tiles
             mfma_exec = (3 * 2 * shared_rows(Fl) * n_ctrl + 2 * 16 * n_ctrl) * n_verts        # flop, fp16 MFMA
             secs = launch_ms * 1e-3

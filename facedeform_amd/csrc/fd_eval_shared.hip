@@ -737,6 +737,7 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr bool shared_wide(int nF, int kind) { return nF > 16 && kind == FD_KERNEL_THIN_PLATE; }
 constexpr int kWideSlots = 32;                      // frame records
+constexpr int kWideDefaultVar = 0;
 constexpr int kWideW16 = 3 * 2 * 2 * 64;            // 16-byte words of weight tiles per K block: [component][K step][hi, lo][lane]
 
 // grid (nkb, 3 components), 256 threads.  Output regions as in k_pack_shared with nT = 6: weight tiles, 6 x 64 words of
@@ -831,16 +832,15 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 #ifndef FD_WIDE_VPM
 #define FD_WIDE_VPM 3            // vector instructions placed after each matrix instruction of the K loop
 #endif
-#ifndef FD_WIDE_PATTERN
-#define FD_WIDE_PATTERN 1
-#endif
-#ifndef FD_WIDE_UNROLL2
-#define FD_WIDE_UNROLL2 0        // 1: two operand buffers in turn instead of 32 register copies per block (41 spills around the loop; no faster)
-#endif
 
+// VAR (A/B inside one process, FD_SHARED_WIDE_VAR): bit 0 = two operand buffers in turn instead of 32 register copies per
+// block, bit 1 = the plain issue pattern (one matrix instruction, one logarithm, vector work) instead of the staged one
+template <int VAR>
 __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 {
+    constexpr bool SKEWED = (VAR & 1) != 0;
+    constexpr bool STAGED = true;
     constexpr int TV = 2;                        // vertex tiles (of 32) per wave
     constexpr int kSlots = kWideSlots;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -849,6 +849,9 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     uint4 *s_poly = reinterpret_cast<uint4 *>(smem + sizeof(SharedFrame) * (size_t)kSlots);
     uint2 *s_ct = reinterpret_cast<uint2 *>(s_poly + 3 * 64);
     uint4 *s_w = reinterpret_cast<uint4 *>(s_ct + (size_t)128 * p.kchunk);
+    // fd_falloff pointers of the straight-line epilogue: store q of a group covers frames 4 q .. 4 q + 3, 16 lanes x 16 B each
+    uint64_t *s_ftab = reinterpret_cast<uint64_t *>(s_w + (size_t)kWideW16 * p.kchunk);
+    unsigned *s_ticket = reinterpret_cast<unsigned *>(s_ftab + 512);      // next 64-vertex unit of this workgroup
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -856,6 +859,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     const float n0 = p.norm[0], n1 = p.norm[1], n2 = p.norm[2];
     const float inv_s = p.norm[3];
     const bool resident = p.nkb <= p.kchunk;
+    const unsigned long long st_t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;     // from the kernel's entry
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -868,9 +872,19 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             for (int q = tid; q < nk * 64; q += kSharedThreads) dst[q] = src[q];
         }
         {
+            // eight loads in flight per thread (one at a time the copy of a resident model took 14 round trips to L2,
+            // about a twentieth of the launch, with nothing else running)
             const uint4 *src = p.wtiles + (size_t)kb0 * kWideW16;
             const int n16 = nk * kWideW16;
-            for (int q = tid; q < n16; q += kSharedThreads) s_w[q] = src[q];
+            int q = tid;
+            for (; q + 7 * kSharedThreads < n16; q += 8 * kSharedThreads) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[q + u * kSharedThreads];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s_w[q + u * kSharedThreads] = v[u];
+            }
+            for (; q < n16; q += kSharedThreads) s_w[q] = src[q];
         }
         __syncthreads();
     };
@@ -886,6 +900,8 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         for (int q = tid; q < kSlots * (int)(sizeof(SharedFrame) / 16); q += kSharedThreads) dst[q] = src[q];
         const uint4 *psrc = p.wtiles + (size_t)p.nkb * kWideW16;
         for (int q = tid; q < 3 * 64; q += kSharedThreads) s_poly[q] = psrc[q];
+        if (tid == 0) *s_ticket = 0u;
+        if (p.fast) s_ftab[tid] = (uint64_t)p.frames[4 * (tid >> 6) + ((tid & 63) >> 4)].falloff_out + 16u * (unsigned)(tid & 15);
     }
     if (resident) {
         stage(0, p.nkb);
@@ -893,6 +909,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             __builtin_amdgcn_s_sleep(12);
             for (int q = 0; q < (p.stagger & 0xff); ++q) __builtin_amdgcn_s_sleep(127);
         }
+        if ((p.dbg & 4) && wave >= 4) return;      // diagnostics: one wave per SIMD (no barrier follows while the model is resident)
     } else {
         __syncthreads();
     }
@@ -900,14 +917,28 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     const bool stamp = p.stamps != nullptr && blockIdx.x == 0;
     unsigned long long st_prev = 0, st_acc[5] = {0, 0, 0, 0, 0};
 #define FD_SSTAMP(K) if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[K] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
-    unsigned long long st_t0 = 0, st_r0 = 0;
-    if (stamp) { st_prev = st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (stamp) st_prev = __builtin_amdgcn_s_memtime();
     // lane (h, j) holds the two vertices (vt, j) -- both lane halves the same two
     struct GroupRaw { float p[TV][3]; float d2[TV]; };
-    auto load_raw = [&](int grp_, auto fastTag) {
+    // Units: the workgroup's groups (blockIdx + k gridDim) are eight 64-vertex units each; unit u of the workgroup is unit
+    // u & 7 of its group u >> 3.  While the model is resident (no barrier in the loop) a wave takes its NEXT unit from a
+    // counter in LDS instead of always the one with its own number: the two waves of a SIMD do not run at the same pace
+    // (the second starts later and yields more often), and with fixed shares the first four waves of a workgroup
+    // finished a group's time before the others, who then ran their last group with the matrix pipe half empty.
+    constexpr bool DYNAMIC = (VAR & 2) == 0;
+    const bool dynamic = DYNAMIC && resident;
+    auto unit_group = [&](int u) { return (int)blockIdx.x + (u >> 3) * (int)gridDim.x; };
+    auto unit_global = [&](int u) { return (int64_t)unit_group(u) * 8 + (u & 7); };
+    auto next_unit = [&](int u) {
+        if (!dynamic) return u + 8;
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto load_raw = [&](int64_t gu, auto fastTag) {
         constexpr bool FAST = decltype(fastTag)::value;
         GroupRaw r;
-        const int64_t vb = ((int64_t)grp_ * (kSharedThreads / 64) + wave) * 64;
+        const int64_t vb = gu * 64;
 #pragma unroll
         for (int t = 0; t < TV; ++t) {
             const int64_t vi = vb + 32 * t + j;
@@ -920,12 +951,12 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     auto settle = [&](const GroupRaw &r) {
         asm volatile("" :: "v"(r.p[0][0]), "v"(r.p[0][1]), "v"(r.p[0][2]), "v"(r.p[1][0]), "v"(r.p[1][1]), "v"(r.p[1][2]));
     };
-    GroupRaw nxt = load_raw(blockIdx.x < (unsigned)ngroups ? (int)blockIdx.x : 0, std::false_type{});
-    settle(nxt);
-    auto do_group = [&](int grp, auto fastTag) {
+    GroupRaw nxt;
+    auto do_group = [&](int u, int un, auto fastTag) {
         constexpr bool FAST = decltype(fastTag)::value;
-        const int64_t vbase = ((int64_t)grp * (kSharedThreads / 64) + wave) * 64;
-        if ((((grp / (int)gridDim.x) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+        const int64_t vbase = unit_global(u) * 64;
+        const int64_t gu_next = unit_group(un) < ngroups ? unit_global(un) : unit_global(u);       // whose positions to request
+        if ((((u >> 3) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
         const GroupRaw cur = nxt;
         // this lane's own vertex in the epilogue is (vt = h, j)
@@ -962,8 +993,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         }
         const bool wave_work = FAST ? true : __any(lane_live);
         if constexpr (FAST) {
-            const int gn = grp + (int)gridDim.x;
-            nxt = load_raw(gn < ngroups ? gn : grp, fastTag);      // a whole K loop ahead of this group's stores (as above)
+            nxt = load_raw(gu_next, fastTag);      // a whole K loop ahead of this group's stores (as above)
         }
         FD_SSTAMP(0)
 
@@ -1015,7 +1045,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             // contraction to cover their latency, then one logarithm and FD_WIDE_VPM vector instructions under each
             // matrix instruction; the weights of a (component, K step) pair are read from LDS one pair ahead
             auto interleave = [&]() {
-#if FD_WIDE_PATTERN == 1
+              if constexpr (STAGED) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // d2 operands, weights of the first pair
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1029,7 +1059,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                     if (q >= 2 && q < 34) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
                 }
-#else
+              } else {
 #pragma unroll
                 for (int q = 0; q < 32; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
@@ -1041,33 +1071,82 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
                 }
-#endif
+              }
             };
-#if FD_WIDE_UNROLL2
-            // two operand buffers in turn, no copies; a full scheduling barrier between the halves
-            u32x8 bhA[TV], blA[TV], bhB[TV], blB[TV];
-            phi_block(0, bhA, blA);
-            int kb = 0;
-            for (; kb + 2 < nk; kb += 2) {
-                phi_block(kb + 1, bhB, blB);
-                contract(kb, bhA, blA);
-                interleave();
-                __builtin_amdgcn_sched_barrier(0);
-                phi_block(kb + 2, bhA, blA);
-                contract(kb + 1, bhB, blB);
-                interleave();
-                __builtin_amdgcn_sched_barrier(0);
+          if constexpr (SKEWED) {
+            // Pipeline skewed by HALF a block, no operand copies: the d2 of block kb + 1 is issued in the middle of
+            // block kb; its K step 0 operands are formed under block kb's K step 1 instructions (whose own step 0
+            // operands are dead by then) and its K step 1 operands under the first half of block kb + 1.
+            u32x4 b0h[TV], b0l[TV], b1h[TV], b1l[TV];
+            f32x16 dd[TV];
+            auto d2_block = [&](int kb) {
+                const f16x4 aop0 = __builtin_bit_cast(f16x4, s_ct[(size_t)kb * 128 + lane]);
+                const f16x4 aop1 = __builtin_bit_cast(f16x4, s_ct[(size_t)kb * 128 + 64 + lane]);
+#pragma unroll
+                for (int t = 0; t < TV; ++t) {
+                    dd[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(aop0, bop0[t], zero16, 0, 0, 0);
+                    dd[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(aop1, bop1[t], dd[t], 0, 0, 0);
+                }
+            };
+            auto phi_half = [&](int s, u32x4 (&xh)[TV], u32x4 (&xl)[TV]) {
+#pragma unroll
+                for (int t = 0; t < TV; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned hh, ll;
+                        split_pair_f16(d2_log_d2(dd[t][8 * s + 2 * q]), d2_log_d2(dd[t][8 * s + 2 * q + 1]), hh, ll);
+                        xh[t][q] = hh; xl[t][q] = ll;
+                    }
+            };
+            auto contract_half = [&](int kb, int s, const u32x4 (&xh)[TV], const u32x4 (&xl)[TV]) {
+                const uint4 *wk = s_w + (size_t)kb * kWideW16 + lane;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, wk[((c * 2 + s) * 2) * 64]), al = __builtin_bit_cast(f16x8, wk[((c * 2 + s) * 2 + 1) * 64]);
+#pragma unroll
+                    for (int t = 0; t < TV; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, xh[t]), acc[c][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TV; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, xh[t]), acc[c][t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TV; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, xl[t]), acc[c][t], 0, 0, 0);
+                }
+            };
+            d2_block(0);
+            phi_half(0, b0h, b0l);
+            for (int kb = 0; kb + 1 < nk; ++kb) {
+                phi_half(1, b1h, b1l);
+                contract_half(kb, 0, b0h, b0l);
+                d2_block(kb + 1);
+                phi_half(0, b0h, b0l);
+                contract_half(kb, 1, b1h, b1l);
+                // issue order: 18 matrix instructions of K step 0 with the 16 logarithms of this block's step 1 operands,
+                // the four d2 instructions, 18 of K step 1 with the next block's 16 (two instructions after the d2)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int q = 0; q < 18; ++q) {
+                    if (q % 6 == 0 && q > 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (q < 16) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 18; ++q) {
+                    if (q % 6 == 0 && q > 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                }
             }
-            if (kb + 1 < nk) {
-                phi_block(kb + 1, bhB, blB);
-                contract(kb, bhA, blA);
-                interleave();
-                __builtin_amdgcn_sched_barrier(0);
-                contract(kb + 1, bhB, blB);
-            } else {
-                contract(kb, bhA, blA);
-            }
-#else
+            phi_half(1, b1h, b1l);
+            contract_half(nk - 1, 0, b0h, b0l);
+            contract_half(nk - 1, 1, b1h, b1l);
+          } else {
             u32x8 bh[TV], bl[TV];
             phi_block(0, bh, bl);
             for (int kb = 0; kb + 1 < nk; ++kb) {
@@ -1079,7 +1158,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 for (int t = 0; t < TV; ++t) { bh[t] = nbh[t]; bl[t] = nbl[t]; }
             }
             contract(nk - 1, bh, bl);
-#endif
+          }
         }
 
         FD_SSTAMP(1)
@@ -1101,14 +1180,17 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         const bool gated = own_d2 > p.radius2;
         const unsigned off12 = 12u * (unsigned)lane, off4 = 4u * (unsigned)lane;
         if constexpr (!FAST) {
-            const int gn = grp + (int)gridDim.x;
-            nxt = load_raw(gn < ngroups ? gn : grp, fastTag);
+            nxt = load_raw(gu_next, fastTag);
         }
         FD_SSTAMP(2)
         if constexpr (FAST) {
-            // straight-line stores (see k_deform32_tps_shared): 32 positions + 16 paired fall-off rows
-            const f32x2 ones = {1.f, 1.f};
-            const unsigned off8 = 8u * (unsigned)(lane & 31);
+            // straight-line stores (see k_deform32_tps_shared): 32 positions + 8 fall-off stores of four frames each.
+            // A frame's scalars come out of the table with v_readlane; its address is the frame's pointer as the
+            // scalar base plus ONE 32-bit lane offset for all frames (12 (vbase + lane); the host checks 12 N < 2^32),
+            // and the fall-off stores take their per-lane pointers from LDS: ~330 instructions per group, not 640.
+            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+            const unsigned voff = 12u * (unsigned)vbase + off12;
+            const uint64_t fbase = 4ull * (uint64_t)vbase;
 #pragma unroll
             for (int fs = 0; fs < kSlots; ++fs) {
                 const float inv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs) / 64], (8 * fs) % 64));
@@ -1116,17 +1198,9 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                                       (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 4) / 64], (8 * fs + 4) % 64);
                 const int t = (fs % 8) / 4, r = 4 * (fs / 8) + fs % 4;
                 const float d0 = acc[0][t][r], d1 = acc[1][t][r], d2c = acc[2][t][r];
-                Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)((char FD_GLOBAL *)(pout + 12ull * (uint64_t)vbase) + off12);
-                if (fs % 2 == 0) {
-                    const uint64_t fa = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 7) / 64], (8 * fs + 7) % 64) << 32) |
-                                        (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 6) / 64], (8 * fs + 6) % 64);
-                    const int fs1 = fs + 1;
-                    const uint64_t fb = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs1 + 7) / 64], (8 * fs1 + 7) % 64) << 32) |
-                                        (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs1 + 6) / 64], (8 * fs1 + 6) % 64);
-                    const uint64_t fo = (lane < 32 ? fa : fb) + 4ull * (uint64_t)vbase;
-                    *(f32x2 FD_GLOBAL *)((char FD_GLOBAL *)fo + off8) = ones;
-                }
-                store_pos3(dstP, __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]), __builtin_fmaf(d2c, inv, pos[2]));
+                if (fs % 4 == 0) *(f32x4 FD_GLOBAL *)(s_ftab[(fs / 4) * 64 + lane] + fbase) = ones;
+                store_pos3((Pos3 FD_GLOBAL *)((char FD_GLOBAL *)pout + voff), __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]),
+                           __builtin_fmaf(d2c, inv, pos[2]));
             }
             settle(nxt);
             FD_SSTAMP(3)
@@ -1199,18 +1273,31 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         }
         FD_SSTAMP(3)
     };
-    int grp = blockIdx.x;
     bool built_here = true;
 #pragma unroll
     for (int q = 0; q < kTabRegs; ++q) {
         const int idx = 64 * q + lane;
         if ((idx & 7) == 1) built_here = built_here && tab[q] != 0u;
     }
-    if (p.fast && __all(built_here)) {
-        const int nfull = (int)(p.N / kSharedThreads);
-        for (; grp < nfull; grp += gridDim.x) do_group(grp, std::true_type{});
+    const bool fast_ok = p.fast && __all(built_here);
+    const int nfull = (int)(p.N / kSharedThreads);       // groups in which every wave's 64 vertices exist
+    int u = dynamic ? next_unit(0) : wave;
+    nxt = load_raw(unit_group(u) < ngroups ? unit_global(u) : 0, std::false_type{});
+    settle(nxt);
+    // two loops, not one with a branch: where the two kinds of group met at the loop's head the compiler had to assume the
+    // worst of both for the loads in flight, and waited for every store of the straight-line epilogue again
+    if (fast_ok) {
+        while (unit_group(u) < nfull) {
+            const int un = next_unit(u);     // taken now: its positions are requested a K loop ahead
+            do_group(u, un, std::true_type{});
+            u = un;
+        }
     }
-    for (; grp < ngroups; grp += gridDim.x) do_group(grp, std::false_type{});
+    while (unit_group(u) < ngroups) {
+        const int un = next_unit(u);
+        do_group(u, un, std::false_type{});
+        u = un;
+    }
     if (stamp && lane == 0) {
         for (int q = 0; q < 4; ++q) p.stamps[wave * 8 + q] = st_acc[q];
         p.stamps[wave * 8 + 4] = __builtin_amdgcn_s_memtime() - st_t0;          // shader clock against the 100 MHz reference
@@ -1267,7 +1354,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     {
         static const bool no_fast = getenv("FD_SHARED_NO_FAST") != nullptr;       // A/B: general epilogue everywhere
         bool fast = !no_fast && (p.dbg & 1) == 0 && a.dist2 == nullptr && a.tu == nullptr && a.radius2 > 0.f && a.falloff_out != nullptr &&
-                    a.nF == shared_slots(nT, dense);
+                    a.nF == shared_slots(nT, dense) && a.N < ((int64_t)1 << 28);
         for (int f = 0; fast && f < a.nF; ++f) fast = a.falloff_out[f] != nullptr && a.P_out[f] != nullptr;
         p.fast = fast ? 1 : 0;
     }
@@ -1277,7 +1364,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (want_stamps && !d_stamps) (void)hipMalloc((void **)&d_stamps, 64 * sizeof(unsigned long long));
     p.stamps = want_stamps ? d_stamps : nullptr;
     { static const bool e = getenv("FD_SHARED_STAMPS_GENERAL") != nullptr; if (want_stamps && e) p.fast = 0; }
-    const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)3 * 64 * 16
+    const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)3 * 64 * 16 + 512 * sizeof(uint64_t) + 16
                               : sizeof(SharedFrame) * (size_t)shared_slots(nT, dense) + (size_t)nT * 64 * 16;
     const size_t per_kb = wide ? (size_t)1024 + (size_t)kWideW16 * 16 : 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
     int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);
@@ -1308,14 +1395,21 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((k_deform32_tps_shared<NTV, DNS, GSS>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
     }
 #define FD_SHARED_KIND(NTV, DNS) { if (gauss) FD_SHARED_CASE(NTV, DNS, true) else FD_SHARED_CASE(NTV, DNS, false) }
+#define FD_WIDE_CASE(V)                                                                                              \
+    {                                                                                                                \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide<V>,                          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+            if (e != hipSuccess) return e;                                                                           \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_deform32_tps_shared_wide<V>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
+    }
     if (wide) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_deform32_tps_shared_wide, dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups);
+        const char *ev = getenv("FD_SHARED_WIDE_VAR");
+        const int var = ev ? atoi(ev) : kWideDefaultVar;
+        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else FD_WIDE_CASE(0)
     } else if (dense) {
         if (nT == 3) FD_SHARED_KIND(3, true)
         else if (nT == 6) FD_SHARED_KIND(6, true)
@@ -1328,6 +1422,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     }
 #undef FD_SHARED_KIND
 #undef FD_SHARED_CASE
+#undef FD_WIDE_CASE
     if (want_stamps && d_stamps) {
         unsigned long long h[64];
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {

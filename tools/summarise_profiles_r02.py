@@ -32,15 +32,18 @@ def main():
         if os.path.exists(f"{SRC}/{a}"):
             open(f"{DST}/{b}", "w").write(clean(f"{SRC}/{a}"))
     tot = {}
+    kname = "k_deform32_tps_shared"
     for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mfma"):
         for r in csv.DictReader(open(glob.glob(f"{SRC}/{d}/**/*counter_collection.csv", recursive=True)[0])):
             if KERNEL in r["Kernel_Name"]:
                 tot.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                if "shared_wide" in r["Kernel_Name"]:
+                    kname = "k_deform32_tps_shared_wide"
     m = {k: sum(v) / len(v) for k, v in tot.items()}
     fetch, write = m["FETCH_SIZE"] * 1024 * 2, m["WRITE_SIZE"] * 1024
     cycles = m["GRBM_GUI_ACTIVE"] / 8
     with open(f"{DST}/r02_pmc_shared_c2.txt", "w") as f:
-        f.write("k_deform32_tps_shared<6, dense, thin-plate>, C2 (N=1e6, M=256), 32 frames per launch; rocprofv3 --pmc, one counter group per pass\n")
+        f.write(f"{kname}, C2 (N=1e6, M=256), 32 thin-plate frames per launch; rocprofv3 --pmc, one counter group per pass\n")
         f.write(f"(tools/collect_profiles_r02.sh: FETCH_SIZE | WRITE_SIZE | SQ_* activity | SQ_*MFMA/LDS), mean over {len(tot['FETCH_SIZE'])} launches\n\n")
         for k in sorted(m):
             f.write(f"{k:28s} {m[k]:16.1f}\n")
@@ -53,7 +56,7 @@ def main():
         f.write(f"VALU instructions = {m['SQ_INSTS_VALU']:.0f}; LDS instructions = {m['SQ_INSTS_LDS']:.0f}; LDS bank conflicts = {m['SQ_LDS_BANK_CONFLICT']:.0f}\n")
         f.write(f"SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:.3f};  SQ_WAIT_ANY / SQ_WAVE_CYCLES = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.3f}\n")
     tj = json.load(open(f"{DST}/traffic_c2.json"))
-    k = tj["kernels"]["k_deform32_tps_shared"]
+    k = tj["kernels"].setdefault(kname, dict(tj["kernels"]["k_deform32_tps_shared"]))
     k.update({"FETCH_SIZE_KiB_raw": m["FETCH_SIZE"], "WRITE_SIZE_KiB": m["WRITE_SIZE"], "hbm_bytes_per_launch": fetch + write,
               "hbm_bytes_fixed_per_launch": fetch, "hbm_bytes_per_frame": write / 32,
               "mfma_busy_frac": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024),
