@@ -737,7 +737,7 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr bool shared_wide(int nF, int kind) { return nF > 16 && kind == FD_KERNEL_THIN_PLATE; }
 constexpr int kWideSlots = 32;                      // frame records
-constexpr int kWideDefaultVar = 0;
+constexpr int kWideDefaultVar = 1;      // skewed K loop, units from the counter: the fastest inside bench.py (tests/tools/wide_variants_timing.py for the others)
 constexpr int kWideW16 = 3 * 2 * 2 * 64;            // 16-byte words of weight tiles per K block: [component][K step][hi, lo][lane]
 
 // grid (nkb, 3 components), 256 threads.  Output regions as in k_pack_shared with nT = 6: weight tiles, 6 x 64 words of

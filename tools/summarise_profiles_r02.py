@@ -28,7 +28,7 @@ def main():
     shutil.copy(glob.glob(f"{SRC}/shared/**/*kernel_stats.csv", recursive=True)[0], f"{DST}/r02_shared_c2_kernel_stats.csv")
     for a, b in (("scaled_delta_parity.txt", "r02_scaled_delta_parity.txt"), ("shared_timing_c2.txt", "r02_shared_timing.txt"),
                  ("solver_latency.txt", "r02_solver_latency.txt"), ("hbm_write_rate.txt", "r02_hbm_write_rate.txt"),
-                 ("ubench_mfma16.txt", "r02_ubench_mfma16.txt")):
+                 ("ubench_mfma16.txt", "r02_ubench_mfma16.txt"), ("wide_variants.txt", "r02_wide_variants.txt")):
         if os.path.exists(f"{SRC}/{a}"):
             open(f"{DST}/{b}", "w").write(clean(f"{SRC}/{a}"))
     tot = {}
