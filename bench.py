@@ -86,9 +86,10 @@ def parse_args():
                          "(hipExtStreamCreateWithCUMask): --eval-cus CUs for the evaluation, the others for the builds.  Measured "
                          "worse (68k against 112k Mverts/s: confined to 32 CUs a batched build takes 1.37 ms instead of 0.8 -- "
                          "unconfined, the builds also use the evaluation's CUs between its launches); kept for the record")
-    ap.add_argument("--c5-group", type=int, default=16,
-                    help="config c5: frames per group (one batched build, one broadcast, one evaluation launch; 8: 55k, 16: 86k, 32: 86k "
-                         "Mverts/s on one GPU -- at 32 the 512-centre model no longer fits the LDS in one piece)")
+    ap.add_argument("--c5-group", type=int, default=32,
+                    help="config c5: frames per group (one batched build, one broadcast, one evaluation launch; 8: 55k, 16: 86k, 32: 88.5k "
+                         "Mverts/s on one GPU -- at 32 the 512-centre model no longer fits the LDS in one piece, but the 32-row kernel "
+                         "it selects makes up for the staging)")
     ap.add_argument("--c5-solve", choices=["broadcast", "redundant"], default="broadcast",
                     help="config c5: rank 0 solves and broadcasts the models (default), or every rank solves them itself")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",

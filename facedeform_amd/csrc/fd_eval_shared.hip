@@ -1303,6 +1303,10 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         p.stamps[wave * 8 + 4] = __builtin_amdgcn_s_memtime() - st_t0;          // shader clock against the 100 MHz reference
         p.stamps[wave * 8 + 5] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
+    if (p.stamps != nullptr && lane == 0) {      // every wave's first and last tick of the 100 MHz clock: the spread over the workgroups
+        p.stamps[64 + ((size_t)blockIdx.x * 8 + wave) * 2] = st_r0;
+        p.stamps[64 + ((size_t)blockIdx.x * 8 + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 #undef FD_SSTAMP
 }
 
@@ -1361,7 +1365,9 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
     static unsigned long long *d_stamps = nullptr;
     static const bool want_stamps = getenv("FD_SHARED_STAMPS") != nullptr;
-    if (want_stamps && !d_stamps) (void)hipMalloc((void **)&d_stamps, 64 * sizeof(unsigned long long));
+    constexpr size_t kStampWords = 64 + (size_t)kNumCU * 8 * 2;
+    if (want_stamps && !d_stamps) (void)hipMalloc((void **)&d_stamps, kStampWords * sizeof(unsigned long long));
+    if (want_stamps && d_stamps) (void)hipMemsetAsync(d_stamps, 0, kStampWords * sizeof(unsigned long long), stream);
     p.stamps = want_stamps ? d_stamps : nullptr;
     { static const bool e = getenv("FD_SHARED_STAMPS_GENERAL") != nullptr; if (want_stamps && e) p.fast = 0; }
     const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)3 * 64 * 16 + 512 * sizeof(uint64_t) + 16
@@ -1424,8 +1430,20 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
 #undef FD_SHARED_CASE
 #undef FD_WIDE_CASE
     if (want_stamps && d_stamps) {
-        unsigned long long h[64];
+        static unsigned long long h[kStampWords];
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (wide) {
+                // first tick anywhere to every workgroup's first and last tick: who starts late, who finishes late (10 ns units)
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (unsigned b = 0; b < grid * 8; ++b) if (h[64 + 2 * b]) { t0 = h[64 + 2 * b] < t0 ? h[64 + 2 * b] : t0; t1 = h[65 + 2 * b] > t1 ? h[65 + 2 * b] : t1; }
+                fprintf(stderr, "[shared stamps: %u workgroups, first entry to last exit %.1f us; per workgroup (entry, exit) in us after the first entry:]\n", grid, (t1 - t0) * 0.01);
+                for (unsigned b = 0; b < grid; ++b) {
+                    unsigned long long a = ~0ull, z = 0;
+                    for (int w = 0; w < 8; ++w) if (h[64 + 2 * (b * 8 + w)]) { a = h[64 + 2 * (b * 8 + w)] < a ? h[64 + 2 * (b * 8 + w)] : a; z = h[65 + 2 * (b * 8 + w)] > z ? h[65 + 2 * (b * 8 + w)] : z; }
+                    fprintf(stderr, "%s%5.1f-%5.1f", b % 8 ? "  " : "\n   ", (a - t0) * 0.01, (z - t0) * 0.01);
+                }
+                fprintf(stderr, "\n");
+            }
             fprintf(stderr, "[shared stamps, shader cycles per wave of workgroup 0: load+poly | K loop | transposes | per-vertex + frames]\n");
             for (int w = 0; w < 8; ++w)
                 fprintf(stderr, "   wave %d: %8llu %8llu %8llu %8llu   (whole: %llu counts in %llu reference ticks)\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3],

@@ -399,3 +399,34 @@ def test_shared_launch_at_the_edges_of_its_vertex_groups(hip_lib, oracle, kind, 
     batch.close()
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize("wide,var", [("1", "0"), ("1", "1"), ("1", "2"), ("1", "3"), ("0", "0")])
+def test_every_form_of_the_32_frame_launch_matches_the_oracle(hip_lib, oracle, monkeypatch, wide, var):
+    """17..32 thin-plate frames take the 32-row tiles (k_deform32_tps_shared_wide); its build variants and the 16-row
+    kernel stay selectable per launch (FD_SHARED_WIDE, FD_SHARED_WIDE_VAR) for A/B runs -- each held to the oracle, on the
+    straight-line epilogue (full groups, fd_falloff everywhere) and on the general one (ragged tail, gate)."""
+    monkeypatch.setenv("FD_SHARED_WIDE", wide)
+    monkeypatch.setenv("FD_SHARED_WIDE_VAR", var)
+    M, N, F = 256, 5 * 512 + 77, 32
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F)
+    outs = [torch.empty_like(d_P) for _ in range(F)]
+    falls = [torch.full((N,), 7.0, device=dev) for _ in range(F)]
+    dist2 = (np.random.default_rng(5).random(N) * 0.6).astype(np.float32)
+    d_d2 = torch.from_numpy(dist2).to(dev)
+    r2 = np.float32(0.49)
+    for gate in (False, True):
+        kw = dict(d_dist2=d_d2.data_ptr(), radius2=r2, falloffrate=1.5) if gate else {}
+        okw = dict(dist2=dist2, radius2=r2, falloffrate=1.5) if gate else {}
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], d_falloff=[f.data_ptr() for f in falls], **kw)
+        torch.cuda.synchronize()
+        for f in (0, 5, 17, 31):
+            table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
+            rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+            ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, **okw)
+            out = outs[f].cpu().numpy()
+            assert parity_ratio(out, ref, P, TOL) <= 1.0, (gate, f)
+            gated = dist2 > r2 if gate else np.zeros(N, bool)
+            assert np.array_equal(out[gated], P[gated])
+            assert np.allclose(falls[f].cpu().numpy()[~gated], ref_fall[~gated], rtol=2e-6, atol=1e-7)
+    _close(engines, batch)
