@@ -275,9 +275,18 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
             for (int q = tid; q < 2 * nk * per; q += kSharedThreads) dst[q] = src[q];
         }
         {
-            const uint4 *src = p.wtiles + (size_t)kb0 * NT * 128;
+            // eight loads in flight per thread (native vectors: an array of HIP's uint4 structs goes through scratch memory)
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(p.wtiles + (size_t)kb0 * NT * 128);
+            u32x4 *dst = reinterpret_cast<u32x4 *>(s_w);
             const int n16 = nk * NT * 128;
-            for (int q = tid; q < n16; q += kSharedThreads) s_w[q] = src[q];
+            int q = tid;
+            for (; q + 7 * kSharedThreads < n16; q += 8 * kSharedThreads) {
+                const u32x4 v0 = src[q], v1 = src[q + kSharedThreads], v2 = src[q + 2 * kSharedThreads], v3 = src[q + 3 * kSharedThreads];
+                const u32x4 v4 = src[q + 4 * kSharedThreads], v5 = src[q + 5 * kSharedThreads], v6 = src[q + 6 * kSharedThreads], v7 = src[q + 7 * kSharedThreads];
+                dst[q] = v0; dst[q + kSharedThreads] = v1; dst[q + 2 * kSharedThreads] = v2; dst[q + 3 * kSharedThreads] = v3;
+                dst[q + 4 * kSharedThreads] = v4; dst[q + 5 * kSharedThreads] = v5; dst[q + 6 * kSharedThreads] = v6; dst[q + 7 * kSharedThreads] = v7;
+            }
+            for (; q < n16; q += kSharedThreads) dst[q] = src[q];
         }
         __syncthreads();
     };
@@ -840,6 +849,7 @@ __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 {
     constexpr bool SKEWED = (VAR & 1) != 0;
+    constexpr bool AHEAD = (VAR & 4) != 0;
     constexpr bool STAGED = true;
     constexpr int TV = 2;                        // vertex tiles (of 32) per wave
     constexpr int kSlots = kWideSlots;
@@ -874,17 +884,18 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         {
             // eight loads in flight per thread (one at a time the copy of a resident model took 14 round trips to L2,
             // about a twentieth of the launch, with nothing else running)
-            const uint4 *src = p.wtiles + (size_t)kb0 * kWideW16;
+            // (native vectors: an array of HIP's uint4 structs went through scratch memory)
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(p.wtiles + (size_t)kb0 * kWideW16);
+            u32x4 *dst = reinterpret_cast<u32x4 *>(s_w);
             const int n16 = nk * kWideW16;
             int q = tid;
             for (; q + 7 * kSharedThreads < n16; q += 8 * kSharedThreads) {
-                uint4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[q + u * kSharedThreads];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s_w[q + u * kSharedThreads] = v[u];
+                const u32x4 v0 = src[q], v1 = src[q + kSharedThreads], v2 = src[q + 2 * kSharedThreads], v3 = src[q + 3 * kSharedThreads];
+                const u32x4 v4 = src[q + 4 * kSharedThreads], v5 = src[q + 5 * kSharedThreads], v6 = src[q + 6 * kSharedThreads], v7 = src[q + 7 * kSharedThreads];
+                dst[q] = v0; dst[q + kSharedThreads] = v1; dst[q + 2 * kSharedThreads] = v2; dst[q + 3 * kSharedThreads] = v3;
+                dst[q + 4 * kSharedThreads] = v4; dst[q + 5 * kSharedThreads] = v5; dst[q + 6 * kSharedThreads] = v6; dst[q + 7 * kSharedThreads] = v7;
             }
-            for (; q < n16; q += kSharedThreads) s_w[q] = src[q];
+            for (; q < n16; q += kSharedThreads) dst[q] = src[q];
         }
         __syncthreads();
     };
@@ -1121,6 +1132,32 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 contract_half(kb, 1, b1h, b1l);
                 // issue order: 18 matrix instructions of K step 0 with the 16 logarithms of this block's step 1 operands,
                 // the four d2 instructions, 18 of K step 1 with the next block's 16 (two instructions after the d2)
+              if constexpr (AHEAD) {
+                // LDS reads one (component, K step) pair AHEAD of their use: the pair after next is requested behind the
+                // first matrix instruction of the current one (as written above, each pair's first instruction waited
+                // out the LDS latency of its own operands: six exposed round trips per block)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int q = 0; q < 18; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (q % 6 == 0 && q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (q == 12) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // d2 operands, first pair of K step 1
+                    if (q < 16) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 18; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (q % 6 == 0 && q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                }
+              } else {
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
                 for (int q = 0; q < 18; ++q) {
@@ -1142,6 +1179,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                     if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
                 }
+              }
             }
             phi_half(1, b1h, b1l);
             contract_half(nk - 1, 0, b0h, b0l);
@@ -1415,7 +1453,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (wide) {
         const char *ev = getenv("FD_SHARED_WIDE_VAR");
         const int var = ev ? atoi(ev) : kWideDefaultVar;
-        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else FD_WIDE_CASE(0)
+        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else FD_WIDE_CASE(0)
     } else if (dense) {
         if (nT == 3) FD_SHARED_KIND(3, true)
         else if (nT == 6) FD_SHARED_KIND(6, true)
