@@ -87,7 +87,7 @@ def parse_args():
                          "worse (68k against 112k Mverts/s: confined to 32 CUs a batched build takes 1.37 ms instead of 0.8 -- "
                          "unconfined, the builds also use the evaluation's CUs between its launches); kept for the record")
     ap.add_argument("--c5-group", type=int, default=32,
-                    help="config c5: frames per group (one batched build, one broadcast, one evaluation launch; 8: 55k, 16: 86k, 32: 88.5k "
+                    help="config c5: frames per group (one batched build, one broadcast, one evaluation launch; 8: 55k, 16: 86k, 32: 97k "
                          "Mverts/s on one GPU -- at 32 the 512-centre model no longer fits the LDS in one piece, but the 32-row kernel "
                          "it selects makes up for the staging)")
     ap.add_argument("--c5-solve", choices=["broadcast", "redundant"], default="broadcast",
