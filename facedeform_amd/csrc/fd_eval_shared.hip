@@ -938,8 +938,17 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     // finished a group's time before the others, who then ran their last group with the matrix pipe half empty.
     constexpr bool DYNAMIC = (VAR & 2) == 0;
     const bool dynamic = DYNAMIC && resident;
-    auto unit_group = [&](int u) { return (int)blockIdx.x + (u >> 3) * (int)gridDim.x; };
-    auto unit_global = [&](int u) { return (int64_t)unit_group(u) * 8 + (u & 7); };
+    // The groups that do not fill a last round (ngroups % gridDim of them) are dealt out as single units, workgroup by
+    // workgroup (VAR bit 3 clear): every workgroup then ends with one or two lone units at a lone wave's pace (0.6 of a
+    // round) instead of a few workgroups running a whole extra round beside idle CUs (at 192 CUs: 34 of them).
+    constexpr bool POOL = (VAR & 8) == 0;
+    const int whole_rounds = (dynamic && POOL) ? ngroups / (int)gridDim.x : (ngroups + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int64_t pool0 = (int64_t)whole_rounds * (int64_t)gridDim.x * 8, total_units = (int64_t)ngroups * 8;
+    auto unit_global = [&](int u) -> int64_t {          // the 64-vertex unit behind local ticket u (>= total_units: none)
+        if (u < 8 * whole_rounds) return ((int64_t)blockIdx.x + (int64_t)(u >> 3) * (int64_t)gridDim.x) * 8 + (u & 7);
+        return pool0 + (int64_t)blockIdx.x + (int64_t)(u - 8 * whole_rounds) * (int64_t)gridDim.x;
+    };
+    auto unit_group = [&](int u) -> int64_t { const int64_t g = unit_global(u); return g < total_units ? (g >> 3) : (int64_t)ngroups; };
     auto next_unit = [&](int u) {
         if (!dynamic) return u + 8;
         unsigned v = 0;
@@ -1453,7 +1462,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (wide) {
         const char *ev = getenv("FD_SHARED_WIDE_VAR");
         const int var = ev ? atoi(ev) : kWideDefaultVar;
-        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else FD_WIDE_CASE(0)
+        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else if (var == 9) FD_WIDE_CASE(9) else FD_WIDE_CASE(0)
     } else if (dense) {
         if (nT == 3) FD_SHARED_KIND(3, true)
         else if (nT == 6) FD_SHARED_KIND(6, true)
