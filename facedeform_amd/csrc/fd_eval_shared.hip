@@ -744,7 +744,7 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 // r of lane half h -- which after the logarithm ARE the lane's B operands of the two K = 16 steps (registers 0..7 and
 // 8..15): the weight tiles are packed to that centre order.  The epilogue needs one v_permlane32_swap per register pair.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr bool shared_wide(int nF, int kind) { return nF > 16 && kind == FD_KERNEL_THIN_PLATE; }
+constexpr bool shared_wide(int nF, int kind) { (void)kind; return nF > 16; }      // thin-plate and the Gaussian kinds alike
 constexpr int kWideSlots = 32;                      // frame records
 constexpr int kWideDefaultVar = 1;      // skewed K loop, units from the counter: the fastest inside bench.py (tests/tools/wide_variants_timing.py for the others)
 constexpr int kWideW16 = 3 * 2 * 2 * 64;            // 16-byte words of weight tiles per K block: [component][K step][hi, lo][lane]
@@ -753,7 +753,7 @@ constexpr int kWideW16 = 3 * 2 * 2 * 64;            // 16-byte words of weight t
 // polynomial tiles (the first 3 x 64 used), then the d2 operands of the centres ([kb][2 instructions][64 lanes] x 8 B
 // inside the 2 x 768 B per K block of the 16-row layout's centre tiles) and the normalisation.
 __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slots, const SharedOut out, int nF, int Mpad,
-                                                           uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles)
+                                                           uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles, int gauss)
 {
     const int kb = blockIdx.x, c = blockIdx.y, nkb = gridDim.x;
     const size_t poly_at = (size_t)nkb * kWideW16, copy_at = poly_at + 6 * 64;
@@ -761,7 +761,15 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
         // lane (h, r) of instruction i: k-slots 4 h .. 4 h + 3 of centre r = coordinate group 2 i + h of the 16-row tile
         constexpr int per = (int)(sizeof(MfmaTileH) / 16);
         uint2 *dst = reinterpret_cast<uint2 *>(wtiles + copy_at) + (size_t)kb * 128;
-        if (threadIdx.x < 128) {
+        if (gauss) {
+            // Gaussian kinds: the K block's slot holds its 32 centre records instead ({c'x, c'y, c'z, -log2(e) s^2 / R_j^2}:
+            // the first half of Rec32), read by direct differences
+            if (threadIdx.x < 32) {
+                const int centre = 32 * kb + (int)threadIdx.x;
+                wtiles[copy_at + (size_t)kb * 64 + threadIdx.x] =
+                    centre < Mpad ? *reinterpret_cast<const uint4 *>(&slots.rec32[0][centre]) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else if (threadIdx.x < 128) {
             const int i = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
             const int tile = 2 * kb + (r >> 4);
             uint2 v = make_uint2(0u, 0u);
@@ -791,7 +799,7 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
             s_scale[f] = ldexpf(1.f, k);
             if (kb == 0 && c == 0) {
                 SharedFrame fr;
-                fr.inv_scale = ldexpf(1.f, -k);
+                fr.inv_scale = ldexpf(1.f, -k - (gauss ? kGaussShift : 0));
                 fr.built = (f < nF && slots.model[f]->terminationtype == 1) ? 1 : 0;
                 fr.pad[0] = fr.pad[1] = 0;
                 fr.P_out = f < nF ? out.P_out[f] : nullptr;
@@ -844,11 +852,12 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 
 // VAR (A/B inside one process, FD_SHARED_WIDE_VAR): bit 0 = two operand buffers in turn instead of 32 register copies per
 // block, bit 1 = the plain issue pattern (one matrix instruction, one logarithm, vector work) instead of the staged one
-template <int VAR>
+template <int VAR, bool GAUSS = false>
 __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 {
     constexpr bool SKEWED = (VAR & 1) != 0;
+    static_assert(!GAUSS || SKEWED, "the Gaussian kinds take the skewed loop only");
     constexpr bool AHEAD = (VAR & 4) != 0;
     constexpr bool STAGED = true;
     constexpr int TV = 2;                        // vertex tiles (of 32) per wave
@@ -983,12 +992,14 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         const float pos[3] = {h ? cur.p[1][0] : cur.p[0][0], h ? cur.p[1][1] : cur.p[0][1], h ? cur.p[1][2] : cur.p[0][2]};
         const float own_d2 = h ? cur.d2[1] : cur.d2[0];
         f16x4 bop0[TV], bop1[TV];
+        float xn[TV], yn[TV], zn[TV];            // GAUSS: the normalised coordinates, for the direct differences
         f32x16 acc[3][TV];
         bool lane_live = false;
 #pragma unroll
         for (int t = 0; t < TV; ++t) {
             const int64_t vi = vbase + 32 * t + j;
             const float x = (cur.p[t][0] - n0) * inv_s, y = (cur.p[t][1] - n1) * inv_s, z = (cur.p[t][2] - n2) * inv_s;
+            xn[t] = x; yn[t] = y; zn[t] = z;
             const float d2v = cur.d2[t];
             if constexpr (FAST) lane_live = true; else lane_live |= (vi < p.N) && !(d2v > p.radius2);
             const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
@@ -1000,12 +1011,15 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             bop0[t] = (f16x4){ha, la, ha, la};
             bop1[t] = h == 0 ? (f16x4){hb, lb, hb, lb} : (f16x4){one, one, hb, lb};
             // polynomial operand, K = 16 (k_pack_shared_wide): half 0 {1, xh, yh, zh, xxh, xl, yl, zl}, half 1 {xxl, 1, xh, yh, zh, xxh, 0, 0}
+            // (GAUSS: everything times 2^10, the factor phi carries; undone with the frame's scale)
+            constexpr float ps = GAUSS ? (float)(1 << kGaussShift) : 1.f;
+            constexpr unsigned one16 = GAUSS ? 0x6400u : 0x3c00u;         // fp16 1024 / 1
             unsigned xyh, xyl, zxh, zxl;
-            split_pair_f16(x, y, xyh, xyl);
-            split_pair_f16(z, xx, zxh, zxl);
+            split_pair_f16(x * ps, y * ps, xyh, xyl);
+            split_pair_f16(z * ps, xx * ps, zxh, zxl);
             u32x4 pb;
-            if (h == 0) pb = (u32x4){0x3c00u | (xyh << 16), (xyh >> 16) | (zxh << 16), (zxh >> 16) | (xyl << 16), (xyl >> 16) | (zxl << 16)};
-            else pb = (u32x4){(zxl >> 16) | (0x3c00u << 16), xyh, zxh, 0u};
+            if (h == 0) pb = (u32x4){one16 | (xyh << 16), (xyh >> 16) | (zxh << 16), (zxh >> 16) | (xyl << 16), (xyl >> 16) | (zxl << 16)};
+            else pb = (u32x4){(zxl >> 16) | (one16 << 16), xyh, zxh, 0u};
             const f16x8 pbv = __builtin_bit_cast(f16x8, pb);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
@@ -1100,6 +1114,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             u32x4 b0h[TV], b0l[TV], b1h[TV], b1l[TV];
             f32x16 dd[TV];
             auto d2_block = [&](int kb) {
+                if constexpr (GAUSS) return;
                 const f16x4 aop0 = __builtin_bit_cast(f16x4, s_ct[(size_t)kb * 128 + lane]);
                 const f16x4 aop1 = __builtin_bit_cast(f16x4, s_ct[(size_t)kb * 128 + 64 + lane]);
 #pragma unroll
@@ -1108,7 +1123,35 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                     dd[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(aop1, bop1[t], dd[t], 0, 0, 0);
                 }
             };
-            auto phi_half = [&](int s, u32x4 (&xh)[TV], u32x4 (&xl)[TV]) {
+            auto phi_half = [&](int kbsrc, int s, u32x4 (&xh)[TV], u32x4 (&xl)[TV]) {
+                if constexpr (GAUSS) {
+                    // exp(-d2 / R_j^2) from direct coordinate differences (the expanded d2 is not accurate enough under the
+                    // 1 / R^2 the exponent multiplies it by: DESIGN.md 4.1), ONE value per instruction (packed arithmetic
+                    // under in-flight matrix instructions: see k_deform32_tps_shared); this lane's eight centres of the
+                    // half block -- 8 (2 s + q / 2) + 4 h + 2 (q % 2) + {0, 1} -- come from LDS once for both vertex tiles
+                    const float4 *cr = reinterpret_cast<const float4 *>(s_ct + (size_t)kbsrc * 128) + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 c0 = cr[8 * (2 * s + (q >> 1)) + 2 * (q & 1)], c1 = cr[8 * (2 * s + (q >> 1)) + 2 * (q & 1) + 1];
+#pragma unroll
+                        for (int t = 0; t < TV; ++t) {
+                            float ph[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const float4 c = e ? c1 : c0;
+                                const float dx = xn[t] - c.x, dy = yn[t] - c.y, dz = zn[t] - c.z;
+                                float d2 = dx * dx;
+                                d2 = __builtin_fmaf(dy, dy, d2);
+                                d2 = __builtin_fmaf(dz, dz, d2);
+                                ph[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(d2, c.w, (float)kGaussShift));
+                            }
+                            unsigned hh, ll;
+                            split_pair_f16<true>(ph[0], ph[1], hh, ll);
+                            xh[t][q] = hh; xl[t][q] = ll;
+                        }
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int t = 0; t < TV; ++t)
 #pragma unroll
@@ -1132,13 +1175,14 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 }
             };
             d2_block(0);
-            phi_half(0, b0h, b0l);
+            phi_half(0, 0, b0h, b0l);
             for (int kb = 0; kb + 1 < nk; ++kb) {
-                phi_half(1, b1h, b1l);
+                phi_half(kb, 1, b1h, b1l);
                 contract_half(kb, 0, b0h, b0l);
                 d2_block(kb + 1);
-                phi_half(0, b0h, b0l);
+                phi_half(kb + 1, 0, b0h, b0l);
                 contract_half(kb, 1, b1h, b1l);
+                if constexpr (GAUSS) continue;       // the Gaussian block is left to the scheduler's own order
                 // issue order: 18 matrix instructions of K step 0 with the 16 logarithms of this block's step 1 operands,
                 // the four d2 instructions, 18 of K step 1 with the next block's 16 (two instructions after the d2)
               if constexpr (AHEAD) {
@@ -1190,7 +1234,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 }
               }
             }
-            phi_half(1, b1h, b1l);
+            phi_half(nk - 1, 1, b1h, b1l);
             contract_half(nk - 1, 0, b0h, b0l);
             contract_half(nk - 1, 1, b1h, b1l);
           } else {
@@ -1381,7 +1425,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (a.mode != 2) {
         if (wide)
             hipLaunchKernelGGL(k_pack_shared_wide, dim3(nkb, 3), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, (uint4 *)a.wtiles,
-                               (SharedFrame *)a.frames, a.ctiles);
+                               (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
         else
             hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
                                (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
@@ -1459,7 +1503,15 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         }                                                                                                            \
         hipLaunchKernelGGL((k_deform32_tps_shared_wide<V>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
     }
-    if (wide) {
+    if (wide && gauss) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_deform32_tps_shared_wide<1, true>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups);
+    } else if (wide) {
         const char *ev = getenv("FD_SHARED_WIDE_VAR");
         const int var = ev ? atoi(ev) : kWideDefaultVar;
         if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else if (var == 9) FD_WIDE_CASE(9) else FD_WIDE_CASE(0)
