@@ -158,11 +158,16 @@ __global__ void k_qnn_cap(const BatchSlot *tab, int M, double z)
 // A workgroup fills a (16 TS) x (16 TS) tile, 16 x 16 elements at a time (consecutive threads
 // walk a column: coalesced), and contributes ONE atomicMax to max|A|: with a 16 x 16 tile per
 // workgroup the 67 600 same-address atomics of an order-2080 system took 0.7 ms by themselves.
+// sym: the block is symmetric bit for bit (a kernel without per-column radii, no polynomial columns: (c_i - c_j)^2 and
+// (c_j - c_i)^2 are the same doubles), so the tiles above the diagonal are not computed -- the tile across the diagonal
+// stores them too.  Half the fp64 logarithms of a thin-plate build.
 template <int TS>
 __global__ __launch_bounds__(256) void k_assemble(const BatchSlot *tab, int M,
                                                    int n, int npad, int lda, int kind, int T,
-                                                   double lambda, int radii_off)
+                                                   double lambda, int radii_off, int sym)
 {
+    if (sym && blockIdx.x > blockIdx.y) return;
+    const bool mirror = sym && blockIdx.x < blockIdx.y;
     const double *centres = tab[blockIdx.z].centres, *radii = tab[blockIdx.z].radii + radii_off;
     double *A = tab[blockIdx.z].A;
     DevModel *model = tab[blockIdx.z].model;
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(256) void k_assemble(const BatchSlot *tab, int M,
                 v = (i == j) ? 1.0 : 0.0;           // identity padding
             }
             A[(size_t)j * lda + i] = v;
+            if (mirror) A[(size_t)i * lda + j] = v;
             if (real) m = fmax(m, fabs(v));
         }
     }
@@ -914,14 +920,17 @@ hipError_t launch_backsub_rows(const BuildBuffers &b, hipStream_t stream, int ro
 hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int npad_a, int radii_off)
 {
     const unsigned nb = (unsigned)b.nbatch;
+    // kernels without per-column radii give a block that is symmetric bit for bit: half of it is computed
+    static const bool no_sym = getenv("FD_ASSEMBLE_FULL") != nullptr;
+    const int sym = (!no_sym && b.kind != FD_KERNEL_GAUSSIAN && b.kind != FD_KERNEL_GAUSSIAN_QNN && b.kind != FD_KERNEL_GAUSSIAN_ML) ? 1 : 0;
     if (npad_a <= 512) {
         const unsigned g = (unsigned)(npad_a + 31) / 32;
         hipLaunchKernelGGL((k_assemble<2>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, b.M, b.M, npad_a,
-                           b.lda, b.kind, 0, b.lambda, radii_off);
+                           b.lda, b.kind, 0, b.lambda, radii_off, sym);
     } else {
         const unsigned g = (unsigned)(npad_a + 63) / 64;
         hipLaunchKernelGGL((k_assemble<4>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, b.M, b.M, npad_a,
-                           b.lda, b.kind, 0, b.lambda, radii_off);
+                           b.lda, b.kind, 0, b.lambda, radii_off, sym);
     }
     return hipGetLastError();
 }
@@ -1003,11 +1012,11 @@ hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev
     if (b.npad <= 512) {
         const unsigned g = (unsigned)(b.npad + 31) / 32;
         hipLaunchKernelGGL((k_assemble<2>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
-                           b.lda, b.kind, b.T, b.lambda, 0);
+                           b.lda, b.kind, b.T, b.lambda, 0, 0);
     } else {
         const unsigned g = (unsigned)(b.npad + 63) / 64;
         hipLaunchKernelGGL((k_assemble<4>), dim3(g, g, nb), dim3(256), 0, stream, b.d_slots, M, b.n, b.npad,
-                           b.lda, b.kind, b.T, b.lambda, 0);
+                           b.lda, b.kind, b.T, b.lambda, 0, 0);
     }
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     hipError_t e = launch_lu_factor_solve(b, stream);
