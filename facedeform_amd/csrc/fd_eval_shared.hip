@@ -860,8 +860,13 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 #define FD_WIDE_VPM 3            // vector instructions placed after each matrix instruction of the K loop
 #endif
 
-// VAR (A/B inside one process, FD_SHARED_WIDE_VAR): bit 0 = two operand buffers in turn instead of 32 register copies per
-// block, bit 1 = the plain issue pattern (one matrix instruction, one logarithm, vector work) instead of the staged one
+// VAR (build variants kept for A/B runs inside one process: FD_SHARED_WIDE_VAR, tests/tools/wide_variants_timing.py):
+//   bit 0  the K loop skewed by half a block, operands written straight into dead registers (clear: phi of block k + 1 under
+//          the whole contraction of block k, 32 register copies per block)
+//   bit 1  fixed shares of the units per wave (clear: the counter in LDS)
+//   bit 2  LDS reads of the weights one (component, K step) pair ahead of their use (skewed loop only)
+//   bit 3  the last, partial round dealt out as whole groups (clear: as single units)
+// Instantiated: 0, 1 (the default), 2, 3, 5, 9; the Gaussian kinds: 1.
 template <int VAR, bool GAUSS = false>
 __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
@@ -869,7 +874,6 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     constexpr bool SKEWED = (VAR & 1) != 0;
     static_assert(!GAUSS || SKEWED, "the Gaussian kinds take the skewed loop only");
     constexpr bool AHEAD = (VAR & 4) != 0;
-    constexpr bool STAGED = true;
     constexpr int TV = 2;                        // vertex tiles (of 32) per wave
     constexpr int kSlots = kWideSlots;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1089,7 +1093,6 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             // contraction to cover their latency, then one logarithm and FD_WIDE_VPM vector instructions under each
             // matrix instruction; the weights of a (component, K step) pair are read from LDS one pair ahead
             auto interleave = [&]() {
-              if constexpr (STAGED) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // d2 operands, weights of the first pair
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1103,19 +1106,6 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                     if (q >= 2 && q < 34) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
                 }
-              } else {
-#pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);      // transcendental
-                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);      // VALU
-                }
-#pragma unroll
-                for (int q = 32; q < 4 + 36; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
-                }
-              }
             };
           if constexpr (SKEWED) {
             // Pipeline skewed by HALF a block, no operand copies: the d2 of block kb + 1 is issued in the middle of
