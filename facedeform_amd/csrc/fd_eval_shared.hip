@@ -245,6 +245,16 @@ __device__ __forceinline__ void store_pos3(Pos3 FD_GLOBAL *dst, float x, float y
     dst->x = x; dst->y = y; dst->z = z;      // member-wise: a struct assignment through an address-space pointer does not compile on the host pass
 }
 
+// the same with the non-temporal hint: the 512 MB a launch writes need not displace what else lives in L2
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef f32x3 f32x3_a4 __attribute__((aligned(4)));
+typedef f32x4 f32x4_a16 __attribute__((aligned(16)));
+typedef f32x2 f32x2_a8 __attribute__((aligned(8)));
+__device__ __forceinline__ void store_pos3_nt(Pos3 FD_GLOBAL *dst, float x, float y, float z)
+{
+    __builtin_nontemporal_store((f32x3){x, y, z}, (f32x3_a4 FD_GLOBAL *)dst);
+}
+
 template <int NT, bool DENSE, bool GAUSS>
 __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_deform32_tps_shared(const SharedParams p, int ngroups)
@@ -628,9 +638,10 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
                     const uint64_t fb = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs1 + 7) / 64], (8 * fs1 + 7) % 64) << 32) |
                                         (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs1 + 6) / 64], (8 * fs1 + 6) % 64);
                     const uint64_t fo = (lane < 32 ? fa : fb) + 4ull * (uint64_t)vbase;
-                    *(f32x2 FD_GLOBAL *)((char FD_GLOBAL *)fo + off8) = ones;
+                    __builtin_nontemporal_store(ones, (f32x2_a8 FD_GLOBAL *)((char FD_GLOBAL *)fo + off8));
                 }
-                store_pos3(dstP, __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]), __builtin_fmaf(d2c, inv, pos[2]));
+                // (non-temporal, like everything this launch writes: see the 32-row kernel)
+                store_pos3_nt(dstP, __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]), __builtin_fmaf(d2c, inv, pos[2]));
             }
             settle(nxt);
             FD_SSTAMP(3)
@@ -708,8 +719,8 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
                 }
-                if (fout) *(float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4) = fall;
-                store_pos3(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+                if (fout) __builtin_nontemporal_store(fall, (float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4));
+                store_pos3_nt(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
             }
         }
         FD_SSTAMP(3)
@@ -746,7 +757,7 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr bool shared_wide(int nF, int kind) { (void)kind; return nF > 16; }      // thin-plate and the Gaussian kinds alike
 constexpr int kWideSlots = 32;                      // frame records
-constexpr int kWideDefaultVar = 1;      // skewed K loop, units from the counter: the fastest inside bench.py (tests/tools/wide_variants_timing.py for the others)
+constexpr int kWideDefaultVar = 17;      // skewed K loop, units from the counter, non-temporal stores: the fastest inside bench.py (tests/tools/wide_variants_timing.py for the others)
 constexpr int kWideW16 = 3 * 2 * 2 * 64;            // 16-byte words of weight tiles per K block: [component][K step][hi, lo][lane]
 
 // grid (nkb, 3 components), 256 threads.  Output regions as in k_pack_shared with nT = 6: weight tiles, 6 x 64 words of
@@ -866,7 +877,8 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 //   bit 1  fixed shares of the units per wave (clear: the counter in LDS)
 //   bit 2  LDS reads of the weights one (component, K step) pair ahead of their use (skewed loop only)
 //   bit 3  the last, partial round dealt out as whole groups (clear: as single units)
-// Instantiated: 0, 1 (the default), 2, 3, 5, 9; the Gaussian kinds: 1.
+//   bit 4  the straight-line epilogue's stores with the non-temporal hint
+// Instantiated: 0, 1, 2, 3, 5, 9, 17 (the default); the Gaussian kinds: 17.
 template <int VAR, bool GAUSS = false>
 __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
@@ -874,6 +886,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     constexpr bool SKEWED = (VAR & 1) != 0;
     static_assert(!GAUSS || SKEWED, "the Gaussian kinds take the skewed loop only");
     constexpr bool AHEAD = (VAR & 4) != 0;
+    constexpr bool NONTEMPORAL = (VAR & 16) != 0;
     constexpr int TV = 2;                        // vertex tiles (of 32) per wave
     constexpr int kSlots = kWideSlots;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1289,9 +1302,15 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                                       (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 4) / 64], (8 * fs + 4) % 64);
                 const int t = (fs % 8) / 4, r = 4 * (fs / 8) + fs % 4;
                 const float d0 = acc[0][t][r], d1 = acc[1][t][r], d2c = acc[2][t][r];
-                if (fs % 4 == 0) *(f32x4 FD_GLOBAL *)(s_ftab[(fs / 4) * 64 + lane] + fbase) = ones;
-                store_pos3((Pos3 FD_GLOBAL *)((char FD_GLOBAL *)pout + voff), __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]),
-                           __builtin_fmaf(d2c, inv, pos[2]));
+                if constexpr (NONTEMPORAL) {
+                    if (fs % 4 == 0) __builtin_nontemporal_store(ones, (f32x4_a16 FD_GLOBAL *)(s_ftab[(fs / 4) * 64 + lane] + fbase));
+                    store_pos3_nt((Pos3 FD_GLOBAL *)((char FD_GLOBAL *)pout + voff), __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]),
+                                  __builtin_fmaf(d2c, inv, pos[2]));
+                } else {
+                    if (fs % 4 == 0) *(f32x4 FD_GLOBAL *)(s_ftab[(fs / 4) * 64 + lane] + fbase) = ones;
+                    store_pos3((Pos3 FD_GLOBAL *)((char FD_GLOBAL *)pout + voff), __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]),
+                               __builtin_fmaf(d2c, inv, pos[2]));
+                }
             }
             settle(nxt);
             FD_SSTAMP(3)
@@ -1359,8 +1378,8 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
             }
-            if (fout) *(float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4) = fall;
-            store_pos3(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+            if (fout) __builtin_nontemporal_store(fall, (float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4));
+            store_pos3_nt(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
         }
         FD_SSTAMP(3)
     };
@@ -1506,15 +1525,15 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (wide && gauss) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide<17, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_deform32_tps_shared_wide<1, true>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups);
+        hipLaunchKernelGGL((k_deform32_tps_shared_wide<17, true>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups);
     } else if (wide) {
         const char *ev = getenv("FD_SHARED_WIDE_VAR");
         const int var = ev ? atoi(ev) : kWideDefaultVar;
-        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else if (var == 9) FD_WIDE_CASE(9) else FD_WIDE_CASE(0)
+        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else if (var == 9) FD_WIDE_CASE(9) else if (var == 17) FD_WIDE_CASE(17) else FD_WIDE_CASE(0)
     } else if (dense) {
         if (nT == 3) FD_SHARED_KIND(3, true)
         else if (nT == 6) FD_SHARED_KIND(6, true)
