@@ -757,7 +757,7 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr bool shared_wide(int nF, int kind) { (void)kind; return nF > 16; }      // thin-plate and the Gaussian kinds alike
 constexpr int kWideSlots = 32;                      // frame records
-constexpr int kWideDefaultVar = 17;      // skewed K loop, units from the counter, non-temporal stores: the fastest inside bench.py (tests/tools/wide_variants_timing.py for the others)
+constexpr int kWideDefaultVar = 49;      // skewed K loop, units from the counter, non-temporal stores and loads: the fastest inside bench.py (tests/tools/wide_variants_timing.py for the others)
 constexpr int kWideW16 = 3 * 2 * 2 * 64;            // 16-byte words of weight tiles per K block: [component][K step][hi, lo][lane]
 
 // grid (nkb, 3 components), 256 threads.  Output regions as in k_pack_shared with nT = 6: weight tiles, 6 x 64 words of
@@ -878,7 +878,8 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 //   bit 2  LDS reads of the weights one (component, K step) pair ahead of their use (skewed loop only)
 //   bit 3  the last, partial round dealt out as whole groups (clear: as single units)
 //   bit 4  the straight-line epilogue's stores with the non-temporal hint
-// Instantiated: 0, 1, 2, 3, 5, 9, 17 (the default); the Gaussian kinds: 17.
+//   bit 5  the positions read with the non-temporal hint
+// Instantiated: 0, 1, 2, 3, 5, 9, 17, 49 (the default); the Gaussian kinds: 49.
 template <int VAR, bool GAUSS = false>
 __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
@@ -999,7 +1000,12 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         for (int t = 0; t < TV; ++t) {
             const int64_t vi = vb + 32 * t + j;
             const int64_t vc = vi < p.N ? vi : p.N - 1;
-            r.p[t][0] = p.P_in[3 * vc]; r.p[t][1] = p.P_in[3 * vc + 1]; r.p[t][2] = p.P_in[3 * vc + 2];
+            if constexpr ((VAR & 32) != 0) {        // read once per launch: streamed past L2 like the outputs
+                r.p[t][0] = __builtin_nontemporal_load(&p.P_in[3 * vc]); r.p[t][1] = __builtin_nontemporal_load(&p.P_in[3 * vc + 1]);
+                r.p[t][2] = __builtin_nontemporal_load(&p.P_in[3 * vc + 2]);
+            } else {
+                r.p[t][0] = p.P_in[3 * vc]; r.p[t][1] = p.P_in[3 * vc + 1]; r.p[t][2] = p.P_in[3 * vc + 2];
+            }
             if constexpr (FAST) r.d2[t] = 0.f; else r.d2[t] = p.dist2 ? p.dist2[vc] : 0.f;
         }
         return r;
@@ -1525,15 +1531,15 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (wide && gauss) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide<17, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide<49, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_deform32_tps_shared_wide<17, true>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups);
+        hipLaunchKernelGGL((k_deform32_tps_shared_wide<49, true>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups);
     } else if (wide) {
         const char *ev = getenv("FD_SHARED_WIDE_VAR");
         const int var = ev ? atoi(ev) : kWideDefaultVar;
-        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else if (var == 9) FD_WIDE_CASE(9) else if (var == 17) FD_WIDE_CASE(17) else FD_WIDE_CASE(0)
+        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else if (var == 9) FD_WIDE_CASE(9) else if (var == 17) FD_WIDE_CASE(17) else if (var == 49) FD_WIDE_CASE(49) else FD_WIDE_CASE(0)
     } else if (dense) {
         if (nT == 3) FD_SHARED_KIND(3, true)
         else if (nT == 6) FD_SHARED_KIND(6, true)

@@ -401,7 +401,7 @@ def test_shared_launch_at_the_edges_of_its_vertex_groups(hip_lib, oracle, kind, 
         e.close()
 
 
-@pytest.mark.parametrize("wide,var", [("1", "0"), ("1", "1"), ("1", "2"), ("1", "3"), ("0", "0")])
+@pytest.mark.parametrize("wide,var", [("1", "0"), ("1", "1"), ("1", "2"), ("1", "3"), ("1", "5"), ("1", "9"), ("1", "17"), ("1", "49"), ("0", "0")])
 def test_every_form_of_the_32_frame_launch_matches_the_oracle(hip_lib, oracle, monkeypatch, wide, var):
     """17..32 thin-plate frames take the 32-row tiles (k_deform32_tps_shared_wide); its build variants and the 16-row
     kernel stay selectable per launch (FD_SHARED_WIDE, FD_SHARED_WIDE_VAR) for A/B runs -- each held to the oracle, on the

@@ -26,7 +26,7 @@ python3 tests/tools/shared_eval_timing.py c2 8,16,24,32 > $OUT/shared_timing_c2.
 python3 tests/tools/shared_eval_timing.py c3 32 >> $OUT/shared_timing_c2.txt 2>&1
 python3 tests/tools/shared_eval_timing.py c2 8,32 qnn >> $OUT/shared_timing_c2.txt 2>&1
 python3 tests/tools/hbm_write_rate.py > $OUT/hbm_write_rate.txt 2>&1
-python3 tests/tools/wide_variants_timing.py 0,1,2,3,16 6 > $OUT/wide_variants.txt 2>&1
+python3 tests/tools/wide_variants_timing.py 0,1,17,49,16 6 > $OUT/wide_variants.txt 2>&1
 [ -x tools/ubench_mfma16 ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_mfma16.hip -o tools/ubench_mfma16
 tools/ubench_mfma16 > $OUT/ubench_mfma16.txt 2>&1
 python3 tools/build_latency.py 256,512,2048 11 > $OUT/solver_latency.txt 2>&1
