@@ -172,12 +172,12 @@ __global__ __launch_bounds__(256) void k_assemble(const BatchSlot *tab, int M,
     double *A = tab[blockIdx.z].A;
     DevModel *model = tab[blockIdx.z].model;
     __shared__ double s_max[4];
+    __shared__ double s_t[16][17];       // a 16 x 16 piece on its way to the other side of the diagonal
     double m = 0.0;                      // max |A_ij| over the real system, for the singularity threshold
     bool dup = false;
 #pragma unroll
     for (int tj = 0; tj < TS; ++tj) {
         const int j = (blockIdx.y * TS + tj) * 16 + (threadIdx.x >> 4);
-        if (j >= npad) continue;
         double cjx = 0.0, cjy = 0.0, cjz = 0.0, inv_r2 = 1.0;
         if (j < M) {
             cjx = centres[3 * j]; cjy = centres[3 * j + 1]; cjz = centres[3 * j + 2];
@@ -187,31 +187,40 @@ __global__ __launch_bounds__(256) void k_assemble(const BatchSlot *tab, int M,
 #pragma unroll
         for (int ti = 0; ti < TS; ++ti) {
             const int i = (blockIdx.x * TS + ti) * 16 + (threadIdx.x & 15);
-            if (i >= npad) continue;
             double v = 0.0;
-            bool real = false;
-            if (i < M && j < M) {
-                const double dx = centres[3 * i] - cjx;
-                const double dy = centres[3 * i + 1] - cjy;
-                const double dz = centres[3 * i + 2] - cjz;
-                const double d2 = dx * dx + dy * dy + dz * dz;
-                v = phi_d(kind, d2, inv_r2);
-                if (i == j) v += lambda;
-                else if (d2 == 0.0) dup = true;     // coincident centres -> -5
-                real = true;
-            } else if (i < n && j < n) {
-                // polynomial block: column M is 1, columns M+1..M+3 are x, y, z
-                const int row = i < M ? i : j;      // the centre index
-                const int col = (i < M ? j : i) - M;
-                if (i < M || j < M) v = col == 0 ? 1.0 : centres[3 * row + col - 1];
-                real = true;
-                (void)T;
-            } else {
-                v = (i == j) ? 1.0 : 0.0;           // identity padding
+            if (i < npad && j < npad) {
+                bool real = false;
+                if (i < M && j < M) {
+                    const double dx = centres[3 * i] - cjx;
+                    const double dy = centres[3 * i + 1] - cjy;
+                    const double dz = centres[3 * i + 2] - cjz;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    v = phi_d(kind, d2, inv_r2);
+                    if (i == j) v += lambda;
+                    else if (d2 == 0.0) dup = true;     // coincident centres -> -5
+                    real = true;
+                } else if (i < n && j < n) {
+                    // polynomial block: column M is 1, columns M+1..M+3 are x, y, z
+                    const int row = i < M ? i : j;      // the centre index
+                    const int col = (i < M ? j : i) - M;
+                    if (i < M || j < M) v = col == 0 ? 1.0 : centres[3 * row + col - 1];
+                    real = true;
+                    (void)T;
+                } else {
+                    v = (i == j) ? 1.0 : 0.0;           // identity padding
+                }
+                A[(size_t)j * lda + i] = v;
+                if (real) m = fmax(m, fabs(v));
             }
-            A[(size_t)j * lda + i] = v;
-            if (mirror) A[(size_t)i * lda + j] = v;
-            if (real) m = fmax(m, fabs(v));
+            if (mirror) {
+                // the piece across the diagonal, through LDS so that consecutive threads again write consecutive addresses
+                // (straight from the registers it was sixteen 32-byte pieces per wave: slower than computing the half anew)
+                __syncthreads();
+                s_t[threadIdx.x >> 4][threadIdx.x & 15] = v;
+                __syncthreads();
+                const int ii = (blockIdx.x * TS + ti) * 16 + (threadIdx.x >> 4), jj = (blockIdx.y * TS + tj) * 16 + (threadIdx.x & 15);
+                if (ii < npad && jj < npad) A[(size_t)ii * lda + jj] = s_t[threadIdx.x & 15][threadIdx.x >> 4];
+            }
         }
     }
     if (dup) model->dup_flag = 1;
