@@ -1475,7 +1475,8 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         static const bool no_fast = getenv("FD_SHARED_NO_FAST") != nullptr;       // A/B: general epilogue everywhere
         bool fast = !no_fast && (p.dbg & 1) == 0 && a.dist2 == nullptr && a.tu == nullptr && a.radius2 > 0.f && a.falloff_out != nullptr &&
                     a.nF == shared_slots(nT, dense) && a.N < ((int64_t)1 << 28);
-        for (int f = 0; fast && f < a.nF; ++f) fast = a.falloff_out[f] != nullptr && a.P_out[f] != nullptr;
+        // (the straight-line epilogues store fd_falloff 8 and 16 bytes at a time: 16-byte aligned arrays, or the general path)
+        for (int f = 0; fast && f < a.nF; ++f) fast = a.falloff_out[f] != nullptr && a.P_out[f] != nullptr && ((uintptr_t)a.falloff_out[f] & 15) == 0;
         p.fast = fast ? 1 : 0;
     }
     { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }

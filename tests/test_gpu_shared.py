@@ -430,3 +430,24 @@ def test_every_form_of_the_32_frame_launch_matches_the_oracle(hip_lib, oracle, m
             assert np.array_equal(out[gated], P[gated])
             assert np.allclose(falls[f].cpu().numpy()[~gated], ref_fall[~gated], rtol=2e-6, atol=1e-7)
     _close(engines, batch)
+
+
+def test_fall_off_arrays_that_are_not_16_byte_aligned_take_the_general_epilogue(hip_lib, oracle):
+    """The straight-line epilogues write fd_falloff in 8- and 16-byte pieces; an array that starts on an odd float (a view
+    into a larger buffer) must still come out right -- the launch falls back to the general epilogue for it."""
+    M, N, F = 128, 3 * 512, 32
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F)
+    outs = [torch.empty_like(d_P) for _ in range(F)]
+    big = torch.full((F, N + 8), 7.0, device=dev)
+    falls = [big[f, 1:N + 1] for f in range(F)]            # 4 bytes past a 16-byte boundary
+    assert all(f.data_ptr() % 16 == 4 for f in falls)
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], d_falloff=[f.data_ptr() for f in falls])
+    torch.cuda.synchronize()
+    for f in (0, 13, 31):
+        table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
+        rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+        ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+        assert parity_ratio(outs[f].cpu().numpy(), ref, P, TOL) <= 1.0, f
+        assert np.allclose(falls[f].cpu().numpy(), ref_fall, rtol=2e-6, atol=1e-7)
+        assert float(big[f, 0]) == 7.0 and float(big[f, N + 1]) == 7.0      # nothing written outside the view
+    _close(engines, batch)
