@@ -328,7 +328,10 @@ int fd_batch_deform_dev(fd_batch *batch, void *hip_stream, int64_t N, const floa
  * (FD_KERNEL_GAUSSIAN, FD_KERNEL_GAUSSIAN_QNN -- the SOP's default model: exp(-d2 / R_j^2) from direct
  * coordinate differences, formed once for all frames), fp32 evaluation, 32 or more centres -- anything else
  * (biharmonic, cubic, the multilayer model, fp64) takes fd_batch_deform_dev on the shared arrays.  Parity
- * with the oracle as for fd_deform (1e-5); NOT bit-identical to the one-frame kernels. */
+ * with the oracle as for fd_deform (1e-5); NOT bit-identical to the one-frame kernels.
+ * Fastest form: 32 frames (17..32 take 32-row output tiles), no d_dist2, no tangent frames, every d_falloff_out
+ * given and 16-byte aligned (results are the same without, through a slower epilogue).  Outputs are written with
+ * the non-temporal hint: they are not expected in L2 by whatever runs next. */
 int fd_batch_deform_shared_dev(fd_batch *batch, void *hip_stream, int64_t N, const float *d_P_in,
                                float *const *d_P_out, const float *d_dist2, float *const *d_falloff_out,
                                const float *d_tu, const float *d_tv, const float *d_nrm, float radius2,
