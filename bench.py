@@ -175,6 +175,7 @@ def run_split_mesh(args, torch, dist, capi, synth, rank, world, local_rank, dev,
             e.set_points_dev(d_rest.data_ptr(), d_deltas.data_ptr(), n_ctrl)
             engines.append(e)
         batch = capi.Batch(engines)
+        batch.set_eval_cus(args.eval_cus)
         batch.build_async(stream.cuda_stream); batch.build_result()
         nbytes = engines[0].model_bytes()
         lanes.append({"stream": stream, "engines": engines, "batch": batch,
@@ -426,8 +427,6 @@ def main():
         self_launch(args)
     if args.eval_cus <= 0:
         args.eval_cus = 192 if (args.build == "one-workgroup" and args.config == "c2") else 224
-    if 0 < args.eval_cus < 256:
-        os.environ["FD_SHARED_CUS"] = str(args.eval_cus)       # read once by the library at its first shared launch
     import torch
     import torch.distributed as dist
     from facedeform_amd import capi, synth
@@ -499,7 +498,9 @@ def main():
             eng.set_kernel(capi.KERNEL_THIN_PLATE)
             eng.set_term(capi.TERM_LINEAR)
             engines.append(eng)
-        lanes.append({"engines": engines, "stream": stream, "batches": {B: capi.Batch(engines)},
+        lane_batch = capi.Batch(engines)
+        lane_batch.set_eval_cus(args.eval_cus)       # CU budget of the shared-rig evaluation, per batch (fd_batch_set_eval_cus)
+        lanes.append({"engines": engines, "stream": stream, "batches": {B: lane_batch},
                       "evals_done": torch.cuda.Event(), "built": torch.cuda.Event(),
                       "out": [torch.empty_like(d_P) for _ in range(B)],
                       "fall": [torch.zeros(n_verts, device=dev, dtype=torch.float32) for _ in range(B)]})
@@ -517,6 +518,7 @@ def main():
         stream = ln["stream"]
         if count not in ln["batches"]:
             ln["batches"][count] = capi.Batch(ln["engines"][:count])
+            ln["batches"][count].set_eval_cus(args.eval_cus)
         batch = ln["batches"][count]
         frames = [((first + k) * world + rank) % N_FRAMES for k in range(count)]
         # The lane's previous group must be done with its models before they are overwritten.  The shared-rig

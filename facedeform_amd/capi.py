@@ -62,7 +62,7 @@ EXPORTS = [
     "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
     "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
     "fd_morph_get_qr",
-    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error", "fd_batch_wait_consumed", "fd_batch_prepare_shared",
+    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error", "fd_batch_wait_consumed", "fd_batch_prepare_shared", "fd_batch_set_eval_cus",
     "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result", "fd_batch_deform_dev",
     "fd_batch_deform_shared_dev",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
@@ -145,6 +145,7 @@ def load() -> C.CDLL:
     L.fd_batch_size.argtypes = [vp]; L.fd_batch_size.restype = i32
     L.fd_batch_wait_consumed.argtypes = [vp, vp]; L.fd_batch_wait_consumed.restype = i32
     L.fd_batch_prepare_shared.argtypes = [vp, vp, vp, vp]; L.fd_batch_prepare_shared.restype = i32
+    L.fd_batch_set_eval_cus.argtypes = [vp, i32]; L.fd_batch_set_eval_cus.restype = i32
     L.fd_batch_last_error.argtypes = [vp]; L.fd_batch_last_error.restype = C.c_char_p
     L.fd_batch_set_points_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32]
     L.fd_batch_set_points_dev.restype = i32
@@ -508,6 +509,10 @@ class Batch:
         outs = (vp * n)(*d_P_out)
         falls = None if d_falloff is None else (vp * n)(*[p or None for p in d_falloff])
         self._check(self.L.fd_batch_prepare_shared(self.h, vp(stream_ptr or 0), outs, falls))
+
+    def set_eval_cus(self, n_cus: int):
+        """fd_batch_set_eval_cus: CUs this batch's shared-rig evaluation launches may occupy (0: all)."""
+        self._check(self.L.fd_batch_set_eval_cus(self.h, int(n_cus)))
 
     def wait_consumed(self, stream_ptr=None):
         """fd_batch_wait_consumed: `stream_ptr` waits until the last shared-rig evaluation has its own copy of

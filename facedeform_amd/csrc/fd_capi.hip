@@ -134,6 +134,12 @@ struct fd_batch {
         hipEvent_t eval_ev = nullptr;    // behind the last evaluation that read it
         bool eval_pending = false;
     } sets[2];
+    // "One rest rig" is decided on the host by the address the rest points were read from; an address does not identify
+    // its contents (the array may have been rewritten, or freed and allocated again, between the set-ups of two contexts:
+    // ADVICE r2), so the pack kernel compares every context's centres with context 0's ON THE DEVICE, passes a frame that
+    // differs through like a failed build and posts 1 + its index here (page-locked); the next call on the batch reports it.
+    int *h_mismatch = nullptr;
+    int eval_cus = 0;                    // fd_batch_set_eval_cus: CUs a shared-rig evaluation may occupy (0: all)
     int cur_set = 0;                     // the set packed last
     bool packed_valid = false;           // sets[cur_set].packed_ev is recorded (fd_batch_wait_consumed)
     bool prepared = false;               // sets[cur_set] holds the contexts' CURRENT models and prep_* outputs
@@ -643,7 +649,8 @@ int fd_build_async(fd_ctx *ctx)
         if (ctx->use_graph && ctx->resolve_exec) FD_HIP(ctx, hipGraphLaunch(ctx->resolve_exec, st));
         else FD_HIP(ctx, launch_resolve(b, st, nullptr));
         FD_HIP(ctx, hipEventRecord(ctx->ev1, st));
-        ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
+        // a later evaluation on ANOTHER stream (fd_deform_dev_stream, fd_batch_deform*) is ordered behind this build
+        ctx->wait_event = ctx->ev1; ctx->wait_stream = st; ctx->wait_batch = nullptr;
         ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
         ctx->last_spd = b.spd != 0;
         ctx->build_pending = true;
@@ -695,7 +702,10 @@ int fd_build_async(fd_ctx *ctx)
         FD_HIP(ctx, launch_build(b, cur_stream(ctx), ctx->ev_mid));
     }
     FD_HIP(ctx, hipEventRecord(ctx->ev1, cur_stream(ctx)));
-    ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
+    // A later evaluation on ANOTHER stream is ordered behind this build (order_after_batch): a single build as much as
+    // a batched one, and in particular the LU rebuild that poll_status enqueues here when the Cholesky lost definiteness --
+    // the evaluation that triggered the repair may launch on a stream that knows nothing of this one.
+    ctx->wait_event = ctx->ev1; ctx->wait_stream = cur_stream(ctx); ctx->wait_batch = nullptr;
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
     ctx->have_factor = b.ml_layers == 0;     // the multilayer model keeps no single factorisation to reuse
     ctx->last_spd = b.spd != 0;
@@ -792,7 +802,7 @@ static int poll_status(fd_ctx *ctx)
         // its buffers on streams this context knows nothing about
         if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
         ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
-        return fd_build_async(ctx);
+        return fd_build_async(ctx);       // leaves wait_event = the rebuild's end on cur_stream(ctx): callers order their stream behind it
     }
     ctx->sticky_rc = tt == -5 ? FD_E_DUPLICATE : FD_E_SINGULAR;
     set_err(ctx, tt == -5 ? "the model's build failed: coincident control points" : "the model's build failed: singular system");
@@ -1270,7 +1280,8 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     BuildBuffers b;
     fill_build_buffers(ctx, b);
     FD_HIP(ctx, launch_pack_from_weights(b, cur_stream(ctx), ctx->imported_layers));
-    ctx->wait_event = nullptr; ctx->wait_stream = nullptr; ctx->wait_batch = nullptr;
+    FD_HIP(ctx, hipEventRecord(ctx->ev1, cur_stream(ctx)));
+    ctx->wait_event = ctx->ev1; ctx->wait_stream = cur_stream(ctx); ctx->wait_batch = nullptr;      // evaluations on other streams wait for the pack
     if (!on_device) FD_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     ctx->have_factor = false;
     ctx->deltas_only = false;
@@ -1321,6 +1332,8 @@ fd_batch *fd_batch_create(fd_ctx *const *ctxs, int n)
     ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev_mid) == hipSuccess &&
          hipEventCreate(&b->ev1) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&b->status_ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&b->h_mismatch, sizeof(int), hipHostMallocMapped) == hipSuccess;
+    if (ok) *b->h_mismatch = 0;
     if (!ok) {
         set_err(nullptr, "fd_batch_create: device resource allocation failed: %s", hipGetErrorString(hipGetLastError()));
         fd_batch_destroy(b);
@@ -1355,6 +1368,7 @@ void fd_batch_destroy(fd_batch *b)
         if (st.eval_ev) (void)hipEventDestroy(st.eval_ev);
     }
     if (b->fallback_ev) (void)hipEventDestroy(b->fallback_ev);
+    if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -1368,6 +1382,7 @@ int fd_batch_set_points_dev(fd_batch *b, const float *const *d_rest_xyz, const f
     if (!b || !d_rest_xyz || !d_delta_xyz) return FD_E_INVALID;
     if (M <= 0 || M + 4 > kMaxOrder) { batch_err(b, "fd_batch_set_points_dev: M = %d outside 1..%d", M, kMaxOrder - 4); return FD_E_INVALID; }
     b->prepared = false;
+    if (b->h_mismatch) *b->h_mismatch = 0;
     for (int i = 0; i < b->n; ++i)
         if (!d_rest_xyz[i] || !d_delta_xyz[i]) { batch_err(b, "fd_batch_set_points_dev: null array for context %d", i); return FD_E_INVALID; }
     for (int i = 0; i < b->n; ++i) {
@@ -1519,6 +1534,11 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
 // the statuses a batched build posted: one event query while they are in flight, then every context on its own
 static int batch_poll(fd_batch *b)
 {
+    if (b->h_mismatch && *b->h_mismatch != 0) {
+        batch_err(b, "shared-rig evaluation: context %d was built on other rest points than context 0 (same address, other "
+                     "contents); its frame was passed through", *b->h_mismatch - 1);
+        return FD_E_INVALID;
+    }
     bool any = false;
     for (int i = 0; i < b->n; ++i) any = any || b->ctxs[i]->status_inflight || b->ctxs[i]->sticky_rc != FD_OK;
     if (!any) return FD_OK;
@@ -1584,9 +1604,11 @@ int fd_batch_deform_dev(fd_batch *b, void *hip_stream, int64_t N, const float *c
         a.model = c->d_model;
         a.precision = c->eval_precision;
         a.variant = c->eval_variant;
-        if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
     }
+    // statuses first: a model the poll had to rebuild (on its context's stream) is then ordered like any other build
     if ((rc = batch_poll(b))) return rc;
+    for (int i = 0; i < b->n; ++i)
+        if ((rc = order_after_batch(b->ctxs[i], stream))) { batch_err(b, "context %d: %s", i, b->ctxs[i]->err); return rc; }
     hipError_t e = launch_deform_batch(args, b->n, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_batch failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
     return FD_OK;
@@ -1607,7 +1629,8 @@ static int shared_applies(fd_batch *b, const char *who, float *const *d_P_out, i
         if (!d_P_out[i]) { batch_err(b, "%s: NULL output array for context %d", who, i); return FD_E_INVALID; }
         if (!c->built && !c->build_pending) { batch_err(b, "%s: context %d has no built model", who, i); return FD_E_NOT_BUILT; }
         // one rest rig: every context read its rest points in place from the SAME device array
-        if (!c->rest_src || c->rest_src != c0->rest_src || c->M != c0->M || c->kind != c0->kind || c->term != c0->term) {
+        if (!c->rest_src || c->rest_src != c0->rest_src || c->M != c0->M || c->kind != c0->kind ||
+            c->term != c0->term || c->nparams != c0->nparams || memcmp(c->params, c0->params, sizeof(c->params)) != 0) {
             batch_err(b, "%s: the contexts must share one rest rig (fd_batch_set_points_dev with the "
                          "same rest array for all), kernel and term; context %d does not", who, i);
             return FD_E_INVALID;
@@ -1634,12 +1657,12 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
     a.N = 1; a.Mpad = round_up(c0->M, kRecPad); a.nF = b->n; a.kind = ek; a.ctiles = c0->d_tiles16;
     a.falloff_out = d_falloff_out;
     int rc;
+    if ((rc = batch_poll(b))) return rc;           // before the ordering: a repaired model's rebuild is ordered with the rest
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];
-        a.rec32[i] = c->d_rec32; a.model[i] = c->d_model; a.P_out[i] = d_P_out[i];
+        a.rec32[i] = c->d_rec32; a.model[i] = c->d_model; a.P_out[i] = d_P_out[i]; a.centres[i] = c->d_centres;
         if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
     }
-    if ((rc = batch_poll(b))) return rc;
     const size_t wb = shared_wtile_bytes(a.Mpad, a.nF), fb = shared_frame_bytes(a.nF);
     if (wb > st.cap_wtiles || fb > st.cap_frames) {
         // (hipFree drains the device: no launch still reads the old scratch)
@@ -1662,6 +1685,8 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
     a.wtiles = st.d_wtiles; a.frames = st.d_frames;
     a.packed_ev = make_event(&st.packed_ev) ? st.packed_ev : nullptr;
     a.mode = 1;
+    a.M = c0->M;
+    if (b->h_mismatch && hipHostGetDevicePointer((void **)&a.mismatch, b->h_mismatch, 0) != hipSuccess) { (void)hipGetLastError(); a.mismatch = nullptr; }
     hipError_t e = launch_deform_shared(a, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_shared (pack) failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
     b->cur_set = si;
@@ -1724,10 +1749,10 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
         reuse = b->prep_P_out[i] == d_P_out[i] && (!d_falloff_out || b->prep_fall[i] == d_falloff_out[i]) &&
                 b->prep_gen[i] == b->ctxs[i]->model_gen;          // a context rebuilt or re-imported on its own since: pack again
     if (reuse) {
-        for (int i = 0; i < b->n; ++i)
-            if ((rc = order_after_batch(b->ctxs[i], stream))) { batch_err(b, "context %d: %s", i, b->ctxs[i]->err); return rc; }
         if ((rc = batch_poll(b))) return rc;
-        if (!b->prepared) reuse = false;         // the poll repaired a model: pack again
+        if (!b->prepared) reuse = false;         // the poll repaired a model: pack again (shared_pack orders the stream)
+        for (int i = 0; reuse && i < b->n; ++i)
+            if ((rc = order_after_batch(b->ctxs[i], stream))) { batch_err(b, "context %d: %s", i, b->ctxs[i]->err); return rc; }
     }
     if (reuse) {
         fd_batch::SharedSet &ps = b->sets[b->cur_set];
@@ -1750,6 +1775,7 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     a.wtiles = st.d_wtiles; a.frames = st.d_frames;
     a.packed_ev = nullptr;
     a.mode = 2;
+    a.max_wgs = b->eval_cus;
     hipError_t e = launch_deform_shared(a, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_shared failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
     if (make_event(&st.eval_ev)) {
@@ -1775,6 +1801,13 @@ int fd_batch_wait_consumed(fd_batch *b, void *hip_stream)
         batch_err(b, "fd_batch_wait_consumed: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
         return FD_E_DEVICE;
     }
+    return FD_OK;
+}
+
+int fd_batch_set_eval_cus(fd_batch *b, int n_cus)
+{
+    if (!b) return FD_E_INVALID;
+    b->eval_cus = n_cus > 0 ? n_cus : 0;
     return FD_OK;
 }
 

@@ -98,7 +98,26 @@ struct SharedParams {
 struct SharedSlots {              // the models of the frames (kernel argument of the pack kernel)
     const Rec32 *rec32[kMaxBatch];
     const DevModel *model[kMaxBatch];
+    const double *centres[kMaxBatch];     // fp64 centres as built / imported (M x 3): compared with model 0's
+    int M;
+    int nreal;                            // frames of the launch (the slots beyond repeat frame nreal - 1)
+    int *mismatch;                        // page-locked word (device address) or null
 };
+
+// "One rest rig" by content: frame f's centres against frame 0's, all M of them, by the `per` lanes (a power of two inside
+// one wave, lane index l) that also scan the frame's weights in the pack workgroup that writes its frame record.  A frame
+// that differs is reported (1 + index) and recorded as unbuilt, i.e. passed through.  Every lane must call it.
+__device__ __forceinline__ bool rig_matches(const SharedSlots &slots, int f, int nF, int l, int per)
+{
+    bool same = true;
+    if (f > 0 && f < nF && slots.centres[f] != slots.centres[0]) {
+        const double *a = slots.centres[f], *b0 = slots.centres[0];
+        for (int e = l; e < 3 * slots.M; e += per) same = same && a[e] == b0[e];
+    }
+    for (int off = per / 2; off >= 1; off >>= 1) same = (__shfl_xor((int)same, off) != 0) && same;
+    if (!same && l == 0 && slots.mismatch) *slots.mismatch = (f < slots.nreal ? f : slots.nreal - 1) + 1;
+    return same;
+}
 
 // weight tiles, polynomial tiles and frame records from the solved models.  grid (nkb, nT), 256 threads (the first 64 write the tile).
 // The polynomial part of a frame (DevModel::poly32: C0 + L.x' + q |x'|^2 per output) rides in the
@@ -156,6 +175,7 @@ __global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, co
             if (l < 15) m = fmaxf(m, fabsf(slots.model[f]->poly32[l]));
         }
         for (int off = per / 2; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));      // per is 16 or 64: inside a wave
+        const bool same_rig = (kb == 0 && (!dense || T % 3 == 0)) ? rig_matches(slots, f, nF, l, per) : true;
         if (l == 0) {
             int k = 0;
             if (m > 0.f && m < INFINITY) k = 13 - (__builtin_amdgcn_frexp_expf(m) - 1);
@@ -164,7 +184,7 @@ __global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, co
             if (kb == 0 && (!dense || T % 3 == 0)) {
                 SharedFrame fr;
                 fr.inv_scale = ldexpf(1.f, -k - (gauss ? kGaussShift : 0));
-                fr.built = (f < nF && slots.model[f]->terminationtype == 1) ? 1 : 0;
+                fr.built = (f < nF && same_rig && slots.model[f]->terminationtype == 1) ? 1 : 0;
                 fr.pad[0] = fr.pad[1] = 0;
                 fr.P_out = f < nF ? out.P_out[f] : nullptr;
                 fr.falloff_out = f < nF ? out.falloff_out[f] : nullptr;
@@ -757,20 +777,29 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr bool shared_wide(int nF, int kind) { (void)kind; return nF > 16; }      // thin-plate and the Gaussian kinds alike
 constexpr int kWideSlots = 32;                      // frame records
-constexpr int kWideDefaultVar = 49;      // skewed K loop, units from the counter, non-temporal stores and loads: the fastest inside bench.py (tests/tools/wide_variants_timing.py for the others)
-constexpr int kWideW16 = 3 * 2 * 2 * 64;            // 16-byte words of weight tiles per K block: [component][K step][hi, lo][lane]
+constexpr int kWideDefaultVar = 49;      // skewed K loop, units from the counter, non-temporal stores and loads: the fastest inside bench.py
+// Rows of the output tiles are packed densely: row 3 f + c of the stack of 32-row tiles is component c of frame slot f, so
+// 17..20 frames are TWO tiles (60 rows of 64) where one tile per component would be three (r2: 96 rows whatever the frame
+// count) -- a third fewer matrix instructions for the driver's 20-frame launch.  After the epilogue's lane-half swap a lane
+// holds every row of every tile for its own vertex, so any row <-> (frame, component) map costs nothing there.
+// Frame slots come in fours (the fall-off rows leave four frames per store): a launch of nF frames runs
+// NSLOT = 4 ceil(nF / 4) slots, and slots nF .. NSLOT - 1 are DUPLICATES of frame nF - 1 (same weights, scale and output
+// pointers: the same bits stored twice to the same address) -- so every frame count takes the straight-line epilogue.
+constexpr int wide_slots(int nF) { return (nF + 3) / 4 * 4; }
+constexpr int wide_tiles(int nslot) { return (3 * nslot + 31) / 32; }               // 2 up to 20 slots (21 frames would fit, 24 slots do not), else 3
+constexpr int wide_w16(int nt) { return nt * 2 * 2 * 64; }                          // 16-byte words of weight tiles per K block: [tile][K step][hi, lo][lane]
 
-// grid (nkb, 3 components), 256 threads.  Output regions as in k_pack_shared with nT = 6: weight tiles, 6 x 64 words of
-// polynomial tiles (the first 3 x 64 used), then the d2 operands of the centres ([kb][2 instructions][64 lanes] x 8 B
-// inside the 2 x 768 B per K block of the 16-row layout's centre tiles) and the normalisation.
-__global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slots, const SharedOut out, int nF, int Mpad,
+// grid (nkb, NT row tiles), 256 threads.  Output regions: weight tiles [kb][tile][K step][hi, lo][lane], NT x 64 words of
+// polynomial tiles, then the d2 operands of the centres ([kb][2 instructions][64 lanes] x 8 B) and the normalisation.
+// nslot frame slots (a multiple of 4); slots.rec32 / model / out of the slots beyond nF point at frame nF - 1 (the host sets them).
+__global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slots, const SharedOut out, int nF, int nslot, int Mpad,
                                                            uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles, int gauss)
 {
-    const int kb = blockIdx.x, c = blockIdx.y, nkb = gridDim.x;
-    const size_t poly_at = (size_t)nkb * kWideW16, copy_at = poly_at + 6 * 64;
-    if (c == 0) {
+    const int kb = blockIdx.x, T = blockIdx.y, nkb = gridDim.x, NT = gridDim.y;
+    const int w16 = wide_w16(NT);
+    const size_t poly_at = (size_t)nkb * w16, copy_at = poly_at + (size_t)NT * 64;
+    if (T == 0) {
         // lane (h, r) of instruction i: k-slots 4 h .. 4 h + 3 of centre r = coordinate group 2 i + h of the 16-row tile
-        constexpr int per = (int)(sizeof(MfmaTileH) / 16);
         uint2 *dst = reinterpret_cast<uint2 *>(wtiles + copy_at) + (size_t)kb * 128;
         if (gauss) {
             // Gaussian kinds: the K block's slot holds its 32 centre records instead ({c'x, c'y, c'z, -log2(e) s^2 / R_j^2}:
@@ -789,15 +818,15 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
         }
         if (kb == 0 && threadIdx.x == 255) {
             const float *nn = slots.model[0]->norm32;
-            wtiles[copy_at + (size_t)2 * nkb * per] = make_uint4(__float_as_uint(nn[0]), __float_as_uint(nn[1]), __float_as_uint(nn[2]), __float_as_uint(nn[3]));
+            wtiles[copy_at + (size_t)nkb * 64] = make_uint4(__float_as_uint(nn[0]), __float_as_uint(nn[1]), __float_as_uint(nn[2]), __float_as_uint(nn[3]));
         }
     }
-    // scale of each frame: largest |weight| or |polynomial coefficient| to [2^13, 2^14); 8 lanes per frame
+    // scale of each frame slot: largest |weight| or |polynomial coefficient| to [2^13, 2^14); 8 lanes per slot
     __shared__ float s_scale[kWideSlots];
     {
         const int f = threadIdx.x >> 3, l = threadIdx.x & 7;
         float m = 0.f;
-        if (f < nF) {
+        if (f < nslot) {
             // eight weight triples in flight per lane (one 16-byte load each; one at a time this scan was most of the
             // kernel's 12 us, and the kernel sits on the build stream between a group's solve and the next one's)
             const f32x4 *w = reinterpret_cast<const f32x4 *>(slots.rec32[f]) + 1;       // {wx, wy, wz, pad} of record 0; stride 2
@@ -813,32 +842,35 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
             for (int e = l; e < 15; e += 8) m = fmaxf(m, fabsf(slots.model[f]->poly32[e]));
         }
         for (int off = 4; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const bool same_rig = (kb == 0 && T == 0) ? rig_matches(slots, f, nslot, l, 8) : true;
         if (l == 0) {
             int k = 0;
             if (m > 0.f && m < INFINITY) k = 13 - (__builtin_amdgcn_frexp_expf(m) - 1);
             k = k < -100 ? -100 : (k > 100 ? 100 : k);
             s_scale[f] = ldexpf(1.f, k);
-            if (kb == 0 && c == 0) {
+            if (kb == 0 && T == 0) {
                 SharedFrame fr;
                 fr.inv_scale = ldexpf(1.f, -k - (gauss ? kGaussShift : 0));
-                fr.built = (f < nF && slots.model[f]->terminationtype == 1) ? 1 : 0;
+                fr.built = (f < nslot && same_rig && slots.model[f]->terminationtype == 1) ? 1 : 0;
                 fr.pad[0] = fr.pad[1] = 0;
-                fr.P_out = f < nF ? out.P_out[f] : nullptr;
-                fr.falloff_out = f < nF ? out.falloff_out[f] : nullptr;
+                fr.P_out = f < nslot ? out.P_out[f] : nullptr;
+                fr.falloff_out = f < nslot ? out.falloff_out[f] : nullptr;
                 frames[f] = fr;
             }
         }
     }
     __syncthreads();
     if (threadIdx.x >= 128) return;
-    const int s = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, f = lane & 31;        // row = frame
-    const float sc = s_scale[f];
+    const int s = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
+    const int row = 32 * T + (lane & 31), f = row / 3, c = row % 3;               // row 3 f + c = component c of frame slot f
+    const bool live = f < nslot;
+    const float sc = live ? s_scale[f] : 0.f;
     f16x8 hi, lo;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int centre = 32 * kb + 8 * (2 * s + (m >> 2)) + 4 * h + (m & 3);
         float w = 0.f;
-        if (f < nF && centre < Mpad) {
+        if (live && centre < Mpad) {
             const Rec32 r = slots.rec32[f][centre];
             w = (c == 0 ? r.wx : (c == 1 ? r.wy : r.wz)) * sc;
         }
@@ -846,11 +878,11 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
         hi[m] = hh;
         lo[m] = (_Float16)(w - (float)hh);
     }
-    uint4 *dst = wtiles + (size_t)kb * kWideW16 + (size_t)((c * 2 + s) * 2) * 64;
+    uint4 *dst = wtiles + (size_t)kb * w16 + (size_t)((T * 2 + s) * 2) * 64;
     dst[lane] = __builtin_bit_cast(uint4, hi);
     dst[64 + lane] = __builtin_bit_cast(uint4, lo);
     if (kb == 0 && s == 0) {
-        // polynomial tile of component c, K = 16: coefficients {C0, Lx, Ly, Lz, q} as (hi, lo) against the vertex
+        // polynomial tile of row tile T, K = 16: coefficients {C0, Lx, Ly, Lz, q} as (hi, lo) against the vertex
         // operand's {1, x, y, z, |x|^2} as (hi, lo) -- lane half 0: hi[0..4] x hi, then hi[1..3] x lo(x, y, z);
         // lane half 1: hi[4] x lo(|x|^2), lo[0..4] x hi, two unused
         f16x8 pt;
@@ -859,11 +891,11 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
             const int coef = h == 0 ? (m < 5 ? m : m - 4) : (m == 0 ? 4 : (m < 6 ? m - 1 : -1));
             const bool want_lo = h == 1 && m >= 1;
             float w = 0.f;
-            if (f < nF && coef >= 0) w = slots.model[f]->poly32[5 * c + coef] * sc;
+            if (live && coef >= 0) w = slots.model[f]->poly32[5 * c + coef] * sc;
             const _Float16 hh = (_Float16)w;
             pt[m] = want_lo ? (_Float16)(w - (float)hh) : hh;
         }
-        wtiles[poly_at + (size_t)c * 64 + lane] = __builtin_bit_cast(uint4, pt);
+        wtiles[poly_at + (size_t)T * 64 + lane] = __builtin_bit_cast(uint4, pt);
     }
 }
 
@@ -879,11 +911,14 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 //   bit 3  the last, partial round dealt out as whole groups (clear: as single units)
 //   bit 4  the straight-line epilogue's stores with the non-temporal hint
 //   bit 5  the positions read with the non-temporal hint
-// Instantiated: 0, 1, 2, 3, 5, 9, 17, 49 (the default); the Gaussian kinds: 49.
-template <int VAR, bool GAUSS = false>
+// Instantiated: 49 only (r2 kept eight for A/B runs; the others lost and are gone from the library).
+// NT row tiles of 32 (2 or 3), NSLOT frame slots (20: NT = 2; 24, 28, 32: NT = 3) -- see wide_slots / wide_tiles.
+template <int VAR, bool GAUSS, int NT, int NSLOT>
 __global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 {
+    static_assert(NSLOT % 4 == 0 && NSLOT <= kWideSlots && 3 * NSLOT <= 32 * NT, "frame slots in fours, three rows each");
+    constexpr int kWideW16 = wide_w16(NT);
     constexpr bool SKEWED = (VAR & 1) != 0;
     static_assert(!GAUSS || SKEWED, "the Gaussian kinds take the skewed loop only");
     constexpr bool AHEAD = (VAR & 4) != 0;
@@ -891,10 +926,10 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     constexpr int TV = 2;                        // vertex tiles (of 32) per wave
     constexpr int kSlots = kWideSlots;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: [frame records 32][polynomial tiles 3 x 64 x 16 B][d2 operands kchunk x 2 x 64 x 8 B][weight tiles kchunk x 12 KiB]
+    // LDS: [frame records 32][polynomial tiles NT x 64 x 16 B][d2 operands kchunk x 2 x 64 x 8 B][weight tiles kchunk x NT x 4 KiB]
     SharedFrame *s_frames = reinterpret_cast<SharedFrame *>(smem);
     uint4 *s_poly = reinterpret_cast<uint4 *>(smem + sizeof(SharedFrame) * (size_t)kSlots);
-    uint2 *s_ct = reinterpret_cast<uint2 *>(s_poly + 3 * 64);
+    uint2 *s_ct = reinterpret_cast<uint2 *>(s_poly + NT * 64);
     uint4 *s_w = reinterpret_cast<uint4 *>(s_ct + (size_t)128 * p.kchunk);
     // fd_falloff pointers of the straight-line epilogue: store q of a group covers frames 4 q .. 4 q + 3, 16 lanes x 16 B each
     uint64_t *s_ftab = reinterpret_cast<uint64_t *>(s_w + (size_t)kWideW16 * p.kchunk);
@@ -947,9 +982,9 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         uint4 *dst = reinterpret_cast<uint4 *>(s_frames);
         for (int q = tid; q < kSlots * (int)(sizeof(SharedFrame) / 16); q += kSharedThreads) dst[q] = src[q];
         const uint4 *psrc = p.wtiles + (size_t)p.nkb * kWideW16;
-        for (int q = tid; q < 3 * 64; q += kSharedThreads) s_poly[q] = psrc[q];
+        for (int q = tid; q < NT * 64; q += kSharedThreads) s_poly[q] = psrc[q];
         if (tid == 0) *s_ticket = 0u;
-        if (p.fast) s_ftab[tid] = (uint64_t)p.frames[4 * (tid >> 6) + ((tid & 63) >> 4)].falloff_out + 16u * (unsigned)(tid & 15);
+        if (p.fast && tid < NSLOT * 16) s_ftab[tid] = (uint64_t)p.frames[4 * (tid >> 6) + ((tid & 63) >> 4)].falloff_out + 16u * (unsigned)(tid & 15);
     }
     if (resident) {
         stage(0, p.nkb);
@@ -1026,7 +1061,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         const float own_d2 = h ? cur.d2[1] : cur.d2[0];
         f16x4 bop0[TV], bop1[TV];
         float xn[TV], yn[TV], zn[TV];            // GAUSS: the normalised coordinates, for the direct differences
-        f32x16 acc[3][TV];
+        f32x16 acc[NT][TV];
         bool lane_live = false;
 #pragma unroll
         for (int t = 0; t < TV; ++t) {
@@ -1055,7 +1090,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             else pb = (u32x4){(zxl >> 16) | (one16 << 16), xyh, zxh, 0u};
             const f16x8 pbv = __builtin_bit_cast(f16x8, pb);
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < NT; ++c)
                 acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, s_poly[c * 64 + lane]), pbv, zero16, 0, 0, 0);
         }
         const bool wave_work = FAST ? true : __any(lane_live);
@@ -1084,7 +1119,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         auto contract = [&](int kb, const u32x8 (&xh)[TV], const u32x8 (&xl)[TV]) {
             const uint4 *wk = s_w + (size_t)kb * kWideW16 + lane;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < NT; ++c) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const f16x8 ah = __builtin_bit_cast(f16x8, wk[((c * 2 + s) * 2) * 64]), al = __builtin_bit_cast(f16x8, wk[((c * 2 + s) * 2 + 1) * 64]);
@@ -1183,7 +1218,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             auto contract_half = [&](int kb, int s, const u32x4 (&xh)[TV], const u32x4 (&xl)[TV]) {
                 const uint4 *wk = s_w + (size_t)kb * kWideW16 + lane;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int c = 0; c < NT; ++c) {
                     const f16x8 ah = __builtin_bit_cast(f16x8, wk[((c * 2 + s) * 2) * 64]), al = __builtin_bit_cast(f16x8, wk[((c * 2 + s) * 2 + 1) * 64]);
 #pragma unroll
                     for (int t = 0; t < TV; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, xh[t]), acc[c][t], 0, 0, 0);
@@ -1230,13 +1265,17 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                     __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
                 }
               } else {
+                // NM matrix instructions per K step; the 16 logarithms of a half block go under them one at a time (three
+                // row tiles: 18 instructions) or two at a time at first (two row tiles: 12)
+                constexpr int NM = 6 * NT, VPM = NT == 3 ? FD_WIDE_VPM : FD_WIDE_VPM + 2;
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-                for (int q = 0; q < 18; ++q) {
+                for (int q = 0; q < NM; ++q) {
                     if (q % 6 == 0 && q > 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (q < 16) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                    if (NT == 2 && q < 4) __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                    else if (q < 16) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
@@ -1245,11 +1284,12 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                     __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
                 }
 #pragma unroll
-                for (int q = 0; q < 18; ++q) {
+                for (int q = 0; q < NM; ++q) {
                     if (q % 6 == 0 && q > 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, FD_WIDE_VPM, 0);
+                    if (NT == 2 && q >= 2 && q < 8) __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                    else if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
                 }
               }
             }
@@ -1272,11 +1312,12 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         }
 
         FD_SSTAMP(1)
-        // ---- epilogue.  Register r of acc[c][vt] holds frame 8 (r / 4) + 4 h + r % 4 for vertex (vt, j); swapping the
-        // upper half of tile 0's register with the lower half of tile 1's leaves every lane with its OWN vertex
-        // (vbase + lane): acc[c][0][r] = frame 8 (r / 4) + r % 4, acc[c][1][r] = frame 8 (r / 4) + 4 + r % 4.
+        // ---- epilogue.  Register r of acc[T][vt] holds row 8 (r / 4) + 4 h + r % 4 of row tile T for vertex (vt, j); swapping
+        // the upper half of vertex tile 0's register with the lower half of vertex tile 1's leaves every lane with its OWN
+        // vertex (vbase + lane): acc[T][0][r] = row 8 (r / 4) + r % 4, acc[T][1][r] = row 8 (r / 4) + 4 + r % 4.
+        // Row 3 f + c of the stack is component c of frame slot f (row_of below).
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < NT; ++c) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[c][0][r]), __float_as_uint(acc[c][1][r]), false, false);
@@ -1292,6 +1333,11 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         if constexpr (!FAST) {
             nxt = load_raw(gu_next, fastTag);
         }
+        // component c of frame slot fs after the swap (indices are compile-time after unrolling)
+        auto row_of = [&](int fs, int c) -> float {
+            const int row = 3 * fs + c, T = row / 32, rho = row % 32;
+            return acc[T][(rho % 8) / 4][4 * (rho / 8) + rho % 4];
+        };
         FD_SSTAMP(2)
         if constexpr (FAST) {
             // straight-line stores (see k_deform32_tps_shared): 32 positions + 8 fall-off stores of four frames each.
@@ -1302,12 +1348,11 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             const unsigned voff = 12u * (unsigned)vbase + off12;
             const uint64_t fbase = 4ull * (uint64_t)vbase;
 #pragma unroll
-            for (int fs = 0; fs < kSlots; ++fs) {
+            for (int fs = 0; fs < NSLOT; ++fs) {
                 const float inv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs) / 64], (8 * fs) % 64));
                 const uint64_t pout = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 5) / 64], (8 * fs + 5) % 64) << 32) |
                                       (unsigned)__builtin_amdgcn_readlane((int)tab[(8 * fs + 4) / 64], (8 * fs + 4) % 64);
-                const int t = (fs % 8) / 4, r = 4 * (fs / 8) + fs % 4;
-                const float d0 = acc[0][t][r], d1 = acc[1][t][r], d2c = acc[2][t][r];
+                const float d0 = row_of(fs, 0), d1 = row_of(fs, 1), d2c = row_of(fs, 2);
                 if constexpr (NONTEMPORAL) {
                     if (fs % 4 == 0) __builtin_nontemporal_store(ones, (f32x4_a16 FD_GLOBAL *)(s_ftab[(fs / 4) * 64 + lane] + fbase));
                     store_pos3_nt((Pos3 FD_GLOBAL *)((char FD_GLOBAL *)pout + voff), __builtin_fmaf(d0, inv, pos[0]), __builtin_fmaf(d1, inv, pos[1]),
@@ -1360,7 +1405,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             }
         }
 #pragma unroll
-        for (int fs = 0; fs < kSlots; ++fs) {
+        for (int fs = 0; fs < NSLOT; ++fs) {
             const int f = fs;
             if (f >= p.nF) continue;
             const float inv = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)tab[(8 * f) / 64], (8 * f) % 64));
@@ -1375,8 +1420,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 if (pout != (uint64_t)p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
                 continue;
             }
-            const int t = (fs % 8) / 4, r = 4 * (fs / 8) + fs % 4;
-            float disp[3] = {acc[0][t][r] * inv, acc[1][t][r] * inv, acc[2][t][r] * inv};       // 2^-k is exact
+            float disp[3] = {row_of(fs, 0) * inv, row_of(fs, 1) * inv, row_of(fs, 2) * inv};       // 2^-k is exact
             if (p.dbg & 1) continue;
             if (p.tu) {
                 const float da1 = disp[0] * a1[0] + disp[1] * a1[1] + disp[2] * a1[2];
@@ -1393,7 +1437,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 #pragma unroll
     for (int q = 0; q < kTabRegs; ++q) {
         const int idx = 64 * q + lane;
-        if ((idx & 7) == 1) built_here = built_here && tab[q] != 0u;
+        if (idx < NSLOT * 8 && (idx & 7) == 1) built_here = built_here && tab[q] != 0u;
     }
     const bool fast_ok = p.fast && __all(built_here);
     const int nfull = (int)(p.N / kSharedThreads);       // groups in which every wave's 64 vertices exist
@@ -1428,31 +1472,52 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 
 }  // namespace
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one process may hold contexts on
+// several GPUs (fd_config.device), so "done" is remembered per (kernel, device), not per process.
+constexpr int kMaxDevices = 64;
+struct LdsAttrOnce {
+    bool done[kMaxDevices] = {};
+    hipError_t ensure(const void *fn, int bytes)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < kMaxDevices && done[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && dev >= 0 && dev < kMaxDevices) done[dev] = true;
+        return e;
+    }
+};
+
 // Frames of one mesh and one rest rig (SharedDeformArgs): pack the weight tiles, then one launch.
 hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
 {
     if (a.N <= 0 || a.nF <= 0) return hipSuccess;
     if (a.nF > kMaxBatch || a.Mpad % 16 != 0) return hipErrorInvalidValue;
     const int ntiles = a.Mpad / 16, nkb = (ntiles + 1) / 2;
-    const bool dense = shared_dense(a.nF);
-    const int nT = shared_tiles(a.nF);
     const bool gauss = a.kind != FD_KERNEL_THIN_PLATE;       // FD_KERNEL_GAUSSIAN / _QNN: per-record scale, direct differences
+    // 17..32 frames: 32-row tiles (r2 kept the 16-row kernel selectable for them, at six tiles: 201 against 175 us at C2 x 32)
+    const bool wide = shared_wide(a.nF, a.kind);
+    const bool dense = shared_dense(a.nF);
+    const int nT = shared_tiles(a.nF);                       // 16-row tiles (also what the scratch is sized by)
+    const int wslot = wide_slots(a.nF), wNT = wide_tiles(wslot);
+    // Frame slots beyond nF are duplicates of the LAST frame: same weights, same scale, same output pointers, so their
+    // stores repeat that frame's bits at the same addresses and the straight-line epilogue needs no "unused slot" case.
+    const int nslot = wide ? wslot : shared_slots(nT, dense);
     SharedSlots slots{};
     SharedOut out{};
     for (int f = 0; f < kMaxBatch; ++f) {
-        const int q = f < a.nF ? f : 0;
-        slots.rec32[f] = a.rec32[q]; slots.model[f] = a.model[q];
+        const int q = f < a.nF ? f : a.nF - 1;
+        slots.rec32[f] = a.rec32[q]; slots.model[f] = a.model[q]; slots.centres[f] = a.centres[q];
         out.P_out[f] = a.P_out[q]; out.falloff_out[f] = a.falloff_out ? a.falloff_out[q] : nullptr;
     }
-    // 17..32 thin-plate frames: 32-row tiles (FD_SHARED_WIDE=0: the 16-row kernel, for A/B runs)
-    const bool wide_on = [] { const char *e = getenv("FD_SHARED_WIDE"); return !(e && atoi(e) == 0); }();      // read per launch: A/B inside one process
-    const bool wide = wide_on && shared_wide(a.nF, a.kind);
+    slots.M = a.M; slots.nreal = a.nF; slots.mismatch = a.mismatch;
     if (a.mode != 2) {
         if (wide)
-            hipLaunchKernelGGL(k_pack_shared_wide, dim3(nkb, 3), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, (uint4 *)a.wtiles,
+            hipLaunchKernelGGL(k_pack_shared_wide, dim3(nkb, wNT), dim3(256), 0, stream, slots, out, a.nF, wslot, a.Mpad, (uint4 *)a.wtiles,
                                (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
         else
-            hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, a.nF, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
+            hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, nslot, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
                                (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
         if (a.packed_ev) {
             hipError_t e = hipEventRecord(a.packed_ev, stream);
@@ -1464,7 +1529,11 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     p.N = a.N; p.P_in = a.P_in; p.dist2 = a.dist2; p.tu = a.tu; p.tv = a.tv; p.nrm = a.nrm;
     p.radius2 = a.radius2; p.falloffrate = a.falloffrate;
     p.ntiles = ntiles; p.nkb = nkb; p.nF = a.nF; p.nT = nT;
-    {
+    if (wide) {
+        const uint4 *copy = (const uint4 *)a.wtiles + (size_t)nkb * wide_w16(wNT) + (size_t)wNT * 64;
+        p.ctiles = reinterpret_cast<const MfmaTileH *>(copy);
+        p.norm = reinterpret_cast<const float *>(copy + (size_t)nkb * 64);
+    } else {
         const uint4 *copy = (const uint4 *)a.wtiles + (size_t)nkb * nT * 128 + (size_t)nT * 64;
         p.ctiles = reinterpret_cast<const MfmaTileH *>(copy);
         p.norm = reinterpret_cast<const float *>(copy + (size_t)2 * nkb * (sizeof(MfmaTileH) / 16));
@@ -1473,13 +1542,18 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     { static const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
     {
         static const bool no_fast = getenv("FD_SHARED_NO_FAST") != nullptr;       // A/B: general epilogue everywhere
+        // no gate, no fall-off input, no tangent frames, fd_falloff wanted for every frame: the straight-line epilogue.
+        // Any frame count: the slots a launch runs beyond nF repeat the last frame (above).
+        // (repeated slots cost stores: worth it up to a quarter of the frames -- 17..32 frames always qualify)
         bool fast = !no_fast && (p.dbg & 1) == 0 && a.dist2 == nullptr && a.tu == nullptr && a.radius2 > 0.f && a.falloff_out != nullptr &&
-                    a.nF == shared_slots(nT, dense) && a.N < ((int64_t)1 << 28);
+                    a.N < ((int64_t)1 << 28) && 4 * (nslot - a.nF) <= a.nF;
         // (the straight-line epilogues store fd_falloff 8 and 16 bytes at a time: 16-byte aligned arrays, or the general path)
         for (int f = 0; fast && f < a.nF; ++f) fast = a.falloff_out[f] != nullptr && a.P_out[f] != nullptr && ((uintptr_t)a.falloff_out[f] & 15) == 0;
         p.fast = fast ? 1 : 0;
     }
     { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+#ifdef FD_SHARED_STAMPS_BUILD
+    // diagnostics, compiled in only for profiling builds (-DFD_SHARED_STAMPS_BUILD): in-kernel clock stamps, printed per launch
     static unsigned long long *d_stamps = nullptr;
     static const bool want_stamps = getenv("FD_SHARED_STAMPS") != nullptr;
     constexpr size_t kStampWords = 64 + (size_t)kNumCU * 8 * 2;
@@ -1487,9 +1561,12 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (want_stamps && d_stamps) (void)hipMemsetAsync(d_stamps, 0, kStampWords * sizeof(unsigned long long), stream);
     p.stamps = want_stamps ? d_stamps : nullptr;
     { static const bool e = getenv("FD_SHARED_STAMPS_GENERAL") != nullptr; if (want_stamps && e) p.fast = 0; }
-    const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)3 * 64 * 16 + 512 * sizeof(uint64_t) + 16
+#else
+    p.stamps = nullptr;
+#endif
+    const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)wNT * 64 * 16 + 512 * sizeof(uint64_t) + 16
                               : sizeof(SharedFrame) * (size_t)shared_slots(nT, dense) + (size_t)nT * 64 * 16;
-    const size_t per_kb = wide ? (size_t)1024 + (size_t)kWideW16 * 16 : 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
+    const size_t per_kb = wide ? (size_t)1024 + (size_t)wide_w16(wNT) * 16 : 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
     int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);
     if (kchunk < 1) return hipErrorInvalidValue;
     if (kchunk > nkb) kchunk = nkb;
@@ -1497,53 +1574,35 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     const size_t lds = fixed + per_kb * (size_t)kchunk;
     const int64_t per = kSharedThreads / 64 * 64;          // vertices per workgroup and group
     const int64_t ngroups = (a.N + per - 1) / per;
-    // One persistent workgroup per CU (150 KiB of LDS, two 240-register waves per SIMD: nothing else
-    // fits beside it).  FD_SHARED_CUS < 256 leaves the other CUs to whatever runs on other streams --
-    // the builds of the next frames in a pipeline (bench.py).
-    static const int64_t max_wgs = [] {
-        const char *e = getenv("FD_SHARED_CUS");
-        const long v = e ? atol(e) : 0;
-        return (int64_t)(v > 0 && v < (long)kNumCU ? v : (long)kNumCU);
-    }();
+    // One persistent workgroup per CU (150 KiB of LDS, two 240-register waves per SIMD: nothing else fits beside it).
+    // a.max_wgs < 256 (fd_batch_set_eval_cus) leaves the other CUs to whatever runs on other streams -- the builds of the
+    // next frames in a pipeline (bench.py).
+    const int64_t max_wgs = (a.max_wgs > 0 && a.max_wgs < kNumCU) ? a.max_wgs : kNumCU;
     const unsigned grid = (unsigned)(ngroups < max_wgs ? ngroups : max_wgs);
 #define FD_SHARED_CASE(NTV, DNS, GSS)                                                                                \
     {                                                                                                                \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared<NTV, DNS, GSS>,                  \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
-            if (e != hipSuccess) return e;                                                                           \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
+        static LdsAttrOnce once;                                                                                     \
+        hipError_t e = once.ensure((const void *)k_deform32_tps_shared<NTV, DNS, GSS>, 160 * 1024);                  \
+        if (e != hipSuccess) return e;                                                                               \
         hipLaunchKernelGGL((k_deform32_tps_shared<NTV, DNS, GSS>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
     }
 #define FD_SHARED_KIND(NTV, DNS) { if (gauss) FD_SHARED_CASE(NTV, DNS, true) else FD_SHARED_CASE(NTV, DNS, false) }
-#define FD_WIDE_CASE(V)                                                                                              \
+#define FD_WIDE_CASE(GSS, NTW, NSL)                                                                                  \
     {                                                                                                                \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide<V>,                          \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
-            if (e != hipSuccess) return e;                                                                           \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
-        hipLaunchKernelGGL((k_deform32_tps_shared_wide<V>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
+        static LdsAttrOnce once;                                                                                     \
+        hipError_t e = once.ensure((const void *)k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL>, 160 * 1024); \
+        if (e != hipSuccess) return e;                                                                               \
+        hipLaunchKernelGGL((k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
     }
-    if (wide && gauss) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_deform32_tps_shared_wide<49, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_deform32_tps_shared_wide<49, true>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups);
-    } else if (wide) {
-        const char *ev = getenv("FD_SHARED_WIDE_VAR");
-        const int var = ev ? atoi(ev) : kWideDefaultVar;
-        if (var == 1) FD_WIDE_CASE(1) else if (var == 2) FD_WIDE_CASE(2) else if (var == 3) FD_WIDE_CASE(3) else if (var == 5) FD_WIDE_CASE(5) else if (var == 9) FD_WIDE_CASE(9) else if (var == 17) FD_WIDE_CASE(17) else if (var == 49) FD_WIDE_CASE(49) else FD_WIDE_CASE(0)
+#define FD_WIDE_KIND(NTW, NSL) { if (gauss) FD_WIDE_CASE(true, NTW, NSL) else FD_WIDE_CASE(false, NTW, NSL) }
+    if (wide) {
+        if (wslot == 20) FD_WIDE_KIND(2, 20)
+        else if (wslot == 24) FD_WIDE_KIND(3, 24)
+        else if (wslot == 28) FD_WIDE_KIND(3, 28)
+        else if (wslot == 32) FD_WIDE_KIND(3, 32)
+        else return hipErrorInvalidValue;
     } else if (dense) {
         if (nT == 3) FD_SHARED_KIND(3, true)
-        else if (nT == 6) FD_SHARED_KIND(6, true)
         else return hipErrorInvalidValue;
     } else {
         if (nT == 1) FD_SHARED_KIND(1, false)
@@ -1554,6 +1613,8 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
 #undef FD_SHARED_KIND
 #undef FD_SHARED_CASE
 #undef FD_WIDE_CASE
+#undef FD_WIDE_KIND
+#ifdef FD_SHARED_STAMPS_BUILD
     if (want_stamps && d_stamps) {
         static unsigned long long h[kStampWords];
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1575,6 +1636,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
                         h[w * 8 + 4], h[w * 8 + 5]);
         }
     }
+#endif
     return hipGetLastError();
 }
 

@@ -226,6 +226,12 @@ struct SharedDeformArgs {
                                           // launch reads nothing of the contexts -- their next build may start
     int mode;                             // 0: pack kernel + evaluation; 1: pack kernel only (fd_batch_prepare_shared);
                                           // 2: evaluation only, on a scratch set packed earlier
+    int max_wgs;                          // CUs the launch may occupy (one persistent workgroup each); 0 or >= 256: all of them
+    // pack kernel only: every model's centres (fp64, M x 3) are compared with model 0's -- "one rest rig" checked by content --
+    // and 1 + the index of a model that differs is posted to *mismatch (device address of a page-locked word; may be null)
+    const double *centres[kMaxBatch];
+    int M;
+    int *mismatch;
 };
 hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream);
 size_t shared_wtile_bytes(int Mpad, int nF);

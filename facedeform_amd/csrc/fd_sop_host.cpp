@@ -315,8 +315,11 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     const bool use_capture = !want_d2 && geo->edge_offsets && geo->rig_ntris >= 0 && (geo->rig_ntris == 0 || geo->rig_tris);
     bool mesh_ready = false;
     if (geo->npoints > 0) {
+        // (a mesh that still carries an earlier cook's CAPTURED dist2 is not reusable once the capture's inputs are gone:
+        // the reference then applies neither radius nor fall-off, :396-399 -- fd_mesh_set drops the stale attribute)
         const bool reuse = geo->mesh_unchanged && fd_mesh_size(ctx) == geo->npoints &&
-                           node->mesh_had_dist2 == want_d2 && node->mesh_had_frames == do_tangent_disp;
+                           node->mesh_had_dist2 == want_d2 && node->mesh_had_frames == do_tangent_disp &&
+                           !(node->captured && !use_capture);
         int mrc = FD_OK;
         if (!reuse) {
             mrc = fd_mesh_set(ctx, geo->npoints, geo->P, geo->dist2, do_tangent_disp ? geo->tangentu : nullptr,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 5   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared (additions only) */
+#define FD_ABI_VERSION 6   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus (additions only) */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -329,7 +329,7 @@ int fd_batch_deform_dev(fd_batch *batch, void *hip_stream, int64_t N, const floa
  * coordinate differences, formed once for all frames), fp32 evaluation, 32 or more centres -- anything else
  * (biharmonic, cubic, the multilayer model, fp64) takes fd_batch_deform_dev on the shared arrays.  Parity
  * with the oracle as for fd_deform (1e-5); NOT bit-identical to the one-frame kernels.
- * Fastest form: 32 frames (17..32 take 32-row output tiles), no d_dist2, no tangent frames, every d_falloff_out
+ * Fastest form: 17..32 frames (32-row output tiles, rows packed three per frame: 20 frames cost two tiles, not three), no d_dist2, no tangent frames, every d_falloff_out
  * given and 16-byte aligned (results are the same without, through a slower epilogue).  Outputs are written with
  * the non-temporal hint: they are not expected in L2 by whatever runs next. */
 int fd_batch_deform_shared_dev(fd_batch *batch, void *hip_stream, int64_t N, const float *d_P_in,
@@ -353,6 +353,11 @@ int fd_batch_wait_consumed(fd_batch *batch, void *hip_stream);
  * rebuild); without it, or with other outputs, fd_batch_deform_shared_dev packs by itself as before.  A no-op when
  * the shared-rig launch does not apply to the batch (other kernels). */
 int fd_batch_prepare_shared(fd_batch *batch, void *hip_stream, float *const *d_P_out, float *const *d_falloff_out);
+/* CU budget of this batch's shared-rig evaluation launches: fd_batch_deform_shared_dev runs one persistent workgroup per
+ * CU (it needs a CU's whole LDS), and a pipeline that builds the next group's models beside the evaluation may want to
+ * leave some CUs to those builds.  n_cus <= 0 or >= the device's CU count: all of them (the default).  Per batch, not
+ * per process: two nodes cooking side by side choose independently (round 2 read an environment variable once). */
+int fd_batch_set_eval_cus(fd_batch *batch, int n_cus);
 
 /* ---- dist2 producer (next row N2) ---------------------------------------------
  * The per-point body of ProximityCapture::capture (src/capture.cpp:58-97) on the

@@ -1,0 +1,139 @@
+"""GPU: the benchmark's OWN launch held to the oracle.
+
+bench.py cooks C2 -- N = 1M vertices, M = 256 control points, thin-plate, linear term -- in groups: one batched build
+with the one-workgroup-per-model solver of its lanes, fd_batch_prepare_shared on the build stream, ONE
+fd_batch_deform_shared_dev per group on another stream, on a CU budget of 192, over its 64 frame phases
+(synth.smooth_deltas(rest, f), f = 0..63, unscaled).  Round 2's tests drew f % 8 only, never ran the 32-row kernel's
+multi-round path (units from the LDS counter, the "pool" of single units after the last whole round: more groups than
+workgroups, i.e. N > 131 072 at 256 CUs) against the oracle, and never took the 192-CU grid.  Here the launch is exactly
+the benchmark's, for ALL 64 phases, at F = 32 (two groups) and F = 20 (the driver's `--steps 20`: four groups, the last
+one ragged at 4 frames), sampled where the unit schedule has its seams:
+
+  * the first and the last 64-vertex unit of every whole round (workgroup 0 / wave 0 and workgroup grid-1 / unit 7),
+  * every pool unit's first vertices and the whole last unit (N % 512 = 64: the last group is one unit),
+  * vertices that sit ON control points (d2 = 0), and a few thousand spread over the mesh.
+
+Bar: conftest.l2_parity_ulp <= 1 (SURVEY 8d's metric with the fp32 rounding of P + d stated) for every frame; the
+per-frame worst ratios go to gpurun_out/ (copied to profiles/r03_bench_launch_parity.txt).
+Replaces, per frame, the loop body of src/SOP_FaceDeform.cpp:404-439 after the build of :331-368."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import l2_parity, l2_parity_ulp, parity_ratio
+from facedeform_amd import capi, synth
+from oracle import fd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+N, M = 1_000_000, 256
+EVAL_CUS = 192          # bench.py's CU budget for the evaluation (the rest is left to the next groups' builds)
+
+
+def _sample_indices(n, grid):
+    """Vertices at the seams of k_deform32_tps_shared_wide's unit schedule (csrc/fd_eval_shared.hip: unit_global)."""
+    per_group, unit = 512, 64
+    ngroups = (n + per_group - 1) // per_group
+    whole = ngroups // grid
+    idx = [np.arange(0, 8)]                                  # vertices moved onto control points by _setup
+    for r in range(whole):
+        g_first, g_last = r * grid, r * grid + grid - 1
+        idx.append(np.arange(g_first * per_group, g_first * per_group + unit))                       # workgroup 0, unit 0
+        idx.append(np.arange(g_last * per_group + 7 * unit, g_last * per_group + 8 * unit))          # last workgroup, unit 7
+    pool0 = whole * grid * 8 * unit                          # first vertex of the pool of single units
+    idx.append(np.arange(pool0, n, 64))                      # first vertex of every pool unit
+    idx.append(np.arange(pool0, min(pool0 + 2 * unit, n)))   # the first two pool units whole
+    idx.append(np.arange(max(n - 2 * unit, 0), n))           # the last units (the very last group is a single unit)
+    idx.append(np.arange(0, n, 241))                         # ~4 150 spread over the mesh
+    idx = np.unique(np.concatenate(idx))
+    return idx[idx < n]
+
+
+@pytest.fixture(scope="module")
+def c2():
+    dev = torch.device("cuda", 0)
+    P = synth.head_mesh(N)
+    rest = synth.control_points(M, "head")
+    P[:8] = rest[:8]                                         # vertices on centres: d2 == 0
+    deltas = np.stack([synth.smooth_deltas(rest, f) for f in range(64)]).astype(np.float32)     # bench.py's N_FRAMES phases
+    return {"dev": dev, "P": P, "rest": rest, "deltas": deltas, "d_P": torch.from_numpy(P).to(dev),
+            "d_rest": torch.from_numpy(rest).to(dev), "d_deltas": torch.from_numpy(deltas).to(dev)}
+
+
+def _report(lines):
+    root = os.environ.get("GRAFT_REPO_ROOT")
+    if not root:
+        return
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "bench_launch_parity.txt"), "a") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("F", [32, 20])
+def test_the_benchmarks_own_launch_matches_the_oracle_for_all_64_phases(hip_lib, oracle, c2, F):
+    dev, P, rest, deltas = c2["dev"], c2["P"], c2["rest"], c2["deltas"]
+    d_P, d_rest, d_deltas = c2["d_P"], c2["d_rest"], c2["d_deltas"]
+    build_stream, eval_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    engines = []
+    for _ in range(F):
+        e = capi.Engine(solver=capi.SOLVER_ONE_WORKGROUP)          # bench.py's lane_solver
+        e.set_stream(build_stream.cuda_stream)
+        e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
+        engines.append(e)
+    batches = {}
+    outs = [torch.empty_like(d_P) for _ in range(F)]
+    falls = [torch.zeros(N, device=dev, dtype=torch.float32) for _ in range(F)]
+    idx = _sample_indices(N, EVAL_CUS)
+    assert idx.size >= 4000
+    Ps = np.ascontiguousarray(P[idx])
+    built = torch.cuda.Event()
+    lines = [f"# bench.py's launch: N = {N}, M = {M}, thin-plate + linear, one-workgroup batched build, prepare_shared + "
+             f"deform_shared_dev, F = {F}, {EVAL_CUS} CUs; {idx.size} sampled vertices per frame (round seams, pool units, centres)",
+             "# phase  frames_in_launch  l2_parity_ulp  l2_parity_raw  parity_ratio"]
+    worst = 0.0
+    for first in range(0, 64, F):
+        count = min(F, 64 - first)
+        if count not in batches:
+            batches[count] = capi.Batch(engines[:count])
+            batches[count].set_eval_cus(EVAL_CUS)
+        batch = batches[count]
+        frames = list(range(first, first + count))
+        with torch.cuda.stream(build_stream):
+            batch.set_points_dev([d_rest.data_ptr()] * count, [d_deltas.data_ptr() + f * M * 12 for f in frames], M)
+            batch.build_async(build_stream.cuda_stream)
+            batch.prepare_shared([o.data_ptr() for o in outs[:count]], d_falloff=[f.data_ptr() for f in falls[:count]],
+                                 stream_ptr=build_stream.cuda_stream)
+            built.record(build_stream)
+        eval_stream.wait_event(built)
+        for o in outs[:count]:
+            o.fill_(float("nan"))
+        torch.cuda.synchronize()
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs[:count]],
+                                d_falloff=[f.data_ptr() for f in falls[:count]], stream_ptr=eval_stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert [r.terminationtype for r in batch.build_result()] == [1] * count
+        sel = torch.from_numpy(idx).to(dev)
+        for k, f in enumerate(frames):
+            table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
+            rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], fo.TERM_LINEAR)
+            assert tt == 1
+            ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, Ps)
+            out = outs[k][sel].cpu().numpy()
+            assert np.isfinite(out).all(), (f, "unwritten vertices in the sample")
+            ulp, raw, comp = l2_parity_ulp(out, ref, Ps, TOL), l2_parity(out, ref, Ps), parity_ratio(out, ref, Ps, TOL)
+            lines.append(f"{f:3d} {count:3d} {ulp:.3f} {raw:.3e} {comp:.3f}")
+            worst = max(worst, ulp)
+            assert ulp <= 1.0, (F, f, ulp, raw)
+            assert torch.all(falls[k][sel] == 1.0)
+        # every vertex of every frame was written (the NaN fill is gone), whatever unit it belonged to
+        for k in range(count):
+            assert not torch.isnan(outs[k]).any().item(), (first, k)
+    lines.append(f"# worst l2_parity_ulp over 64 phases at F = {F}: {worst:.3f}")
+    _report(lines)
+    for b in batches.values():
+        b.close()
+    for e in engines:
+        e.set_stream(None)
+        e.close()

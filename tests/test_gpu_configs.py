@@ -96,9 +96,12 @@ def test_c3_evaluation_at_one_million_vertices(hip_lib, oracle):
 
 def test_c4_eight_frames_of_one_million_vertices_batched(hip_lib, oracle):
     """BASELINE config 4 on one GPU, launched exactly as bench.py launches a group: control points
-    read in place from device arrays, ONE batched build on a lane stream, ONE batched evaluation
-    launch on the evaluation stream that waits for the build.  Every frame is sampled against the
-    oracle, and must equal the same frame cooked alone bit for bit."""
+    read in place from device arrays, ONE batched build on a lane stream, then -- on the evaluation
+    stream, which waits for the build -- BOTH evaluation launches bench.py can take for the group:
+    the shared-rig launch (its default: the frames share mesh and rest rig; fd_batch_prepare_shared on the
+    lane stream, fd_batch_deform_shared_dev on the evaluation stream) and the independent-frames launch
+    (`--eval-launch batched`).  Every frame of both is sampled against the oracle; the independent launch
+    must also equal the same frame cooked alone bit for bit."""
     N, M, F = 1_000_000, 256, 8
     dev = torch.device("cuda", 0)
     P = synth.head_mesh(N)
@@ -121,14 +124,22 @@ def test_c4_eight_frames_of_one_million_vertices_batched(hip_lib, oracle):
     stride = M * 3 * 4
     batch.set_points_dev([d_rest.data_ptr()] * F, [d_deltas.data_ptr() + f * stride for f in range(F)], M)
     batch.build_async(lane.cuda_stream)
+    souts = [torch.empty_like(d_P) for _ in range(F)]
+    sfalls = [torch.zeros(N, device=dev) for _ in range(F)]
+    batch.prepare_shared([o.data_ptr() for o in souts], d_falloff=[f.data_ptr() for f in sfalls], stream_ptr=lane.cuda_stream)
     built = torch.cuda.Event()
     built.record(lane)
     es.wait_event(built)
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in souts], d_falloff=[f.data_ptr() for f in sfalls],
+                            stream_ptr=es.cuda_stream)
     batch.deform_dev(N, [d_P.data_ptr()] * F, [o.data_ptr() for o in outs], d_falloff=[f.data_ptr() for f in falls],
                      stream_ptr=es.cuda_stream)
     torch.cuda.synchronize()
     assert [r.terminationtype for r in batch.build_result()] == [1] * F
     idx = np.unique(np.concatenate([np.arange(0, N, 401), [0, 63, 64, N - 1]]))
+    for f in range(F):
+        _check_sample(oracle, _oracle_model(oracle, rest, deltas[f]), P, souts[f].cpu().numpy(), idx, f"c4 frame {f}, shared-rig launch", raw_holds=False)
+        assert np.array_equal(sfalls[f].cpu().numpy(), np.ones(N, np.float32))
     single = capi.Engine()
     single.set_kernel(capi.KERNEL_THIN_PLATE); single.set_term(capi.TERM_LINEAR)
     worst = 0.0

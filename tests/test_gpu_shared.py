@@ -349,6 +349,48 @@ def test_a_member_rebuilt_on_its_own_is_not_evaluated_from_a_stale_copy(hip_lib,
     _close(engines, batch)
 
 
+def test_one_rest_rig_is_checked_by_content_not_by_address_alone(hip_lib, oracle):
+    """the host decides "one rest rig" by the address the rest points were read from.  An address does not
+    identify its contents: here the array is REWRITTEN between the set-ups of two contexts (same pointer, other rig).  The
+    pack kernel compares the centres on the device: the frame built on other points is passed through (P_out = P_in, as
+    for a failed build), the matching frames are evaluated, and the next call on the batch reports FD_E_INVALID."""
+    M, N = 96, 6_000
+    dev = torch.device("cuda", 0)
+    P = synth.head_mesh(100_000)[::16][:N].copy()
+    rest = synth.control_points(M, "head")
+    other = (rest * np.float32(1.01)).astype(np.float32)
+    deltas = np.stack([synth.smooth_deltas(rest, f) for f in range(3)]).astype(np.float32)
+    d_P = torch.from_numpy(P).to(dev)
+    d_rest = torch.from_numpy(rest).to(dev)
+    d_del = torch.from_numpy(deltas).to(dev)
+    engines = []
+    for _ in range(3):
+        e = capi.Engine(); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR); engines.append(e)
+    pair = capi.Batch(engines[:2]); lone = capi.Batch([engines[2]]); batch = capi.Batch(engines)
+    pair.set_points_dev([d_rest.data_ptr()] * 2, [d_del[k].data_ptr() for k in range(2)], M)
+    pair.build_async(); assert [r.terminationtype for r in pair.build_result()] == [1, 1]
+    d_rest.copy_(torch.from_numpy(other).to(dev))            # the same array, another rig
+    torch.cuda.synchronize()
+    lone.set_points_dev([d_rest.data_ptr()], [d_del[2].data_ptr()], M)
+    lone.build_async(); assert lone.build_result()[0].terminationtype == 1
+    outs = [torch.empty_like(d_P) for _ in range(3)]
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])          # same address everywhere: accepted by the host
+    torch.cuda.synchronize()
+    for k in range(2):
+        table = oracle.control_table(rest, (rest + deltas[k]).astype(np.float32))
+        rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+        ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+        assert parity_ratio(outs[k].cpu().numpy(), ref, P, TOL) <= 1.0, k
+    assert torch.equal(outs[2], d_P)                          # passed through, not evaluated with context 0's centres
+    with pytest.raises(capi.FdError) as ei:
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])
+    assert ei.value.code == capi.FD_E_INVALID and "context 2" in str(ei.value)
+    for b in (pair, lone, batch):
+        b.close()
+    for e in engines:
+        e.close()
+
+
 @pytest.mark.parametrize("kind,okind,params", [(capi.KERNEL_THIN_PLATE, fo.KERNEL_THIN_PLATE, ()),
                                                (capi.KERNEL_GAUSSIAN_QNN, fo.KERNEL_GAUSSIAN_QNN, (1.0, 5.0))])
 @pytest.mark.parametrize("N,F", [(1, 16), (5, 32), (63, 32), (64, 16), (65, 32), (511, 16), (513, 4), (1025, 32), (130, 24), (33, 17)])
@@ -401,28 +443,31 @@ def test_shared_launch_at_the_edges_of_its_vertex_groups(hip_lib, oracle, kind, 
         e.close()
 
 
-@pytest.mark.parametrize("wide,var", [("1", "0"), ("1", "1"), ("1", "2"), ("1", "3"), ("1", "5"), ("1", "9"), ("1", "17"), ("1", "49"), ("0", "0")])
-def test_every_form_of_the_32_frame_launch_matches_the_oracle(hip_lib, oracle, monkeypatch, wide, var):
-    """17..32 thin-plate frames take the 32-row tiles (k_deform32_tps_shared_wide); its build variants and the 16-row
-    kernel stay selectable per launch (FD_SHARED_WIDE, FD_SHARED_WIDE_VAR) for A/B runs -- each held to the oracle, on the
-    straight-line epilogue (full groups, fd_falloff everywhere) and on the general one (ragged tail, gate)."""
-    monkeypatch.setenv("FD_SHARED_WIDE", wide)
-    monkeypatch.setenv("FD_SHARED_WIDE_VAR", var)
-    M, N, F = 256, 5 * 512 + 77, 32
+@pytest.mark.parametrize("F", [17, 20, 21, 23, 24, 27, 28, 31, 32])
+def test_every_frame_count_of_the_32_row_launch_matches_the_oracle(hip_lib, oracle, F):
+    """17..32 frames take the 32-row tiles (k_deform32_tps_shared_wide) with rows packed three per frame: two row tiles up
+    to 20 frames, three above; frame slots come in fours and the slots beyond F repeat the last frame, so EVERY count takes
+    the straight-line epilogue (full groups, fd_falloff everywhere) -- checked here for every frame, together with the
+    general epilogue (ragged tail, gate), and that nothing beyond the F outputs is touched."""
+    M, N = 256, 5 * 512 + 77
     dev, P, rest, deltas, d_P, keep, engines, batch = _setup(M, N, F)
     outs = [torch.empty_like(d_P) for _ in range(F)]
     falls = [torch.full((N,), 7.0, device=dev) for _ in range(F)]
     dist2 = (np.random.default_rng(5).random(N) * 0.6).astype(np.float32)
     d_d2 = torch.from_numpy(dist2).to(dev)
     r2 = np.float32(0.49)
+    refs = {}
     for gate in (False, True):
         kw = dict(d_dist2=d_d2.data_ptr(), radius2=r2, falloffrate=1.5) if gate else {}
         okw = dict(dist2=dist2, radius2=r2, falloffrate=1.5) if gate else {}
         batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], d_falloff=[f.data_ptr() for f in falls], **kw)
         torch.cuda.synchronize()
-        for f in (0, 5, 17, 31):
-            table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
-            rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+        for f in range(F):
+            if f not in refs:
+                table = oracle.control_table(rest, (rest + deltas[f]).astype(np.float32))
+                rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], 0)
+                refs[f] = (table, W, radii)
+            table, W, radii = refs[f]
             ref, ref_fall = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P, **okw)
             out = outs[f].cpu().numpy()
             assert parity_ratio(out, ref, P, TOL) <= 1.0, (gate, f)

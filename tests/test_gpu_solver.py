@@ -282,6 +282,67 @@ def test_failed_async_build_is_repaired_or_reported_without_reading_the_result(h
     e.close()
 
 
+def test_a_repaired_build_is_ordered_before_evaluations_on_other_streams(hip_lib):
+    """the LU rebuild that the status poll enqueues runs on the CONTEXT's stream; the evaluation that
+    found the failed status may launch on another one (bench.py: engines on a lane stream, evaluation on its own
+    stream).  The rebuild's end is published as the context's wait event, so the other stream is ordered behind it:
+    single launch (fd_deform_dev_stream) and the shared-rig launch of a batch alike give the LU's model, bit for bit.
+    Rig: two centres one fp32 step apart under the cubic kernel (Cholesky fails, LU does not)."""
+    M, N = 300, 50_000
+    dev = torch.device("cuda:0")
+    rest = synth.control_points(M, "head")
+    near = rest.copy(); near[17] = near[200] + np.float32(1e-7) * np.array([1, 0.5, -0.3], np.float32)
+    delta = synth.smooth_deltas(rest, 0).astype(np.float32)
+    P = synth.head_mesh(N)
+    d_P = torch.from_numpy(P).to(dev)
+    ref = _engine(capi.KERNEL_CUBIC, [], capi.TERM_LINEAR, near, delta, capi.SOLVER_LU)
+    ref.build()
+    want, _ = ref.deform(P)
+    ref.close()
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    # single context: build on stream A, evaluate on stream B
+    e = _engine(capi.KERNEL_CUBIC, [], capi.TERM_LINEAR, near, delta, capi.SOLVER_AUTO)
+    e.set_stream(sa.cuda_stream)
+    out = torch.empty_like(d_P)
+    e.build_async()
+    torch.cuda.synchronize()                                    # the failed status is posted; the engine is told nothing
+    e.deform_dev_stream(sb.cuda_stream, N, d_P.data_ptr(), out.data_ptr())      # polls, rebuilds on A, must wait for it on B
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    e.set_stream(None); e.close()
+    # a batch (thin-plate so that the shared-rig launch applies; the near-coincident pair makes the Cholesky fail there too)
+    d_near = torch.from_numpy(near).to(dev)
+    d_del = torch.from_numpy(np.stack([delta, (0.5 * delta).astype(np.float32)])).to(dev)
+    refs = []
+    for k in range(2):
+        r = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, near, d_del[k].cpu().numpy(), capi.SOLVER_LU)
+        r.build(); refs.append(r)
+    rb = capi.Batch(refs)
+    rb.set_points_dev([d_near.data_ptr()] * 2, [d_del[k].data_ptr() for k in range(2)], M)
+    rb.build_async(); assert [x.terminationtype for x in rb.build_result()] == [1, 1]
+    wants = [torch.empty_like(d_P) for _ in range(2)]
+    rb.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in wants])
+    torch.cuda.synchronize()
+    engines = []
+    for k in range(2):
+        x = capi.Engine(); x.set_stream(sa.cuda_stream); x.set_kernel(capi.KERNEL_THIN_PLATE); x.set_term(capi.TERM_LINEAR)
+        engines.append(x)
+    b = capi.Batch(engines)
+    b.set_points_dev([d_near.data_ptr()] * 2, [d_del[k].data_ptr() for k in range(2)], M)
+    b.build_async(sa.cuda_stream)
+    torch.cuda.synchronize()
+    outs = [torch.empty_like(d_P) for _ in range(2)]
+    b.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], stream_ptr=sb.cuda_stream)
+    torch.cuda.synchronize()
+    reps = b.build_result()
+    assert [x.terminationtype for x in reps] == [1, 1]
+    for k in range(2):
+        assert torch.equal(outs[k], wants[k]), k
+    b.close(); rb.close()
+    for x in engines + refs:
+        x.set_stream(None); x.close()
+
+
 def test_one_workgroup_build_matches_the_chain(hip_lib):
     """k_build_small (FD_SMALL_BUILD=1: everything after the assembly in one launch of one workgroup).
     Slower than the launch chain on this hardware and therefore off by default; kept selectable, so it
