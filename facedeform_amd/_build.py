@@ -10,7 +10,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfacedeform_hip.so")
-SOURCES = ["fd_eval.hip", "fd_eval_shared.hip", "fd_build.hip", "fd_nullspace.hip", "fd_capi.hip", "fd_morph.hip", "fd_capture.hip", "fd_sop_host.cpp"]
+SOURCES = ["fd_eval.hip", "fd_eval_shared.hip", "fd_build.hip", "fd_nullspace.hip", "fd_build_reg.hip", "fd_capi.hip", "fd_morph.hip", "fd_capture.hip", "fd_sop_host.cpp"]
 # per-file extras: keep the bf16 MFMA results of the evaluation kernel in VGPRs (the default puts
 # them in AGPRs and pays one v_accvgpr_read per value)
 EXTRA_FLAGS = {"fd_eval.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

@@ -19,7 +19,7 @@ FD_E_INVALID, FD_E_NOMEM, FD_E_DEVICE, FD_E_SINGULAR, FD_E_DUPLICATE, FD_E_NOT_B
 KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC, KERNEL_GAUSSIAN_ML = range(6)
 TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
 EVAL_FP32, EVAL_FP64 = 0, 1
-SOLVER_AUTO, SOLVER_LU, SOLVER_ONE_WORKGROUP = 0, 1, 2
+SOLVER_AUTO, SOLVER_LU, SOLVER_ONE_WORKGROUP, SOLVER_REGISTER, SOLVER_CHAIN = 0, 1, 2, 3, 4
 FDSOP_OK, FDSOP_MESSAGE, FDSOP_WARNING, FDSOP_ERROR = range(4)
 
 _f32p = C.POINTER(C.c_float)

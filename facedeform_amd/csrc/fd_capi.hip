@@ -24,6 +24,7 @@ struct fd_ctx {
     unsigned long long model_gen = 0; // counts the models this context has held (every enqueued build, every import): what a
                                      // batch's packed copy of the weights is checked against before it is reused
     bool last_spd = false;           // the build in flight / last finished took the Cholesky path
+    bool last_reg = false;           // ... in its register-resident form (no factorisation is kept: fd_set_deltas builds again)
 
     // model configuration
     int M = 0, kind = FD_KERNEL_GAUSSIAN_QNN, term = FD_TERM_LINEAR, nparams = 0;
@@ -368,7 +369,8 @@ fd_ctx *fd_create(const fd_config *cfg)
     if (cfg) {
         ctx->eval_precision = cfg->eval_precision == FD_EVAL_FP64 ? FD_EVAL_FP64 : FD_EVAL_FP32;
         ctx->eval_variant = cfg->eval_variant;
-        ctx->solver = (cfg->solver == FD_SOLVER_LU || cfg->solver == FD_SOLVER_ONE_WORKGROUP) ? cfg->solver : FD_SOLVER_AUTO;
+        ctx->solver = (cfg->solver == FD_SOLVER_LU || cfg->solver == FD_SOLVER_ONE_WORKGROUP || cfg->solver == FD_SOLVER_REGISTER ||
+                       cfg->solver == FD_SOLVER_CHAIN) ? cfg->solver : FD_SOLVER_AUTO;
     }
     hipDeviceProp_t prop;
     if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
@@ -582,6 +584,16 @@ static bool use_spd(const fd_ctx *ctx)
     return spd_applicable(ctx->kind, ctx->term, ctx_lambda(ctx), ctx->M);
 }
 
+// The register-resident one-launch build (fd_build_reg.hip): what FD_SOLVER_AUTO takes on the definite path up to 256
+// control points; FD_SOLVER_CHAIN keeps the launch chain, FD_SOLVER_ONE_WORKGROUP the round-2 one-workgroup build
+// (FD_REG_BUILD=0 in the environment: never, for A/B measurements).
+static bool use_reg(const fd_ctx *ctx)
+{
+    static const bool off = [] { const char *e = getenv("FD_REG_BUILD"); return e && atoi(e) == 0; }();
+    if (off || !(ctx->solver == FD_SOLVER_AUTO || ctx->solver == FD_SOLVER_REGISTER)) return false;
+    return reg_applicable(ctx->kind, ctx->term, ctx_lambda(ctx), ctx->M);
+}
+
 static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
 {
     b.M = ctx->M;
@@ -603,6 +615,7 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.group_panels = 0;
     b.spd = use_spd(ctx) ? 1 : 0;
     b.small = ctx->solver == FD_SOLVER_ONE_WORKGROUP ? 1 : 0;
+    b.reg = (b.spd && use_reg(ctx)) ? 1 : 0;
     b.aux_stream = nullptr;
     for (hipEvent_t &e : b.aux_events) e = nullptr;
 }
@@ -621,6 +634,12 @@ int fd_build_async(fd_ctx *ctx)
     if ((rc = sync_slot(ctx))) return rc;
     BuildBuffers b;
     fill_build_buffers(ctx, b);
+    if (b.reg) FD_HIP(ctx, reg_build_init());
+    if (ctx->deltas_only && ctx->have_factor && ctx->last_reg) {
+        // the register-resident build keeps no factorisation (it is faster than the stored-factor path was): new deltas
+        // are a new build from the context's own copy of the points -- bit-identical to fd_set_points + fd_build by construction
+        ctx->deltas_only = false;
+    }
     if (ctx->deltas_only && ctx->have_factor) {
         // fd_set_deltas: right-hand sides only, through the factorisation of the last full build
         b.group_panels = ctx->factor_grouped ? 1 : 0;
@@ -670,7 +689,7 @@ int fd_build_async(fd_ctx *ctx)
         FD_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, sizeof(double) * (size_t)ctx->cap_npad * cols, cur_stream(ctx)));
     }
     fd_ctx::GraphKey key{};
-    key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term | (b.spd << 9); key.nparams = ctx->nparams;
+    key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term | (b.spd << 9) | (b.reg << 11); key.nparams = ctx->nparams;
     memcpy(key.params, ctx->params, sizeof(key.params));
     key.A = ctx->d_A; key.rest = ctx->d_rest; key.rec32 = ctx->d_rec32;
     if (ctx->use_graph && (!ctx->build_exec || memcmp(&key, &ctx->graph_key, sizeof(key)) != 0)) {
@@ -709,6 +728,7 @@ int fd_build_async(fd_ctx *ctx)
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
     ctx->have_factor = b.ml_layers == 0;     // the multilayer model keeps no single factorisation to reuse
     ctx->last_spd = b.spd != 0;
+    ctx->last_reg = b.spd != 0 && b.reg != 0;
     ctx->factor_grouped = false;
     ctx->deltas_only = false;
     ctx->build_pending = true;
@@ -1453,6 +1473,10 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         if (!use_spd(b->ctxs[i])) bb.spd = 0;        // one context that fell back to the LU takes the batch with it
     for (int i = 0; i < b->n; ++i)
         if (b->ctxs[i]->solver != FD_SOLVER_ONE_WORKGROUP) bb.small = 0;      // ... and the one-workgroup build is everybody's choice or nobody's
+    for (int i = 0; i < b->n; ++i)
+        if (!use_reg(b->ctxs[i])) bb.reg = 0;                                  // ... and so is the register-resident one
+    if (!bb.spd) bb.reg = 0;
+    if (bb.reg && reg_build_init() != hipSuccess) { (void)hipGetLastError(); bb.reg = 0; }
     static const bool no_groups = getenv("FD_NO_PANEL_PAIRS") != nullptr;
     bb.group_panels = (b->n >= 4 && !no_groups && !getenv("FD_LOOKAHEAD")) ? 1 : 0;
     if (make_lookahead(&b->lu_stream, b->lu_events)) {
@@ -1461,7 +1485,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     }
 
     fd_batch::Key key{};
-    key.M = c0->M; key.kind = c0->kind; key.term = c0->term | (bb.spd << 9) | (bb.small << 10); key.nparams = c0->nparams;
+    key.M = c0->M; key.kind = c0->kind; key.term = c0->term | (bb.spd << 9) | (bb.small << 10) | (bb.reg << 11); key.nparams = c0->nparams;
     memcpy(key.params, c0->params, sizeof(key.params));
     if (b->use_graph && (!b->exec || memcmp(&key, &b->key, sizeof(key)) != 0)) {
         if (b->exec) { (void)hipGraphExecDestroy(b->exec); b->exec = nullptr; }
@@ -1503,6 +1527,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         c->have_factor = bb.ml_layers == 0;   // a batched build leaves a factorisation fd_set_deltas can reuse (not the multilayer model)
         c->factor_grouped = bb.group_panels != 0;
         c->last_spd = bb.spd != 0;
+        c->last_reg = bb.spd != 0 && bb.reg != 0;
         c->deltas_only = false;
         c->build_pending = true;
         ++c->model_gen;

@@ -146,6 +146,7 @@ struct BuildBuffers {
     // Householder reflectors and the projected kernel block, order M - T, is Cholesky-factorised
     // -- no pivot search, so the panel is no longer one workgroup's serial chain.
     int small;                        // FD_SOLVER_ONE_WORKGROUP: k_build_small where it applies
+    int reg;                          // the register-resident one-launch build (fd_build_reg.hip) where it applies: M <= 256 on the definite path
     int spd;
     // Multilayer Gaussian model (FD_KERNEL_GAUSSIAN_ML, fd_nullspace.hip launch_build_ml): number of
     // layers, 0 for every other kind.  `kind` is then FD_KERNEL_GAUSSIAN (what the assembly evaluates).
@@ -182,6 +183,10 @@ bool spd_applicable(int kind, int term, double lambda, int M);
 static inline size_t ns_doubles(int M) { return (size_t)12 * (size_t)M + 64 + (size_t)(M / 32 + 2) * 66 * 32; }
 hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
 hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const PointSrc *src);
+// ---- register-resident one-launch build (fd_build_reg.hip): the definite path for rigs of up to 256 control points
+bool reg_applicable(int kind, int term, double lambda, int M);
+hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
+hipError_t reg_build_init();          // once per device, outside stream capture
 constexpr int kMaxLayers = 8;
 hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);
 // FD_KERNEL_GAUSSIAN_QNN, the SOP's model = 0: least-squares polynomial first, then the pivoted LU

@@ -112,7 +112,7 @@ enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
  * choice for a pipeline that keeps evaluating on the other CUs while the next frames' models are solved (bench.py).
  * Same arithmetic within this choice for single and batched builds (bit-identical weights); against AUTO the
  * weights agree to rounding (1e-12 relative). */
-enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1, FD_SOLVER_ONE_WORKGROUP = 2 };
+enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1, FD_SOLVER_ONE_WORKGROUP = 2, FD_SOLVER_REGISTER = 3, FD_SOLVER_CHAIN = 4 };
 
 typedef struct fd_ctx fd_ctx;
 
