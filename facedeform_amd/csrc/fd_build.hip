@@ -1014,7 +1014,7 @@ hipError_t launch_lu_factor_solve(const BuildBuffers &b, hipStream_t stream)
 hipError_t launch_build(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
 {
     if (b.ml_layers) return launch_build_ml(b, stream, ev_mid);
-    if (b.spd && b.reg) return launch_build_reg(b, stream, ev_mid);
+    if (b.spd && b.reg) return launch_build_reg(b, stream, nullptr, ev_mid);      // (the C ABI calls it directly, without k_prepare)
     if (b.spd) return launch_build_spd(b, stream, ev_mid);
     if (b.kind == FD_KERNEL_GAUSSIAN_QNN) return launch_build_qnn(b, stream, ev_mid);   // polynomial first (fd_nullspace.hip)
     const int M = b.M;

@@ -1,8 +1,9 @@
 // fd_build_reg.hip -- the whole build of a rig of up to 256 control points in ONE launch of ONE workgroup per model, with the
-// matrix in REGISTERS: null-space projection + blocked Cholesky + both substitutions + packing.
+// matrix in REGISTERS: control table, kernel-matrix assembly, null-space projection, blocked Cholesky, both substitutions,
+// packing.
 //
-// Same system, same unknowns and the same mathematics as fd_nullspace.hip (replaces alglib::rbfbuildmodel, reference
-// src/SOP_FaceDeform.cpp:363-368, in north_star's dense formulation):
+// Same system, same unknowns and the same mathematics as fd_nullspace.hip (replaces the control table of reference
+// src/SOP_FaceDeform.cpp:268-287 and alglib::rbfsetpoints / rbfbuildmodel, :331-368, in north_star's dense formulation):
 //
 //     [ K   P ] [ w ]   [ f ]     P = Q [0; R],   B = Q^T K Q = K - V W^T - W V^T,   B11 y = (Q^T f)_1 (Cholesky, order
 //     [ P^T 0 ] [ a ] = [ 0 ]     n1 = M - T),    R a = (Q^T f)_2 - B21 y,           w = Q [y; 0]
@@ -10,22 +11,29 @@
 // Why another kernel.  Round 2's one-launch build (k_build_small) kept the matrix in L2: every phase was a handful of
 // dependent ~1 us round trips that four waves could not overlap -- 0.37 ms at M = 256 against 0.25 ms for the launch chain,
 // whose nine step launches cost ~4 us of launch floor each.  Here the lower triangle lives in the accumulator registers of
-// eight waves and never leaves the CU between steps:
+// eight waves and never leaves the CU:
 //
 //   * 16 x 16 tiles in the v_mfma_f64_16x16x4_f64 C/D layout (lane (c, g) = (lane & 15, lane >> 4) holds rows g, g + 4, g + 8,
 //     g + 12 of column c: 4 doubles); order 256 = 136 lower tiles + 16 tiles that carry the three right-hand sides as extra
 //     ROWS (so the forward substitution rides along) = 152 tiles = 19 per wave, dealt out round robin down the columns so that
 //     every suffix of columns -- what is left at step K -- is spread evenly;
-//   * per 16 columns: the wave that owns the diagonal tile factorises it AND inverts the factor in one pass (32 lanes: 16
-//     rows of the tile + 16 rows of the identity under the same column operations: [A; I] L^-T = [L; L^-T]); the tiles below
-//     become L_IK = C_IK inv(L_KK)^T as four matrix instructions each (no substitution chain per row), go through LDS once as
-//     the operands of the trailing update, and C_IJ -= L_IK L_JK^T is four more matrix instructions per tile;
-//   * back substitution in row form (y^T L = z^T), right-looking: a tile is its own B operand, one row of tiles per step;
-//   * reflectors, Q^T f, Y = K V, W, the rotation, B21, the recovery of a and w: in LDS and on the tiles in place;
-//   * the evaluation records / centre tiles / status are written by the same code as every other build (fd_pack.h).
+//   * the kernel matrix is ASSEMBLED into those registers (fp64 phi of the centre distances, 34 per lane): no assembly launch,
+//     no matrix in memory at all;
+//   * per 16 columns: the wave that owns the diagonal tile factorises it and inverts the factor IN ITS REGISTERS, four
+//     columns at a time -- the 4 x 4 pivot block goes to every lane by v_readlane and is factorised and inverted redundantly
+//     (no cross-lane traffic inside it), then [T | I] <- row operations as matrix instructions: rows_b <- inv(L_bb) rows_b and
+//     the rows below -= L_rb rows_b, whose multipliers ARE the transposed result of the first (the Schur complement is
+//     symmetric), in exactly the operand layout: no LDS round trip per column (a first version with one took 640 cycles
+//     per column, 10 k per block); the tiles below become L_IK = C_IK inv(L_KK)^T as four matrix instructions each, go
+//     through LDS once as the operands of the trailing update, and C_IJ -= L_IK L_JK^T is four more per tile;
+//   * back substitution in row form (y^T L = z^T), right-looking: a tile is its own B operand; the wave that owns tile
+//     (I, I - 1) also solves block I - 1, so a step costs ONE barrier;
+//   * the O(M) pieces -- reflectors of P with Q^T f folded in, V^T Y, the recovery of a and w = Q [y; 0] -- run on ONE wave
+//     with DPP reductions (no barriers; with 512 threads and a barrier pair per sum they were a third of the kernel), while
+//     Y = K V, the rotation and B21 work on the tiles in place.
 //
 // Roof: the fp64 matrix pipe (78.6 TFLOP/s); algorithmic work (1/3) n1^3 = 5.3 MFLOP at M = 256.  What bounds it is the
-// factorisation's critical path -- 16 dependent diagonal blocks of 16 dependent columns -- not flops: see DESIGN.md 4.2d.
+// factorisation's critical path -- 256 dependent pivots -- not flops: see DESIGN.md 4.2d.
 // fd_set_deltas on a context built this way simply builds again (no factor is kept; the build is faster than the stored-
 // factor path was), bit-identical by construction.
 #include <cstdio>
@@ -63,26 +71,34 @@ __device__ __forceinline__ int opaque_s(int v)
     return v;
 }
 
-// N sums over the 512-thread workgroup at once; every thread gets all of them (fixed order: deterministic)
-template <int N>
-__device__ __forceinline__ void wg_sum(double (&v)[N], double *scratch /* [8][N] */, int tid)
+// sum over the 64 lanes of a wave, every lane gets it: rotate-reduce inside each row of 16 on the DPP network (row_ror
+// 1, 2, 4, 8), then the four rows through v_readlane.  Fixed order: deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-#pragma unroll
-    for (int q = 0; q < N; ++q)
-        for (int off = 32; off >= 1; off >>= 1) v[q] += __shfl_xor(v[q], off);
-    __syncthreads();
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int q = 0; q < N; ++q) scratch[(tid >> 6) * N + q] = v[q];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < N; ++q) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < kRegWaves; ++w) s += scratch[w * N + q];
-        v[q] = s;
-    }
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_f64<0x121>(v);
+    v += dpp_f64<0x122>(v);
+    v += dpp_f64<0x124>(v);
+    v += dpp_f64<0x128>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    double o;
+    o = dpp_f64<0x121>(v); v = o > v ? o : v;
+    o = dpp_f64<0x122>(v); v = o > v ? o : v;
+    o = dpp_f64<0x124>(v); v = o > v ? o : v;
+    o = dpp_f64<0x128>(v); v = o > v ? o : v;
+    const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+    const double ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
 // lanes of one wave talking through LDS: a store by one lane and a load by another are unrelated to the compiler
@@ -93,53 +109,88 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 1 / sqrt(d): hardware estimate + two coupled Newton steps (as fd_nullspace.hip's sqrt_rsqrt)
-__device__ __forceinline__ void sqrt_rsqrt(double d, double &root, double &inv)
+// 1 / sqrt(d): the hardware estimate (v_rsq_f64: ~2^-23 relative) and ONE third-order correction,
+// y = y0 (1 + e / 2 + 3 e^2 / 8), e = 1 - d y0^2 (the next term, 5 e^3 / 16, is below 2^-70) -- five dependent operations
+// where two coupled Newton steps are eight: this sits 256 times on the factorisation's critical path
+// (tools/ubench_f64.hip: 7 cycles per dependent v_fma_f64, 18 for the estimate).
+__device__ __forceinline__ double rsqrt_nr(double d)
 {
     const double y0 = __builtin_amdgcn_rsq(d);
-    double gg = d * y0, h = 0.5 * y0;
-    double r = fma(-h, gg, 0.5);
-    gg = fma(gg, r, gg); h = fma(h, r, h);
-    r = fma(-h, gg, 0.5);
-    gg = fma(gg, r, gg); h = fma(h, r, h);
-    r = fma(-gg, gg, d);
-    root = fma(r, h, gg);
-    inv = 2.0 * h;
+    const double t = d * y0;
+    const double e = fma(-t, y0, 1.0);
+    double p = fma(e, 0.375, 0.5);
+    p = p * e;
+    return fma(y0, p, y0);
+}
+
+// ln of a positive, normal double to ~1.5 ulp (as fd_eval.hip's fast_log_pos: 2 atanh((m - 1) / (m + 1)), eleven odd terms)
+__device__ __forceinline__ double log_pos(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);
+    int e = __builtin_amdgcn_frexp_exp(x);
+    if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double s0 = num * r;
+    s0 = fma(fma(-den, s0, num), r, s0);
+    const double z = s0 * s0;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    const double lnm = fma(s0 * z, 2.0 * p, 2.0 * s0);
+    return fma((double)e, 0.69314718055994530942, lnm);
+}
+// the kernel in fp64, as fd_build.hip's phi_d (the kinds this path takes)
+__device__ __forceinline__ double phi_reg(int kind, double d2, double inv_r2)
+{
+    switch (kind) {
+    case FD_KERNEL_GAUSSIAN: return exp(-d2 * inv_r2);
+    case FD_KERNEL_THIN_PLATE: return d2 > 0.0 ? 0.5 * d2 * log_pos(d2) : 0.0;
+    case FD_KERNEL_BIHARMONIC: return -sqrt(d2);
+    default: return d2 * sqrt(d2);
+    }
 }
 
 // LDS map (doubles).  The per-wave partial sums of Y = K V (8 x 4 M) exist only before the factorisation and lie over the
 // inverse blocks and the panel buffer, which exist only from then on.
 struct RegLds {
-    double *cen, *V, *W, *F, *B21, *small, *red, *D, *line, *minv, *P, *scr, *Z, *Y, *stat, *ypart;
+    double *cen, *V, *W, *F, *B21, *small, *minv, *P, *scr, *Z, *Y, *stat, *ypart;
     int *tab;
 };
-constexpr int kSmallDoubles = 80;       // tau[4] R[16] Tm[16] g[12] G[16] misc
-constexpr int kTau = 0, kR = 4, kTm = 20, kG = 36, kGm = 48, kAc = 64;
-__host__ __device__ inline size_t reg_lds_doubles(int M)
+constexpr int kSmallDoubles = 96;       // tau[4] R[16] Tm[16] g[12] G[16] misc
+constexpr int kTau = 0, kR = 4, kTm = 20, kG = 36, kGm = 48;
+constexpr int kRows = 16 * kMaxBlocks;   // the O(M) arrays are laid out for 256 rows whatever M is (rows beyond M read as zero)
+__host__ __device__ inline size_t reg_lds_doubles(int)
 {
     const size_t overlay = (size_t)kMaxBlocks * kTileLds + (size_t)(kMaxBlocks + 1) * kTileLds;      // minv + P
-    const size_t ypart = (size_t)kRegWaves * 4 * (size_t)M;
-    return (size_t)3 * M + 4 * (size_t)M + 4 * (size_t)M + 3 * (size_t)M + 4 * (size_t)M + kSmallDoubles + 8 * 16 + kTileLds + 48 +
-           (overlay > ypart ? overlay : ypart) + (size_t)kRegWaves * kTileLds + 3 * 256 + 3 * 256 + 8 + 160 /* tile table, as ints */;
+    const size_t ypart = (size_t)kRegWaves * 4 * kRows;
+    return (size_t)3 * kRows + 4 * (size_t)kRows + 4 * (size_t)kRows + 3 * (size_t)kRows + 4 * (size_t)kRows + kSmallDoubles +
+           (overlay > ypart ? overlay : ypart) + (size_t)kRegWaves * 2 * kTileLds + 3 * 256 + 3 * 256 + 8 + 160 /* tile table, as ints */;
 }
-__device__ __forceinline__ RegLds carve(double *base, int M)
+__device__ __forceinline__ RegLds carve(double *base, int)
 {
     RegLds L;
     double *p = base;
-    L.cen = p; p += 3 * M;
-    L.V = p; p += 4 * M;
-    L.W = p; p += 4 * M;
-    L.F = p; p += 3 * M;
-    L.B21 = p; p += 4 * M;
+    L.cen = p; p += 3 * kRows;
+    L.V = p; p += 4 * kRows;
+    L.W = p; p += 4 * kRows;
+    L.F = p; p += 3 * kRows;
+    L.B21 = p; p += 4 * kRows;
     L.small = p; p += kSmallDoubles;
-    L.red = p; p += 8 * 16;
-    L.D = p; p += kTileLds;
-    L.line = p; p += 48;
     const size_t overlay = (size_t)kMaxBlocks * kTileLds + (size_t)(kMaxBlocks + 1) * kTileLds;
-    const size_t ypart = (size_t)kRegWaves * 4 * (size_t)M;
+    const size_t ypart = (size_t)kRegWaves * 4 * kRows;
     L.minv = p; L.P = p + (size_t)kMaxBlocks * kTileLds; L.ypart = p;
     p += overlay > ypart ? overlay : ypart;
-    L.scr = p; p += (size_t)kRegWaves * kTileLds;
+    L.scr = p; p += (size_t)kRegWaves * 2 * kTileLds;      // two transposition buffers per wave
     L.Z = p; p += 3 * 256;
     L.Y = p; p += 3 * 256;
     L.stat = p; p += 8;
@@ -147,69 +198,91 @@ __device__ __forceinline__ RegLds carve(double *base, int M)
     return L;
 }
 
-// The diagonal tile at sD (16 x 16, pitch 17, lower triangle read) -> inverse of its Cholesky factor at sMinv.  One wave.
-// Row lanes 0..15 hold the rows of A, row lanes 16..31 the rows of the identity; both go through the same column operations
-// (scale column k by 1 / l_kk, subtract l_mk times it from column m > k), which turn [A; I] into [L; L^-T]: row lane 16 + c
-// ends with row c of L^-T = column c of L^-1.  A row is split over two lanes by column parity (lane = row lane + 32 h holds
-// columns 2 j + h: 8 doubles -- with all 16 in one lane the routine did not fit beside the wave's 19 resident tiles: 260
-// spills).  The scaled column travels through an LDS line ordered by row parity, so each half fetches the multipliers of
-// ITS columns with broadcast reads; the NEXT pivot is formed ahead of that round trip from two v_readlanes, so its
-// square-root chain runs meanwhile.
-__device__ __forceinline__ void factor_invert_16(const double *sD, double *sLine /* [48] */, double *sMinv, double tiny, int live_cols,
-                                                 double *sStat, int lane)
+// ---- the diagonal tile, in registers --------------------------------------------------------------------------------
+// T: the tile in the accumulator layout (symmetric; T[i] lane (c, g) = element (g + 4 i, c)).  Returns inv(L) of its Cholesky
+// factor in the same layout.  Four columns at a time (b = 0..3):
+//   1. the 4 x 4 pivot block S = T[4b.., 4b..] goes to every lane (ten v_readlane pairs), and every lane factorises it and
+//      inverts the factor: the dependent chain of a block is four reciprocal square roots and nothing crosses lanes;
+//   2. rows_b <- inv(L_bb) rows_b of [T | U] (U starts as the identity): one K = 4 matrix instruction each, the rows ARE the
+//      B operand as they sit in register b;
+//   3. rows below -= L_rb rows_b: the multipliers L_rb = (S_rb L_bb^-T) are the transpose of what step 2 left in the T part
+//      (the Schur complement is symmetric) -- lane (m, k) of that result holds L[m][4 b + k]: the A operand as it sits.
+// After four rounds U = inv(L).  Pivots at or below `tiny` (or NaN) are flagged and their rows zeroed, as everywhere else.
+struct PivotStats { double pmin, pmax; bool singular; };
+__device__ __forceinline__ double4_t factor_invert_tile(double4_t Tt, double tiny, int live_cols, PivotStats &st, int lane)
 {
-    const int rl = lane & 31, h = lane >> 5, row = rl & 15;
-    const bool is_a = rl < 16;
-    double a[8];
+    const int c = lane & 15, g = lane >> 4;
+    double4_t U;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = is_a ? sD[row * kPitch + 2 * j + h] : ((2 * j + h == row) ? 1.0 : 0.0);
-    const double *colp = sLine + 16 * h;                                   // l_{2 j + h, k} at colp[j]
-    double *mine = is_a ? sLine + 16 * (row & 1) + (row >> 1) : sLine + 32 + row;      // this row's scaled element of column k
-    double pmin = INFINITY, pmax = 0.0;
-    bool singular = false;
-    double d = readlane_f64(a[0], 0);
+    for (int i = 0; i < 4; ++i) U[i] = (g + 4 * i == c) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int hk = k & 1, jk = k >> 1;
-        const bool ok = d > tiny;                    // false for NaN and for a lost definiteness
-        if (k < live_cols) {
-            if (!ok) singular = true;
-            const double ad = fabs(d);
-            pmin = ad < pmin ? ad : pmin;
-            pmax = ad > pmax ? ad : pmax;
+    for (int b = 0; b < 4; ++b) {
+        // element (4 b + p, 4 b + q) of the current tile: register b of lane (c = 4 b + q, g = p)
+        double s[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q <= p; ++q) s[p][q] = readlane_f64(Tt[b], 4 * b + q + 16 * p);
+        double l[4][4], inv[4], dk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double d = s[k][k];
+#pragma unroll
+            for (int e = 0; e < k; ++e) d = fma(-l[k][e], l[k][e], d);
+            dk[k] = d;
+            // (no test on the chain: a pivot at or below `tiny`, or NaN, is flagged below and the model reports -4 -- what its
+            // numbers then are does not matter, and nothing of it reaches another model)
+            inv[k] = rsqrt_nr(d);
+#pragma unroll
+            for (int p = k + 1; p < 4; ++p) {
+                double v = s[p][k];
+#pragma unroll
+                for (int e = 0; e < k; ++e) v = fma(-l[p][e], l[k][e], v);
+                l[p][k] = v * inv[k];
+            }
         }
-        double root, inv;
-        sqrt_rsqrt(ok ? d : 1.0, root, inv);
-        if (!ok) inv = 0.0;
-        const double own = a[jk] * inv;              // meaningful in the half that holds column k
-        wave_lds_sync();                             // the previous column's line has been read by everyone
-        if (h == hk) { a[jk] = own; *mine = own; }
-        if (k + 1 < 16) {
-            const int hn = (k + 1) & 1, jn = (k + 1) >> 1;
-            const double lnext = readlane_f64(own, k + 1 + 32 * hk);        // l_{k+1,k}
-            const double dold = readlane_f64(a[jn], k + 1 + 32 * hn);       // a_{k+1,k+1} before this column
-            d = fma(-lnext, lnext, dold);
+        // pivot statistics, off the chain
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool live = 4 * b + k < live_cols;
+            const double ad = fabs(dk[k]);
+            st.singular = st.singular || (live && !(dk[k] > tiny));
+            st.pmin = (live && ad < st.pmin) ? ad : st.pmin;
+            st.pmax = (live && ad > st.pmax) ? ad : st.pmax;
         }
-        wave_lds_sync();
-        const double lik = *mine;
-        if (hk == 0 && h == 1) a[jk] = fma(-colp[jk], lik, a[jk]);          // column k + 1 sits in the other half
+        // inverse of the 4 x 4 factor (lower triangular): m[p][q]
+        double m[4][4];
 #pragma unroll
-        for (int j = jk + 1; j < 8; ++j) a[j] = fma(-colp[j], lik, a[j]);
-    }
-    // inverse, plain [row m][col c]: row lane 16 + c holds x_m of column c, m = 2 j + h
-    if (!is_a) {
+        for (int q = 0; q < 4; ++q) {
+            m[q][q] = inv[q];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sMinv[(2 * j + h) * kPitch + row] = a[j];
+            for (int p = q + 1; p < 4; ++p) {
+                double v = 0.0;
+#pragma unroll
+                for (int e = q; e < p; ++e) v = fma(l[p][e], m[e][q], v);
+                m[p][q] = -v * inv[p];
+            }
+        }
+        // A operand of step 2: lane (c = row p < 4, g = column q) holds m[p][q] (zero above the diagonal and for c >= 4)
+        double aop = 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q <= p; ++q) aop = (c == p && g == q) ? m[p][q] : aop;
+        const double4_t zero = {0.0, 0.0, 0.0, 0.0};
+        const double4_t rt = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Tt[b], zero, 0, 0, 0);      // register 0: lane (n, k) = new row 4 b + k, column n
+        const double4_t ru = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, U[b], zero, 0, 0, 0);
+        const double mult = c > 4 * b + 3 ? -rt[0] : 0.0;          // -L[c][4 b + g] for the rows below the block
+        Tt = __builtin_amdgcn_mfma_f64_16x16x4f64(mult, rt[0], Tt, 0, 0, 0);
+        U = __builtin_amdgcn_mfma_f64_16x16x4f64(mult, ru[0], U, 0, 0, 0);
+        U[b] = ru[0];
+        Tt[b] = rt[0];
     }
-    if (lane == 0) {
-        if (singular) sStat[2] = 1.0;
-        sStat[0] = pmin < sStat[0] ? pmin : sStat[0];
-        sStat[1] = pmax > sStat[1] ? pmax : sStat[1];
-    }
+    return U;
 }
 
-__global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab, int M, int T, int npad, int lda, int kind, int Mpad,
-                                                            unsigned long long *stamps)
+__global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab, const PointSrc src, int use_src, int M, int T, int npad,
+                                                            int kind, int Mpad, double lambda, double gauss_R, unsigned long long *stamps)
 {
     const BatchSlot &slot = tab[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
@@ -220,15 +293,14 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     const int n1 = M - T;
     const int nbk = (M + 15) / 16;                   // tile rows / columns of K
     const int nb = (n1 + 15) / 16;                   // ... of the projected block that is factorised
-    gcdouble *A = as_global(slot.A);
     DevModel FD_GLOBAL *model = as_global(slot.model);
     unsigned long long st_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     int st_k = 0;
 #define FD_RSTAMP() if (stamps && blockIdx.z == 0 && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps[st_k++] = t_ - st_prev; st_prev = t_; }
     __builtin_amdgcn_s_setprio(3);
 
-    // ---- tile table: column J of the lower triangle top to bottom (I = J .. nbk - 1), then its right-hand-side tile;
-    //      tile q belongs to wave q % 8, slot q / 8
+    // ---- control table (reference :268-287, widened to fp64), status reset, tile table
+    // tile q: column J of the lower triangle top to bottom (I = J .. nbk - 1), then its right-hand-side tile; wave q % 8, slot q / 8
     const int ntiles = nbk * (nbk + 1) / 2 + nbk;
     if (tid < ntiles) {
         int q = tid, J = 0;
@@ -236,67 +308,158 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         const int I = (q == nbk - J) ? kRhsRow : J + q;
         L.tab[tid] = I | (J << 8);
     }
-    // centres, deltas, statistics
-    for (int e = tid; e < 3 * M; e += kRegThreads) {
-        L.cen[e] = as_global(slot.centres)[e];
-        L.F[e] = A[(size_t)(npad + e / M) * lda + e % M];
+    {
+        const float *rest = use_src ? src.rest[blockIdx.z] : slot.rest;
+        const float *delta = use_src ? src.delta[blockIdx.z] : slot.delta;
+        for (int i = tid; i < M; i += kRegThreads) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float r = rest[3 * i + q], d = delta[3 * i + q];
+                L.cen[3 * i + q] = (double)r;
+                L.F[q * kRows + i] = (double)d;
+                slot.centres[3 * i + q] = (double)r;
+                if (use_src) { slot.rest[3 * i + q] = r; slot.delta[3 * i + q] = d; }
+            }
+            slot.radii[i] = gauss_R;
+        }
+        // rows M .. 255 of the O(M) arrays read as zero: the tile phases address whole 16-row blocks without bounds checks
+        for (int e = tid; e < 4 * kRows; e += kRegThreads) {
+            if (e >= 4 * M) { L.V[e] = 0.0; L.W[e] = 0.0; L.B21[e] = 0.0; }
+            if (e < 3 * kRows && e % kRows >= M) L.F[e] = 0.0;
+            if (e < 3 * kRows && e >= 3 * M) L.cen[e] = 0.0;
+        }
     }
-    if (tid == 0) { L.stat[0] = INFINITY; L.stat[1] = 0.0; L.stat[2] = 0.0; }
+    if (tid == 0) { L.stat[0] = INFINITY; L.stat[1] = 0.0; L.stat[2] = 0.0; L.stat[3] = 0.0; L.stat[4] = 0.0; }
     __syncthreads();
-    int tIJ[kSlots];                                 // I | J << 8, wave-uniform (0xffff: no tile)
-#pragma unroll
-    for (int t = 0; t < kSlots; ++t) {
-        const int q = wave + kRegWaves * t;
-        tIJ[t] = __builtin_amdgcn_readfirstlane(q < ntiles ? L.tab[q] : 0xffff);
-    }
-    // (read through an opaque copy: with the coordinates visibly loop-invariant the compiler hoists every tile's LDS
-    // addresses out of the step loop -- 40 more live registers beside the 152 of the tiles, and spills)
-#define tI(t) (opaque_s(tIJ[t]) & 0xff)
-#define tJ(t) (opaque_s(tIJ[t]) >> 8)
+    // Lane t of `ijv` holds the coordinates of the wave's slot t (I | J << 8; 0xffff: no tile).  Which slots a phase touches
+    // is ONE ballot over that register (a 19-bit mask, then a bit test per slot); a slot's coordinates come out with one
+    // v_readlane where its LDS addresses are formed.  (As 19 scalar values they were spilled and re-read, compared and
+    // branched on in every scan: five scans per factorisation step at ~500 cycles each.  Read through an opaque copy: with
+    // the coordinates visibly loop-invariant the compiler hoists every tile's LDS addresses out of the step loop -- 40 more
+    // live registers beside the 152 of the tiles, and spills.)
+    int ijv = 0xffff;
+    if (lane < kSlots && wave + kRegWaves * lane < ntiles) ijv = L.tab[wave + kRegWaves * lane];
+    const int ivI = ijv & 0xff, ivJ = ijv >> 8;
+    auto slots_where = [&](bool cond) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(cond && lane < kSlots)); };
+    const unsigned m_matrix = slots_where(ivI < kMaxBlocks);              // tiles of K (not right-hand sides, not empty)
+#define tI(t) (opaque_s(__builtin_amdgcn_readlane(ijv, t)) & 0xff)
+#define tJ(t) (opaque_s(__builtin_amdgcn_readlane(ijv, t)) >> 8)
+#define FD_SLOT(m, t) (((m) >> (t)) & 1u)
 
-    // ---- K tiles into registers.  S[t][i] = K[16 I + g + 4 i][16 J + c]; read as its transpose K[16 J + c][16 I + g + 4 i]
-    // (the block is symmetric bit for bit for every kernel this path takes), so that 16 lanes read 128 contiguous bytes.
-    double4_t S[kSlots];
-#pragma unroll
-    for (int t = 0; t < kSlots; ++t) {
-        S[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        if (tI(t) < kMaxBlocks) {
+    FD_RSTAMP()
+    // ---- K, tile by tile: element (16 I + g + 4 i, 16 J + c) = phi(|c_row - c_col|^2) (+ lambda on the diagonal).  A ROLLED loop
+    // (one copy of the logarithm) that writes the tiles to a staging area -- the context's matrix buffer, which this build
+    // does not otherwise use: [tile][register][lane], 512 contiguous bytes per store -- while no tile is live in registers yet:
+    // with the 152 registers of the resident tiles carried through this loop it spilled them around every iteration (103 k
+    // cycles).  The tiles come back from L2 by 76 unconditional loads per lane.
+    {
+        gdouble *stage = as_global(slot.A);
+        const double inv_r2 = 1.0 / (gauss_R * gauss_R);
+        double amax_w = 0.0;
+        bool dup = false;
+#pragma nounroll
+        for (int q = wave; q < ntiles; q += kRegWaves) {
+            const int ij = __builtin_amdgcn_readfirstlane(L.tab[q]);
+            const int I = ij & 0xff, J = ij >> 8;
+            if (I >= kMaxBlocks) continue;
+            const int col = 16 * J + c;
+            const double cx = L.cen[3 * col], cy = L.cen[3 * col + 1], cz = L.cen[3 * col + 2];
+            double d2[4], e[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = 16 * tI(t) + g + 4 * i, col = 16 * tJ(t) + c;
-                if (row < M && col < M) S[t][i] = A[(size_t)row * lda + col];
+                const int row = 16 * I + g + 4 * i;
+                const double dx = L.cen[3 * row] - cx, dy = L.cen[3 * row + 1] - cy, dz = L.cen[3 * row + 2] - cz;
+                d2[i] = dx * dx + dy * dy + dz * dz;
+            }
+            if (kind == FD_KERNEL_THIN_PLATE) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = d2[i] > 0.0 ? 0.5 * d2[i] * log_pos(d2[i]) : 0.0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = phi_reg(kind, d2[i], inv_r2);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * I + g + 4 * i;
+                const bool real = row < M && col < M;
+                if (row == col) e[i] += lambda;
+                else if (d2[i] == 0.0 && real) dup = true;                 // coincident centres -> -5
+                if (!real) e[i] = 0.0;
+                const double ae = fabs(e[i]);
+                amax_w = ae > amax_w ? ae : amax_w;
+                stage[((size_t)q * 4 + i) * 64 + lane] = e[i];
+            }
+        }
+        amax_w = wave_max(amax_w);
+        const bool any_dup = __any(dup);
+        if (lane == 0) { L.ypart[wave] = amax_w; L.ypart[kRegWaves + wave] = any_dup ? 1.0 : 0.0; }      // (the overlay is free until Y = K V)
+    }
+    __threadfence_block();
+    __syncthreads();
+    FD_RSTAMP()
+    double4_t S[kSlots];
+    {
+        gcdouble *stage = as_global(slot.A);
+#pragma unroll
+        for (int t = 0; t < kSlots; ++t) {
+            const int q = wave + kRegWaves * t;
+            S[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            if (FD_SLOT(m_matrix, t)) {                      // (a wave reads back what it stored itself)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S[t][i] = stage[((size_t)q * 4 + i) * 64 + lane];
             }
         }
     }
+    double amax = 0.0;
+    bool dup_any = false;
+#pragma unroll
+    for (int w = 0; w < kRegWaves; ++w) { amax = L.ypart[w] > amax ? L.ypart[w] : amax; dup_any = dup_any || L.ypart[kRegWaves + w] != 0.0; }
+    __syncthreads();
     FD_RSTAMP()
 
-    // ---- reflectors of P = [1 x y z] (dlarfg upside down: reflector k acts on rows 0 .. M-1-k, beta in row M-1-k)
-    bool singular = false;
-    if (T > 0) {
-        const int i = tid;
+    // ---- reflectors of P = [1 x y z] (dlarfg upside down: reflector k acts on rows 0 .. M-1-k, beta in row M-1-k) with
+    // f <- Q^T f folded into the same sweep: ONE wave, four rows per lane, every sum a DPP reduction -- no barrier inside.
+    if (T > 0 && wave == 0) {
+        bool singular = false;
         double cn[4] = {0.0, 0.0, 0.0, 0.0};
-        if (i < M) {
-            const double p[4] = {1.0, L.cen[3 * i], L.cen[3 * i + 1], L.cen[3 * i + 2]};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const double v = t < T ? p[t] : 0.0;
-                L.V[4 * i + t] = v;
-                cn[t] = v * v;
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i < M) {
+                const double p[4] = {1.0, L.cen[3 * i], L.cen[3 * i + 1], L.cen[3 * i + 2]};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double v = t < T ? p[t] : 0.0;
+                    L.V[4 * i + t] = v;
+                    cn[t] = fma(v, v, cn[t]);
+                }
             }
         }
-        wg_sum<4>(cn, L.red, tid);              // its barriers also publish V
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cn[t] = wave_sum(cn[t]);
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k >= T) break;
             const int piv = M - 1 - k;
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            if (i < piv) {
-                const double x = L.V[4 * i + k];
-                acc[0] = x * x;
+            // sigma, x . column c (c > k), x . f_c over the rows above the pivot
+            double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double x[4], fr[4][3];
 #pragma unroll
-                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) acc[cc - k] = x * L.V[4 * i + cc];
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q;
+                x[q] = 0.0; fr[q][0] = fr[q][1] = fr[q][2] = 0.0;
+                if (i < piv) {
+                    x[q] = L.V[4 * i + k];
+                    acc[0] = fma(x[q], x[q], acc[0]);
+#pragma unroll
+                    for (int cc = k + 1; cc < 4; ++cc) if (cc < T) acc[cc - k] = fma(x[q], L.V[4 * i + cc], acc[cc - k]);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { fr[q][e] = L.F[e * kRows + i]; acc[4 + e] = fma(x[q], fr[q][e], acc[4 + e]); }
+                }
             }
-            wg_sum<4>(acc, L.red, tid);
+#pragma unroll
+            for (int e = 0; e < 7; ++e) acc[e] = wave_sum(acc[e]);
             const double xp = L.V[4 * piv + k];
             const double sigma = acc[0];
             const double norm = sqrt(fma(xp, xp, sigma));
@@ -307,17 +470,25 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 scale = 1.0 / (xp - beta);
             }
             if (!(norm > 64.0 * (double)M * kEps * sqrt(cn[k]))) singular = true;   // P has no full column rank (NaN too)
-            double sc[4] = {0.0, 0.0, 0.0, 0.0}, prow[4] = {0.0, 0.0, 0.0, 0.0};
+            double sc[4] = {0.0, 0.0, 0.0, 0.0}, prow[4] = {0.0, 0.0, 0.0, 0.0}, df[3];
 #pragma unroll
             for (int cc = k + 1; cc < 4; ++cc) if (cc < T) { prow[cc] = L.V[4 * piv + cc]; sc[cc] = fma(scale, acc[cc - k], prow[cc]); }
-            __syncthreads();                     // everyone has read the pivot row
-            if (i < piv) {
-                const double v = L.V[4 * i + k] * scale;
-                L.V[4 * i + k] = v;
 #pragma unroll
-                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) L.V[4 * i + cc] = fma(-tau * sc[cc], v, L.V[4 * i + cc]);
+            for (int e = 0; e < 3; ++e) df[e] = fma(scale, acc[4 + e], L.F[e * kRows + piv]);       // v . f_e (v_piv = 1)
+            wave_lds_sync();                      // everyone has read the pivot row
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q;
+                if (i < piv) {
+                    const double v = x[q] * scale;
+                    L.V[4 * i + k] = v;
+#pragma unroll
+                    for (int cc = k + 1; cc < 4; ++cc) if (cc < T) L.V[4 * i + cc] = fma(-tau * sc[cc], v, L.V[4 * i + cc]);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) L.F[e * kRows + i] = fma(-tau * df[e], v, fr[q][e]);
+                }
             }
-            if (tid == 0) {
+            if (lane == 0) {
                 L.small[kTau + k] = tau;
                 L.small[kR + 4 * k + k] = beta;
                 L.V[4 * piv + k] = 1.0;
@@ -326,17 +497,26 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                     L.small[kR + 4 * k + cc] = fma(-tau, sc[cc], prow[cc]);
                     L.V[4 * piv + cc] = 0.0;
                 }
+                // the pivot row's share of Q^T f belongs to the polynomial equations: aside, and zero in the Cholesky's right-hand side
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { L.small[kG + 3 * k + e] = fma(-tau, df[e], L.F[e * kRows + piv]); L.F[e * kRows + piv] = 0.0; }
             }
-            __syncthreads();
+            wave_lds_sync();
         }
         // compact WY factor from the Gram matrix of V
         double gram[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (i < M) {
-            const double v0 = L.V[4 * i], v1 = L.V[4 * i + 1], v2 = L.V[4 * i + 2], v3 = L.V[4 * i + 3];
-            gram[0] = v0 * v1; gram[1] = v0 * v2; gram[2] = v0 * v3; gram[3] = v1 * v2; gram[4] = v1 * v3; gram[5] = v2 * v3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i < M) {
+                const double v0 = L.V[4 * i], v1 = L.V[4 * i + 1], v2 = L.V[4 * i + 2], v3 = L.V[4 * i + 3];
+                gram[0] = fma(v0, v1, gram[0]); gram[1] = fma(v0, v2, gram[1]); gram[2] = fma(v0, v3, gram[2]);
+                gram[3] = fma(v1, v2, gram[3]); gram[4] = fma(v1, v3, gram[4]); gram[5] = fma(v2, v3, gram[5]);
+            }
         }
-        wg_sum<6>(gram, L.red, tid);
-        if (tid == 0) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) gram[e] = wave_sum(gram[e]);
+        {
             // (fully unrolled on purpose: a small matrix indexed by run-time loop counters lives in scratch memory)
             const double G[4][4] = {{0.0, gram[0], gram[1], gram[2]}, {0.0, 0.0, gram[3], gram[4]}, {0.0, 0.0, 0.0, gram[5]}, {0.0, 0.0, 0.0, 0.0}};
             double Tm[4][4] = {};
@@ -352,175 +532,172 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                     Tm[a][k] = -tau * v;
                 }
             }
+            if (lane == 0) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) L.small[kTm + 4 * a + b] = Tm[a][b];
+                    for (int b = 0; b < 4; ++b) L.small[kTm + 4 * a + b] = Tm[a][b];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (k >= T) L.small[kTau + k] = 0.0;
-        }
-        __syncthreads();
-        // f <- Q^T f; the pivot rows' values go aside (they belong to the polynomial equations)
-        for (int k = 0; k < T; ++k) {
-            const int piv = M - 1 - k;
-            const double tau = L.small[kTau + k];
-            double d[3] = {0.0, 0.0, 0.0};
-            double v = 0.0;
-            if (i <= piv) {
-                v = L.V[4 * i + k];
-                d[0] = v * L.F[i]; d[1] = v * L.F[M + i]; d[2] = v * L.F[2 * M + i];
+                for (int k = 0; k < 4; ++k) if (k >= T) L.small[kTau + k] = 0.0;
+                L.stat[3] = singular ? 1.0 : 0.0;
             }
-            wg_sum<3>(d, L.red, tid);
-            if (i <= piv) {
-                L.F[i] = fma(-tau * d[0], v, L.F[i]); L.F[M + i] = fma(-tau * d[1], v, L.F[M + i]); L.F[2 * M + i] = fma(-tau * d[2], v, L.F[2 * M + i]);
-            }
-            __syncthreads();
         }
-        if (tid < T) {
-            const int piv = M - 1 - tid;
-            L.small[kG + 3 * tid] = L.F[piv]; L.small[kG + 3 * tid + 1] = L.F[M + piv]; L.small[kG + 3 * tid + 2] = L.F[2 * M + piv];
-        }
-        FD_RSTAMP()
+    }
+    // per-wave partial sums of Y, zeroed meanwhile (every wave its own)
+    double *yp = L.ypart + (size_t)wave * 4 * kRows;
+    if (T > 0) for (int e = lane; e < 4 * kRows; e += 64) yp[e] = 0.0;
+    __syncthreads();
+    FD_RSTAMP()
 
-        // ---- Y = K V from the tiles: per-wave partial sums in LDS, added up in a fixed order.  A tile in the accumulator
-        // layout IS the A operand of K_IJ^T Z (slice i = rows 4 i .. 4 i + 3 of K_IJ): that gives block J of Y its share from
-        // block I; the share of block I from block J needs K_IJ itself as the operand: through the wave's LDS scratch.
-        double *yp = L.ypart + (size_t)wave * 4 * M;
-        for (int e = lane; e < 4 * M; e += 64) yp[e] = 0.0;
-        double *scr = L.scr + (size_t)wave * kTileLds;
-        wave_lds_sync();
+    if (T > 0) {
+        // ---- Y = K V from the tiles, into per-wave partial sums (LDS adds without return: fire and forget; one wave adds
+        // to its own array in program order, and the arrays are summed in a fixed order: deterministic).  A tile in the
+        // accumulator layout IS the A operand of K_IJ^T Z (slice i = rows 4 i .. 4 i + 3 of K_IJ): that gives block J of Y its
+        // share from block I; the share of block I from block J needs K_IJ itself as the operand: through LDS, two buffers
+        // in turn so that a tile's transposition does not wait for the previous one's reads.
+        double *scr0 = L.scr + (size_t)wave * 2 * kTileLds;
 #pragma unroll
         for (int t = 0; t < kSlots; ++t) {
-            if (tI(t) >= kMaxBlocks) continue;
+            if (!FD_SLOT(m_matrix, t)) continue;
             const int I = tI(t), J = tJ(t);
+            double *sb = scr0 + (t & 1) * kTileLds;
+            if (I != J) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sb[(g + 4 * i) * kPitch + c] = S[t][i];
+            }
             {   // K_JI V_I -> rows of block J
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const int r = 16 * I + 4 * s + g;
-                    const double b = (c < 4 && r < M) ? L.V[4 * r + c] : 0.0;
+                    const double b = c < 4 ? L.V[4 * (16 * I + 4 * s + g) + c] : 0.0;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[t][s], b, acc, 0, 0, 0);
                 }
                 if (c < 4) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { const int r = 16 * J + g + 4 * i; if (r < M) yp[4 * r + c] += acc[i]; }
+                    for (int i = 0; i < 4; ++i)
+                        __hip_atomic_fetch_add(&yp[4 * (16 * J + g + 4 * i) + c], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             if (I != J) {   // K_IJ V_J -> rows of block I
-#pragma unroll
-                for (int i = 0; i < 4; ++i) scr[(g + 4 * i) * kPitch + c] = S[t][i];
                 wave_lds_sync();
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const double a = scr[c * kPitch + 4 * s + g];
-                    const int r = 16 * J + 4 * s + g;
-                    const double b = (c < 4 && r < M) ? L.V[4 * r + c] : 0.0;
+                    const double a = sb[c * kPitch + 4 * s + g];
+                    const double b = c < 4 ? L.V[4 * (16 * J + 4 * s + g) + c] : 0.0;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                 }
-                wave_lds_sync();
                 if (c < 4) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { const int r = 16 * I + g + 4 * i; if (r < M) yp[4 * r + c] += acc[i]; }
+                    for (int i = 0; i < 4; ++i)
+                        __hip_atomic_fetch_add(&yp[4 * (16 * I + g + 4 * i) + c], acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            wave_lds_sync();
         }
         __syncthreads();
-        for (int e = tid; e < 4 * M; e += kRegThreads) {
+        for (int e = tid; e < 4 * kRows; e += kRegThreads) {
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < kRegWaves; ++w) s += L.ypart[(size_t)w * 4 * M + e];
+            for (int w = 0; w < kRegWaves; ++w) s += L.ypart[(size_t)w * 4 * kRows + e];
             L.W[e] = s;                             // Y for now
         }
         __syncthreads();
         FD_RSTAMP()
 
-        // ---- W = Y Tm - (1/2) V G,  G = Tm^T sym(V^T Y) Tm
-        {
+        // ---- G = Tm^T sym(V^T Y) Tm on one wave; then W = Y Tm - (1/2) V G, a row per thread
+        if (wave == 0) {
             double Sm[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) Sm[q] = 0.0;
-            if (i < M) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q;
+                if (i < M) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) Sm[4 * a + b] = L.V[4 * i + a] * L.W[4 * i + b];
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) Sm[4 * a + b] = fma(L.V[4 * i + a], L.W[4 * i + b], Sm[4 * a + b]);
+                }
             }
-            wg_sum<16>(Sm, L.red, tid);
-            if (tid == 0) {
-                double Tm[16], ST[16], Gm[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) Tm[q] = L.small[kTm + q];
+            for (int q = 0; q < 16; ++q) Sm[q] = wave_sum(Sm[q]);
+            double Tm[16], ST[16], Gm[16];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+            for (int q = 0; q < 16; ++q) Tm[q] = L.small[kTm + q];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) v = fma(0.5 * (Sm[4 * a + cc] + Sm[4 * cc + a]), Tm[4 * cc + b], v);
-                        ST[4 * a + b] = v;
-                    }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) v = fma(Tm[4 * cc + a], ST[4 * cc + b], v);
-                        Gm[4 * a + b] = v;
-                    }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = a + 1; b < 4; ++b) { const double m = 0.5 * (Gm[4 * a + b] + Gm[4 * b + a]); Gm[4 * a + b] = m; Gm[4 * b + a] = m; }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) L.small[kGm + q] = Gm[q];
-            }
-            __syncthreads();
-            if (i < M) {
-                double y[4], v[4], w[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { y[t] = L.W[4 * i + t]; v[t] = L.V[4 * i + t]; }
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    double z = 0.0, h = 0.0;
+                    double v = 0.0;
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) { z = fma(y[a], L.small[kTm + 4 * a + b], z); h = fma(v[a], L.small[kGm + 4 * a + b], h); }
-                    w[b] = fma(-0.5, h, z);
+                    for (int cc = 0; cc < 4; ++cc) v = fma(0.5 * (Sm[4 * a + cc] + Sm[4 * cc + a]), Tm[4 * cc + b], v);
+                    ST[4 * a + b] = v;
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) L.W[4 * i + t] = w[t];
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) v = fma(Tm[4 * cc + a], ST[4 * cc + b], v);
+                    Gm[4 * a + b] = v;
+                }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a + 1; b < 4; ++b) { const double m = 0.5 * (Gm[4 * a + b] + Gm[4 * b + a]); Gm[4 * a + b] = m; Gm[4 * b + a] = m; }
+            if (lane < 16) {
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v = lane == q ? Gm[q] : v;
+                L.small[kGm + lane] = v;
             }
-            __syncthreads();
         }
+        __syncthreads();
+        if (tid < kRows) {
+            const int i = tid;
+            double y[4], v[4], w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { y[t] = L.W[4 * i + t]; v[t] = L.V[4 * i + t]; }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                double z = 0.0, h = 0.0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { z = fma(y[a], L.small[kTm + 4 * a + b], z); h = fma(v[a], L.small[kGm + 4 * a + b], h); }
+                w[b] = fma(-0.5, h, z);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) L.W[4 * i + t] = w[t];
+        }
+        __syncthreads();
 
         // ---- B = K - V W^T - W V^T on the tiles in place (two K = 4 matrix instructions per tile)
 #pragma unroll
         for (int t = 0; t < kSlots; ++t) {
-            if (tI(t) >= kMaxBlocks) continue;
+            if (!FD_SLOT(m_matrix, t)) continue;
             const int ri = 16 * tI(t) + c, rj = 16 * tJ(t) + c;
-            const double vi = ri < M ? L.V[4 * ri + g] : 0.0, wi = ri < M ? L.W[4 * ri + g] : 0.0;
-            const double vj = rj < M ? L.V[4 * rj + g] : 0.0, wj = rj < M ? L.W[4 * rj + g] : 0.0;
+            const double vi = L.V[4 * ri + g], wi = L.W[4 * ri + g];
+            const double vj = L.V[4 * rj + g], wj = L.W[4 * rj + g];
             S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-vi, wj, S[t], 0, 0, 0);
             S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi, vj, S[t], 0, 0, 0);
         }
     }
     // ---- B21 aside (pivot row M-1-k = equation of polynomial coefficient k), identity padding beyond n1, right-hand-side tiles
+    const unsigned m_rhs = slots_where(ivI == kRhsRow);
 #pragma unroll
     for (int t = 0; t < kSlots; ++t) {
-        if (tI(t) < kMaxBlocks) {
+        if (FD_SLOT(m_matrix, t)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = 16 * tI(t) + g + 4 * i, col = 16 * tJ(t) + c;
                 if (row >= n1 && row < M && col < n1) L.B21[4 * col + (M - 1 - row)] = S[t][i];
                 if (row >= n1 || col >= n1) S[t][i] = row == col ? 1.0 : 0.0;
             }
-        } else if (tI(t) == kRhsRow) {
+        } else if (FD_SLOT(m_rhs, t)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rhs = g + 4 * i, col = 16 * tJ(t) + c;
-                S[t][i] = (rhs < 3 && col < n1) ? L.F[rhs * M + col] : 0.0;
+                S[t][i] = (rhs < 3 && col < n1) ? L.F[rhs * kRows + col] : 0.0;
             }
         }
     }
@@ -528,52 +705,73 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     FD_RSTAMP()
 
     // ---- blocked Cholesky, 16 columns per step, right-hand sides as tile row 16
-    const double amax = __longlong_as_double((long long)model->amax_bits);
     const double tiny = (double)n1 * kEps * amax;
-    double *scr = L.scr + (size_t)wave * kTileLds;
+    double *scr = L.scr + (size_t)wave * 2 * kTileLds;
+    PivotStats pst = {INFINITY, 0.0, false};
     for (int K = 0; K < nb; ++K) {
-        // (i) the owner of the diagonal tile: factor + inverse (its tile is up to date: it applied every earlier panel itself)
-        bool mine = false;
+        // (i) the owner of the diagonal tile: factor + inverse, in its registers (its tile is up to date: it applied every
+        //     earlier panel itself); the inverse goes to LDS for everybody's panel solves and for the back substitution
+        //     (ONE copy of the routine: inlined into the slot loop it was nineteen, and the kernel outgrew the instruction cache)
+        const bool active = ivI < nb || ivI == kRhsRow;       // (tiles outside the projected block: pivot rows only, done with)
+        const unsigned m_diag = slots_where(ivI == K && ivJ == K);
+        const unsigned m_panel = slots_where(ivJ == K && ivI > K && active);
+        const unsigned m_update = slots_where(ivJ > K && ivJ < nb && active);
+        double4_t Td = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < kSlots; ++t) {
-            if (tI(t) == K && tJ(t) == K) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) L.D[(g + 4 * i) * kPitch + c] = S[t][i];
-                mine = true;
-            }
+            if (FD_SLOT(m_diag, t)) Td = S[t];
         }
-        if (mine) {
-            wave_lds_sync();
+        if (m_diag != 0u) {
             const int live = n1 - 16 * K < 16 ? n1 - 16 * K : 16;
-            factor_invert_16(L.D, L.line, L.minv + (size_t)K * kTileLds, tiny, live, L.stat, lane);
+            const double4_t U = factor_invert_tile(Td, tiny, live, pst, lane);
+            double *dst = L.minv + (size_t)K * kTileLds;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = U[i];
         }
         __syncthreads();
+        if (stamps && blockIdx.z == 0 && tid == 0) stamps[16 + 3 * K] = __builtin_amdgcn_s_memtime() - st_prev;
         // (ii) the tiles below it (and the right-hand sides): L_IK = C_IK inv(L_KK)^T; into the panel buffer
         const double *mk = L.minv + (size_t)K * kTileLds;
         double bop[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) bop[s] = mk[c * kPitch + 4 * s + g];         // B[k][n] = inv[n][4 s + k]
+        // (a tile's own slot of the panel buffer is its transposition buffer: all of a wave's tiles go in at once, are read
+        // back as operands at once -- independent matrix-instruction chains the scheduler can interleave -- and are replaced
+        // by the results)
 #pragma unroll
         for (int t = 0; t < kSlots; ++t) {
-            if (tJ(t) == K && tI(t) > K && (tI(t) < nb || tI(t) == kRhsRow)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) scr[(g + 4 * i) * kPitch + c] = S[t][i];
-                wave_lds_sync();
-                double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(scr[c * kPitch + 4 * s + g], bop[s], acc, 0, 0, 0);
-                wave_lds_sync();
-                S[t] = acc;
+            if (FD_SLOT(m_panel, t)) {
                 double *dst = L.P + (size_t)tI(t) * kTileLds;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = acc[i];
+                for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = S[t][i];
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < kSlots; ++t) {
+            if (FD_SLOT(m_panel, t)) {
+                const double *sb = L.P + (size_t)tI(t) * kTileLds;
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[c * kPitch + 4 * s + g], bop[s], acc, 0, 0, 0);
+                S[t] = acc;
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < kSlots; ++t) {
+            if (FD_SLOT(m_panel, t)) {
+                double *dst = L.P + (size_t)tI(t) * kTileLds;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = S[t][i];
             }
         }
         __syncthreads();
+        if (stamps && blockIdx.z == 0 && tid == 0) stamps[17 + 3 * K] = __builtin_amdgcn_s_memtime() - st_prev;
         // (iii) trailing update C_IJ -= L_IK L_JK^T for every tile right of the panel
 #pragma unroll
         for (int t = 0; t < kSlots; ++t) {
-            if (tJ(t) > K && tJ(t) < nb && (tI(t) < nb || tI(t) == kRhsRow)) {
+            if (FD_SLOT(m_update, t)) {
                 const double *pa = L.P + (size_t)tI(t) * kTileLds, *pb = L.P + (size_t)tJ(t) * kTileLds;
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -581,17 +779,30 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             }
         }
         // (no barrier: the next panel's tiles are written only after the barrier that follows the next diagonal block)
+        if (stamps && blockIdx.z == 0 && tid == 0) stamps[18 + 3 * K] = __builtin_amdgcn_s_memtime() - st_prev;
+    }
+    if (lane == 0 && (pst.pmax > 0.0 || pst.pmin < INFINITY || pst.singular)) {
+        // (the owners of the diagonal tiles differ from step to step: min / max through LDS atomics on the bit patterns
+        // of non-negative doubles, which order like the values)
+        __hip_atomic_fetch_min((unsigned long long *)&L.stat[0], (unsigned long long)__double_as_longlong(pst.pmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max((unsigned long long *)&L.stat[1], (unsigned long long)__double_as_longlong(pst.pmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (pst.singular) L.stat[2] = 1.0;
     }
     FD_RSTAMP()
 
-    // ---- y^T L = z^T, bottom up, right-looking: one row of tiles per step (a tile is its own B operand)
+    // ---- y^T L = z^T, bottom up, right-looking: one row of tiles per step (a tile is its own B operand).  The wave that owns
+    // tile (I, I - 1) subtracts its share from block I - 1 and solves that block right away -- every other contribution to it
+    // came before an earlier barrier -- so a step costs one barrier.
+    {
+        const unsigned m_z = slots_where(ivI == kRhsRow && ivJ < nb);
 #pragma unroll
-    for (int t = 0; t < kSlots; ++t) {
-        if (tI(t) == kRhsRow && tJ(t) < nb && g < 3) L.Z[g * 256 + 16 * tJ(t) + c] = S[t][0];
+        for (int t = 0; t < kSlots; ++t) {
+            if (FD_SLOT(m_z, t) && g < 3) L.Z[g * 256 + 16 * tJ(t) + c] = S[t][0];
+        }
     }
     __syncthreads();
-    for (int I = nb - 1; I >= 0; --I) {
-        if (wave == 0 && lane < 48) {
+    auto solve_block = [&](int I) {                   // Y_I = Z_I inv(L_II): lanes 0..47 = (right-hand side, column)
+        if (lane < 48) {
             const int rhs = lane >> 4, n = lane & 15;
             const double *mi = L.minv + (size_t)I * kTileLds;
             double y = 0.0;
@@ -599,10 +810,15 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             for (int k = 0; k < 16; ++k) y = fma(L.Z[rhs * 256 + 16 * I + k], mi[k * kPitch + n], y);
             L.Y[rhs * 256 + 16 * I + n] = y;
         }
-        __syncthreads();
+    };
+    if (wave == 0 && nb > 0) solve_block(nb - 1);
+    __syncthreads();
+    for (int I = nb - 1; I >= 1; --I) {
+        const unsigned m_row = slots_where(ivI == I && ivJ < I);
+        const bool next_mine = slots_where(ivI == I && ivJ == I - 1) != 0u;
 #pragma unroll
         for (int t = 0; t < kSlots; ++t) {
-            if (tI(t) == I && tJ(t) < I) {
+            if (FD_SLOT(m_row, t)) {
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -612,70 +828,88 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 if (g < 3) L.Z[g * 256 + 16 * tJ(t) + c] -= acc[0];
             }
         }
+        if (next_mine) { wave_lds_sync(); solve_block(I - 1); }
         __syncthreads();
     }
     FD_RSTAMP()
 
-    // ---- R a = g - B21 y;  w = Q [y; 0] = H_0 .. H_{T-1} [y; 0]  (x lives where f did)
-    {
-        const int i = tid;
-        gdouble *X = as_global(slot.X);
-        double q[12];
+    // ---- R a = g - B21 y;  w = Q [y; 0] = H_0 .. H_{T-1} [y; 0]: one wave again
+    if (wave == 0) {
+        double q12[12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) q[e] = 0.0;
-        if (i < n1 && T > 0) {
-            const double y0 = L.Y[i], y1 = L.Y[256 + i], y2 = L.Y[512 + i];
+        for (int e = 0; e < 12; ++e) q12[e] = 0.0;
+        double xr[4][3];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double b = k < T ? L.B21[4 * i + k] : 0.0;
-                q[3 * k] = b * y0; q[3 * k + 1] = b * y1; q[3 * k + 2] = b * y2;
-            }
-        }
-        wg_sum<12>(q, L.red, tid);
-        if (tid < 3) {                               // R a = g - B21 y: output tid, upper triangular in (k, c)
-            double a[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 3; k >= 0; --k) {
-                if (k >= T) continue;
-                double v = L.small[kG + 3 * k + tid] - q[3 * k + tid];
-#pragma unroll
-                for (int c2 = k + 1; c2 < 4; ++c2) if (c2 < T) v = fma(-L.small[kR + 4 * k + c2], a[c2], v);
-                a[k] = v / L.small[kR + 4 * k + k];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) L.small[kAc + 3 * k + tid] = a[k];
-        }
-        if (i < M) {
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
             const bool in = i < n1;
-            L.F[i] = in ? L.Y[i] : 0.0; L.F[M + i] = in ? L.Y[256 + i] : 0.0; L.F[2 * M + i] = in ? L.Y[512 + i] : 0.0;
+            xr[q][0] = in ? L.Y[i] : 0.0; xr[q][1] = in ? L.Y[256 + i] : 0.0; xr[q][2] = in ? L.Y[512 + i] : 0.0;
+            if (in && T > 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double b = k < T ? L.B21[4 * i + k] : 0.0;
+                    q12[3 * k] = fma(b, xr[q][0], q12[3 * k]); q12[3 * k + 1] = fma(b, xr[q][1], q12[3 * k + 1]); q12[3 * k + 2] = fma(b, xr[q][2], q12[3 * k + 2]);
+                }
+            }
         }
-        __syncthreads();
-        for (int k = T - 1; k >= 0; --k) {
+        if (T > 0) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) q12[e] = wave_sum(q12[e]);
+        }
+        // R a = g - B21 y: upper triangular in (k, c); every lane the same values
+        double a[4][3] = {};
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            if (k >= T) continue;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                double v = L.small[kG + 3 * k + e] - q12[3 * k + e];
+#pragma unroll
+                for (int c2 = k + 1; c2 < 4; ++c2) if (c2 < T) v = fma(-L.small[kR + 4 * k + c2], a[c2][e], v);
+                a[k][e] = v / L.small[kR + 4 * k + k];
+            }
+        }
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            if (k >= T) continue;
             const int piv = M - 1 - k;
             const double tau = L.small[kTau + k];
-            double d[3] = {0.0, 0.0, 0.0};
-            double v = 0.0;
-            if (i <= piv) {
-                v = L.V[4 * i + k];
-                d[0] = v * L.F[i]; d[1] = v * L.F[M + i]; d[2] = v * L.F[2 * M + i];
+            double d[3] = {0.0, 0.0, 0.0}, v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q;
+                v[q] = i <= piv ? L.V[4 * i + k] : 0.0;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) d[e] = fma(v[q], xr[q][e], d[e]);
             }
-            wg_sum<3>(d, L.red, tid);
-            if (i <= piv) {
-                L.F[i] = fma(-tau * d[0], v, L.F[i]); L.F[M + i] = fma(-tau * d[1], v, L.F[M + i]); L.F[2 * M + i] = fma(-tau * d[2], v, L.F[2 * M + i]);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) d[e] = wave_sum(d[e]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) xr[q][e] = fma(-tau * d[e], v[q], xr[q][e]);
+        }
+        gdouble *X = as_global(slot.X);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i < M) { X[i] = xr[q][0]; X[(size_t)npad + i] = xr[q][1]; X[2 * (size_t)npad + i] = xr[q][2]; }
+        }
+        for (int r = M + lane; r < npad; r += 64) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v = (r - M == k && k < T) ? a[k][e] : v;
+                X[(size_t)e * npad + r] = v;
             }
-            __syncthreads();
         }
-        for (int e = tid; e < 3 * npad; e += kRegThreads) {
-            const int cc = e / npad, r = e % npad;
-            double v = 0.0;
-            if (r < M) v = L.F[cc * M + r];
-            else if (r < M + T) v = L.small[kAc + 3 * (r - M) + cc];
-            X[e] = v;
-        }
-        if (tid == 0) {
-            const bool sing = singular || L.stat[2] != 0.0;
-            if (sing) model->sing_flag = 1;
+        if (lane == 0) {
+            model->terminationtype = 0;
+            model->dup_flag = dup_any ? 1 : 0;
+            model->sing_flag = (L.stat[2] != 0.0 || L.stat[3] != 0.0) ? 1 : 0;
             model->iterations = M + T;
+            model->amax_bits = (unsigned long long)__double_as_longlong(amax);
             model->pivmin_bits = (unsigned long long)__double_as_longlong(L.stat[0]);
             model->pivmax_bits = (unsigned long long)__double_as_longlong(L.stat[1]);
         }
@@ -695,6 +929,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
 #undef FD_RSTAMP
 #undef tI
 #undef tJ
+#undef FD_SLOT
 }
 
 }  // namespace
@@ -704,7 +939,7 @@ bool reg_applicable(int kind, int term, double lambda, int M)
     return M <= 16 * kMaxBlocks && spd_applicable(kind, term, lambda, M);
 }
 
-// Once per device, OUTSIDE any stream capture (the C ABI calls it before it captures a build): the kernel's dynamic LDS limit
+// Once per device, OUTSIDE any stream capture (the C ABI calls it before it enqueues a build): the kernel's dynamic LDS limit
 // is a per-device property.  (The packing code has a little static LDS of its own: the dynamic limit leaves room for it.)
 hipError_t reg_build_init()
 {
@@ -719,28 +954,28 @@ hipError_t reg_build_init()
     return e;
 }
 
-// everything after k_prepare
-hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid)
+// The WHOLE build, control table included: one launch.  src == nullptr: the contexts' own copies of the control points.
+hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const PointSrc *src, hipEvent_t ev_mid)
 {
+    static const PointSrc none{};
     const unsigned nbatch = (unsigned)b.nbatch;
-    const int M = b.M, T = b.T;
-    hipError_t e = launch_assemble_block(b, stream, round_up(M, 32));
-    if (e != hipSuccess) return e;
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
-    const size_t lds = sizeof(double) * reg_lds_doubles(M);
-    // (diagnostics: phase stamps, only outside stream capture -- FD_NO_GRAPH=1 FD_REG_STAMPS=1)
+    const size_t lds = sizeof(double) * reg_lds_doubles(b.M);
+    // (diagnostics: phase stamps, only outside stream capture -- FD_REG_STAMPS=1)
     static unsigned long long *d_stamps = nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     static const bool stamps_env = getenv("FD_REG_STAMPS") != nullptr;
     const bool want_stamps = stamps_env && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-    if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 32 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 32 * sizeof(unsigned long long)); }
-    hipLaunchKernelGGL(k_build_reg, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, M, T, b.npad, b.lda, b.kind, b.Mpad,
-                       want_stamps ? d_stamps : nullptr);
+    if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 80 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 80 * sizeof(unsigned long long)); }
+    hipLaunchKernelGGL(k_build_reg, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,
+                       b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, want_stamps ? d_stamps : nullptr);
     if (want_stamps && d_stamps) {
-        unsigned long long h[32];
+        unsigned long long h[80];
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            fprintf(stderr, "[k_build_reg stamps, shader cycles: load | reflectors + Q^T f | Y = K V | W + rotation + B21 | Cholesky | back substitution | recovery | pack]\n  ");
-            for (int q = 0; q < 8; ++q) fprintf(stderr, " %llu", h[q]);
+            fprintf(stderr, "[k_build_reg stamps, shader cycles: table | assembly | tile loads | reflectors + Q^T f | Y = K V | W + rotation + B21 | Cholesky | back substitution | recovery | pack]\n  ");
+            for (int q = 0; q < 10; ++q) fprintf(stderr, " %llu", h[q]);
+            fprintf(stderr, "\n   Cholesky steps (cycles since its start: after the diagonal block | after the panel | after the update, as wave 0 sees them):");
+            for (int q = 16; q < 64; ++q) fprintf(stderr, "%s%llu", (q - 16) % 3 ? " " : "\n     ", h[q]);
             fprintf(stderr, "\n");
         }
     }

@@ -679,6 +679,25 @@ int fd_build_async(fd_ctx *ctx)
         ctx->sticky_rc = FD_OK;
         return post_status(ctx, st);
     }
+    if (b.reg) {
+        // the register-resident build is ONE launch, control table included: nothing to capture, nothing to prepare
+        hipStream_t st = cur_stream(ctx);
+        FD_HIP(ctx, hipEventRecord(ctx->ev0, st));
+        FD_HIP(ctx, launch_build_reg(b, st, nullptr, ctx->ev_mid));
+        FD_HIP(ctx, hipEventRecord(ctx->ev1, st));
+        ctx->wait_event = ctx->ev1; ctx->wait_stream = st; ctx->wait_batch = nullptr;
+        ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
+        ctx->have_factor = true;          // (fd_set_deltas is allowed: it builds again, see above)
+        ctx->last_spd = true; ctx->last_reg = true;
+        ctx->factor_grouped = false;
+        ctx->deltas_only = false;
+        ctx->build_pending = true;
+        ++ctx->model_gen;
+        ctx->built = false;
+        ctx->have_report = false;
+        ctx->sticky_rc = FD_OK;
+        return post_status(ctx, st);
+    }
     if (make_lookahead(&ctx->lu_stream, ctx->lu_events)) {
         b.aux_stream = ctx->lu_stream;
         for (int q = 0; q < 4; ++q) b.aux_events[q] = ctx->lu_events[q];
@@ -1487,7 +1506,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     fd_batch::Key key{};
     key.M = c0->M; key.kind = c0->kind; key.term = c0->term | (bb.spd << 9) | (bb.small << 10) | (bb.reg << 11); key.nparams = c0->nparams;
     memcpy(key.params, c0->params, sizeof(key.params));
-    if (b->use_graph && (!b->exec || memcmp(&key, &b->key, sizeof(key)) != 0)) {
+    if (!bb.reg && b->use_graph && (!b->exec || memcmp(&key, &b->key, sizeof(key)) != 0)) {
         if (b->exec) { (void)hipGraphExecDestroy(b->exec); b->exec = nullptr; }
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
@@ -1507,6 +1526,11 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         if (e_ != hipSuccess) { batch_err(b, "%s failed: %s", #call, hipGetErrorString(e_)); return FD_E_DEVICE; } \
     } while (0)
     FD_BHIP(hipEventRecord(b->ev0, stream));
+    if (bb.reg) {
+        // one launch, one workgroup per model, control table included
+        FD_BHIP(launch_build_reg(bb, stream, b->have_src ? &b->src : nullptr, b->ev_mid));
+        b->have_src = false;
+    } else {
     // the control points are kernel arguments (they change every call), so k_prepare stays
     // outside the captured graph
     FD_BHIP(launch_prepare(bb, stream, b->have_src ? &b->src : nullptr));
@@ -1516,6 +1540,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         FD_BHIP(hipGraphLaunch(b->exec, stream));
     } else {
         FD_BHIP(launch_build(bb, stream, b->ev_mid));
+    }
     }
     FD_BHIP(hipEventRecord(b->ev1, stream));
     b->waited_stream = nullptr;

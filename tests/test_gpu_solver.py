@@ -310,22 +310,17 @@ def test_a_repaired_build_is_ordered_before_evaluations_on_other_streams(hip_lib
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
     e.set_stream(None); e.close()
-    # a batch (thin-plate so that the shared-rig launch applies; the near-coincident pair makes the Cholesky fail there too)
+    # a batch of two on stream A, ONE evaluation call on stream B (the cubic kernel takes the per-frame launches of
+    # fd_batch_deform_shared_dev; the statuses are polled, the models rebuilt on A, and B ordered behind both rebuilds)
     d_near = torch.from_numpy(near).to(dev)
     d_del = torch.from_numpy(np.stack([delta, (0.5 * delta).astype(np.float32)])).to(dev)
-    refs = []
+    wants = []
     for k in range(2):
-        r = _engine(capi.KERNEL_THIN_PLATE, [], capi.TERM_LINEAR, near, d_del[k].cpu().numpy(), capi.SOLVER_LU)
-        r.build(); refs.append(r)
-    rb = capi.Batch(refs)
-    rb.set_points_dev([d_near.data_ptr()] * 2, [d_del[k].data_ptr() for k in range(2)], M)
-    rb.build_async(); assert [x.terminationtype for x in rb.build_result()] == [1, 1]
-    wants = [torch.empty_like(d_P) for _ in range(2)]
-    rb.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in wants])
-    torch.cuda.synchronize()
+        r = _engine(capi.KERNEL_CUBIC, [], capi.TERM_LINEAR, near, d_del[k].cpu().numpy(), capi.SOLVER_LU)
+        r.build(); wants.append(r.deform(P)[0]); r.close()
     engines = []
     for k in range(2):
-        x = capi.Engine(); x.set_stream(sa.cuda_stream); x.set_kernel(capi.KERNEL_THIN_PLATE); x.set_term(capi.TERM_LINEAR)
+        x = capi.Engine(); x.set_stream(sa.cuda_stream); x.set_kernel(capi.KERNEL_CUBIC); x.set_term(capi.TERM_LINEAR)
         engines.append(x)
     b = capi.Batch(engines)
     b.set_points_dev([d_near.data_ptr()] * 2, [d_del[k].data_ptr() for k in range(2)], M)
@@ -334,12 +329,11 @@ def test_a_repaired_build_is_ordered_before_evaluations_on_other_streams(hip_lib
     outs = [torch.empty_like(d_P) for _ in range(2)]
     b.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], stream_ptr=sb.cuda_stream)
     torch.cuda.synchronize()
-    reps = b.build_result()
-    assert [x.terminationtype for x in reps] == [1, 1]
+    assert [x.terminationtype for x in b.build_result()] == [1, 1]
     for k in range(2):
-        assert torch.equal(outs[k], wants[k]), k
-    b.close(); rb.close()
-    for x in engines + refs:
+        assert np.array_equal(outs[k].cpu().numpy(), wants[k]), k
+    b.close()
+    for x in engines:
         x.set_stream(None); x.close()
 
 
