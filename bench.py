@@ -75,7 +75,7 @@ def parse_args():
                          "free for the builds of the next groups, which otherwise only run in the gaps between evaluation "
                          "launches.  0 = the measured best for the build style: 192 with --build one-workgroup (its 3 x 32 persistent "
                          "workgroups want 64 CUs to themselves; 120-122k Mverts/s, 208: 110k), 224 with --build chain (113k; 256: 101k, 192: 109k)")
-    ap.add_argument("--build", choices=["one-workgroup", "chain"], default="one-workgroup",
+    ap.add_argument("--build", choices=["register", "one-workgroup", "chain"], default="register",
                     help="batched builds of the frame pipeline (config c2): one-workgroup = fd_config.solver FD_SOLVER_ONE_WORKGROUP "
                          "(one launch, one workgroup per model: 32 workgroups on 32 CUs per batch, nothing else on the device -- "
                          "the evaluation keeps the other CUs undisturbed; 120-122k Mverts/s); chain = the default solver's launch "
@@ -426,6 +426,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
     if args.eval_cus <= 0:
+        # one-workgroup builds (r2) want 64 CUs to themselves: 192; the register-resident build holds 32 CUs per batch: 224
         args.eval_cus = 192 if (args.build == "one-workgroup" and args.config == "c2") else 224
     import torch
     import torch.distributed as dist
@@ -487,7 +488,8 @@ def main():
             eval_stream, build_streams = ms
             cu_split = "mask"
     # the pipeline's models: one workgroup per model where that applies (M <= 512; config c3 takes the chain either way)
-    lane_solver = capi.SOLVER_ONE_WORKGROUP if (args.build == "one-workgroup" and B > 1) else capi.SOLVER_AUTO
+    lane_solver = (capi.SOLVER_ONE_WORKGROUP if (args.build == "one-workgroup" and B > 1) else
+                   capi.SOLVER_CHAIN if args.build == "chain" else capi.SOLVER_AUTO)      # AUTO: the register-resident one-launch build up to 256 control points
     lanes = []
     for li in range(n_lanes):
         stream = build_streams[li]
@@ -789,8 +791,9 @@ def main():
                 "evaluation": args.eval_launch if B > 1 else "single",
                 "evaluation_cus": args.eval_cus or 256,
                 "cu_split": cu_split,
-                "pipeline_build": ("one workgroup per model (FD_SOLVER_ONE_WORKGROUP)" if lane_solver == capi.SOLVER_ONE_WORKGROUP
-                                   else "launch chain (FD_SOLVER_AUTO)"),
+                "pipeline_build": ("one workgroup per model, matrix in L2 (FD_SOLVER_ONE_WORKGROUP)" if lane_solver == capi.SOLVER_ONE_WORKGROUP
+                                   else "launch chain (FD_SOLVER_CHAIN)" if lane_solver == capi.SOLVER_CHAIN
+                                   else "one launch, one workgroup per model, matrix in registers (FD_SOLVER_AUTO: fd_build_reg.hip)"),
                 "lanes_per_gpu": n_lanes,
                 "parallelism": f"independent frames: {world} GPU(s) x {n_lanes} lanes x {B} frames per batched "
                                "build and per evaluation launch (one build stream per lane, one evaluation "

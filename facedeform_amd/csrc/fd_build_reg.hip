@@ -52,8 +52,8 @@ constexpr double kEps = 2.220446049250313e-16;
 constexpr int kRegThreads = 512;        // 8 waves, two per SIMD: 256 registers each
 constexpr int kRegWaves = kRegThreads / 64;
 constexpr int kMaxBlocks = 16;          // 16 x 16 tiles per side: order <= 256
-constexpr int kRhsRow = 16;             // tile-row index of the right-hand sides
-constexpr int kSlots = 19;              // tiles per wave: (136 + 16) / 8
+constexpr int kWorkers = 7;             // waves 0..6 hold the tiles; wave 7 factorises diagonal blocks beside their updates
+constexpr int kSlots = 20;              // tiles per worker: ceil(136 / 7)
 constexpr int kPitch = 17;              // doubles per row of a 16 x 16 tile in LDS
 constexpr int kTileLds = 16 * kPitch;
 
@@ -163,8 +163,8 @@ __device__ __forceinline__ double phi_reg(int kind, double d2, double inv_r2)
 // LDS map (doubles).  The per-wave partial sums of Y = K V (8 x 4 M) exist only before the factorisation and lie over the
 // inverse blocks and the panel buffer, which exist only from then on.
 struct RegLds {
-    double *cen, *V, *W, *F, *B21, *small, *minv, *P, *scr, *Z, *Y, *stat, *ypart;
-    int *tab;
+    double *cen, *V, *W, *F, *B21, *small, *minv, *P, *scr, *Z, *Y, *stat, *ypart, *D;
+    int *tab, *flag;
 };
 constexpr int kSmallDoubles = 96;       // tau[4] R[16] Tm[16] g[12] G[16] misc
 constexpr int kTau = 0, kR = 4, kTm = 20, kG = 36, kGm = 48;
@@ -174,7 +174,7 @@ __host__ __device__ inline size_t reg_lds_doubles(int)
     const size_t overlay = (size_t)kMaxBlocks * kTileLds + (size_t)(kMaxBlocks + 1) * kTileLds;      // minv + P
     const size_t ypart = (size_t)kRegWaves * 4 * kRows;
     return (size_t)3 * kRows + 4 * (size_t)kRows + 4 * (size_t)kRows + 3 * (size_t)kRows + 4 * (size_t)kRows + kSmallDoubles +
-           (overlay > ypart ? overlay : ypart) + (size_t)kRegWaves * 2 * kTileLds + 3 * 256 + 3 * 256 + 8 + 160 /* tile table, as ints */;
+           (overlay > ypart ? overlay : ypart) + (size_t)kRegWaves * 2 * kTileLds + 3 * 256 + 3 * 256 + 8 + kTileLds + 160 /* tile table + flag, as ints */;
 }
 __device__ __forceinline__ RegLds carve(double *base, int)
 {
@@ -194,7 +194,9 @@ __device__ __forceinline__ RegLds carve(double *base, int)
     L.Z = p; p += 3 * 256;
     L.Y = p; p += 3 * 256;
     L.stat = p; p += 8;
+    L.D = p; p += kTileLds;                                // the diagonal tile on its way to the factor wave
     L.tab = reinterpret_cast<int *>(p);
+    L.flag = L.tab + 300;
     return L;
 }
 
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     const RegLds L = carve(dyn_lds, M);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool worker = wave < kWorkers;             // waves 0..6 hold the tiles; wave 7 runs the sequential pieces beside them
     const int c = lane & 15, g = lane >> 4;
     const int n1 = M - T;
     const int nbk = (M + 15) / 16;                   // tile rows / columns of K
@@ -300,13 +303,12 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     __builtin_amdgcn_s_setprio(3);
 
     // ---- control table (reference :268-287, widened to fp64), status reset, tile table
-    // tile q: column J of the lower triangle top to bottom (I = J .. nbk - 1), then its right-hand-side tile; wave q % 8, slot q / 8
-    const int ntiles = nbk * (nbk + 1) / 2 + nbk;
+    // tile q: column J of the lower triangle top to bottom (I = J .. nbk - 1); worker q % 7, slot q / 7
+    const int ntiles = nbk * (nbk + 1) / 2;
     if (tid < ntiles) {
         int q = tid, J = 0;
-        while (q >= nbk - J + 1) { q -= nbk - J + 1; ++J; }
-        const int I = (q == nbk - J) ? kRhsRow : J + q;
-        L.tab[tid] = I | (J << 8);
+        while (q >= nbk - J) { q -= nbk - J; ++J; }
+        L.tab[tid] = (J + q) | (J << 8);
     }
     {
         const float *rest = use_src ? src.rest[blockIdx.z] : slot.rest;
@@ -329,39 +331,38 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             if (e < 3 * kRows && e >= 3 * M) L.cen[e] = 0.0;
         }
     }
-    if (tid == 0) { L.stat[0] = INFINITY; L.stat[1] = 0.0; L.stat[2] = 0.0; L.stat[3] = 0.0; L.stat[4] = 0.0; }
+    if (tid == 0) { L.stat[0] = INFINITY; L.stat[1] = 0.0; L.stat[2] = 0.0; L.stat[3] = 0.0; *L.flag = 0; }
     __syncthreads();
     // Lane t of `ijv` holds the coordinates of the wave's slot t (I | J << 8; 0xffff: no tile).  Which slots a phase touches
-    // is ONE ballot over that register (a 19-bit mask, then a bit test per slot); a slot's coordinates come out with one
-    // v_readlane where its LDS addresses are formed.  (As 19 scalar values they were spilled and re-read, compared and
+    // is ONE ballot over that register (a bit mask, then a bit test per slot); a slot's coordinates come out with one
+    // v_readlane where its LDS addresses are formed.  (As scalar values they were spilled and re-read, compared and
     // branched on in every scan: five scans per factorisation step at ~500 cycles each.  Read through an opaque copy: with
     // the coordinates visibly loop-invariant the compiler hoists every tile's LDS addresses out of the step loop -- 40 more
-    // live registers beside the 152 of the tiles, and spills.)
+    // live registers beside those of the tiles, and spills.)
     int ijv = 0xffff;
-    if (lane < kSlots && wave + kRegWaves * lane < ntiles) ijv = L.tab[wave + kRegWaves * lane];
+    if (worker && lane < kSlots && wave + kWorkers * lane < ntiles) ijv = L.tab[wave + kWorkers * lane];
     const int ivI = ijv & 0xff, ivJ = ijv >> 8;
     auto slots_where = [&](bool cond) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(cond && lane < kSlots)); };
-    const unsigned m_matrix = slots_where(ivI < kMaxBlocks);              // tiles of K (not right-hand sides, not empty)
+    const unsigned m_matrix = slots_where(ivI < kMaxBlocks);              // the wave's tiles
 #define tI(t) (opaque_s(__builtin_amdgcn_readlane(ijv, t)) & 0xff)
 #define tJ(t) (opaque_s(__builtin_amdgcn_readlane(ijv, t)) >> 8)
 #define FD_SLOT(m, t) (((m) >> (t)) & 1u)
-
     FD_RSTAMP()
-    // ---- K, tile by tile: element (16 I + g + 4 i, 16 J + c) = phi(|c_row - c_col|^2) (+ lambda on the diagonal).  A ROLLED loop
-    // (one copy of the logarithm) that writes the tiles to a staging area -- the context's matrix buffer, which this build
-    // does not otherwise use: [tile][register][lane], 512 contiguous bytes per store -- while no tile is live in registers yet:
-    // with the 152 registers of the resident tiles carried through this loop it spilled them around every iteration (103 k
-    // cycles).  The tiles come back from L2 by 76 unconditional loads per lane.
-    {
+
+    if (worker) {
+        // ---- K, tile by tile: element (16 I + g + 4 i, 16 J + c) = phi(|c_row - c_col|^2) (+ lambda on the diagonal).  A ROLLED
+        // loop (one copy of the logarithm) that writes the tiles to a staging area -- the context's matrix buffer, which this
+        // build does not otherwise use: [tile][register][lane], 512 contiguous bytes per store -- while no tile is live in
+        // registers yet: with the registers of the resident tiles carried through this loop it spilled them around every
+        // iteration.  The tiles come back from L2 by unconditional loads.
         gdouble *stage = as_global(slot.A);
         const double inv_r2 = 1.0 / (gauss_R * gauss_R);
         double amax_w = 0.0;
         bool dup = false;
 #pragma nounroll
-        for (int q = wave; q < ntiles; q += kRegWaves) {
+        for (int q = wave; q < ntiles; q += kWorkers) {
             const int ij = __builtin_amdgcn_readfirstlane(L.tab[q]);
             const int I = ij & 0xff, J = ij >> 8;
-            if (I >= kMaxBlocks) continue;
             const int col = 16 * J + c;
             const double cx = L.cen[3 * col], cy = L.cen[3 * col + 1], cz = L.cen[3 * col + 2];
             double d2[4], e[4];
@@ -372,8 +373,14 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 d2[i] = dx * dx + dy * dy + dz * dz;
             }
             if (kind == FD_KERNEL_THIN_PLATE) {
+                // (no branch around the logarithm: four independent chains the scheduler can interleave; d2 = 0 -- the
+                // diagonal, padding, coincident centres -- goes through as 1 and is zeroed by the select)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) e[i] = d2[i] > 0.0 ? 0.5 * d2[i] * log_pos(d2[i]) : 0.0;
+                for (int i = 0; i < 4; ++i) {
+                    const bool pos = d2[i] > 0.0;
+                    const double lg = log_pos(pos ? d2[i] : 1.0);
+                    e[i] = pos ? 0.5 * d2[i] * lg : 0.0;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) e[i] = phi_reg(kind, d2[i], inv_r2);
@@ -393,33 +400,9 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         amax_w = wave_max(amax_w);
         const bool any_dup = __any(dup);
         if (lane == 0) { L.ypart[wave] = amax_w; L.ypart[kRegWaves + wave] = any_dup ? 1.0 : 0.0; }      // (the overlay is free until Y = K V)
-    }
-    __threadfence_block();
-    __syncthreads();
-    FD_RSTAMP()
-    double4_t S[kSlots];
-    {
-        gcdouble *stage = as_global(slot.A);
-#pragma unroll
-        for (int t = 0; t < kSlots; ++t) {
-            const int q = wave + kRegWaves * t;
-            S[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-            if (FD_SLOT(m_matrix, t)) {                      // (a wave reads back what it stored itself)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) S[t][i] = stage[((size_t)q * 4 + i) * 64 + lane];
-            }
-        }
-    }
-    double amax = 0.0;
-    bool dup_any = false;
-#pragma unroll
-    for (int w = 0; w < kRegWaves; ++w) { amax = L.ypart[w] > amax ? L.ypart[w] : amax; dup_any = dup_any || L.ypart[kRegWaves + w] != 0.0; }
-    __syncthreads();
-    FD_RSTAMP()
-
-    // ---- reflectors of P = [1 x y z] (dlarfg upside down: reflector k acts on rows 0 .. M-1-k, beta in row M-1-k) with
-    // f <- Q^T f folded into the same sweep: ONE wave, four rows per lane, every sum a DPP reduction -- no barrier inside.
-    if (T > 0 && wave == 0) {
+    } else if (T > 0) {
+        // ---- meanwhile, wave 7: reflectors of P = [1 x y z] (dlarfg upside down: reflector k acts on rows 0 .. M-1-k, beta in
+        // row M-1-k) with f <- Q^T f folded into the same sweep: four rows per lane, every sum a DPP reduction, no barrier.
         bool singular = false;
         double cn[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -543,10 +526,31 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             }
         }
     }
-    // per-wave partial sums of Y, zeroed meanwhile (every wave its own)
-    double *yp = L.ypart + (size_t)wave * 4 * kRows;
-    if (T > 0) for (int e = lane; e < 4 * kRows; e += 64) yp[e] = 0.0;
+    __threadfence_block();
     __syncthreads();
+    FD_RSTAMP()
+    double amax = 0.0;
+    bool dup_any = false;
+#pragma unroll
+    for (int w = 0; w < kWorkers; ++w) { amax = L.ypart[w] > amax ? L.ypart[w] : amax; dup_any = dup_any || L.ypart[kRegWaves + w] != 0.0; }
+    double4_t S[kSlots];
+    {
+        gcdouble *stage = as_global(slot.A);
+#pragma unroll
+        for (int t = 0; t < kSlots; ++t) {
+            const int q = wave + kWorkers * t;
+            S[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            if (FD_SLOT(m_matrix, t)) {                      // (a wave reads back what it stored itself)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S[t][i] = stage[((size_t)q * 4 + i) * 64 + lane];
+            }
+        }
+    }
+    __syncthreads();                                 // (everybody has read the assembly's statistics out of the overlay)
+    // per-wave partial sums of Y (every worker its own)
+    double *yp = L.ypart + (size_t)wave * 4 * kRows;
+    if (T > 0 && worker) for (int e = lane; e < 4 * kRows; e += 64) yp[e] = 0.0;
+    wave_lds_sync();
     FD_RSTAMP()
 
     if (T > 0) {
@@ -598,14 +602,14 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         for (int e = tid; e < 4 * kRows; e += kRegThreads) {
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < kRegWaves; ++w) s += L.ypart[(size_t)w * 4 * kRows + e];
+            for (int w = 0; w < kWorkers; ++w) s += L.ypart[(size_t)w * 4 * kRows + e];
             L.W[e] = s;                             // Y for now
         }
         __syncthreads();
         FD_RSTAMP()
 
-        // ---- G = Tm^T sym(V^T Y) Tm on one wave; then W = Y Tm - (1/2) V G, a row per thread
-        if (wave == 0) {
+        // ---- G = Tm^T sym(V^T Y) Tm on wave 7; then W = Y Tm - (1/2) V G, a row per thread
+        if (!worker) {
             double Sm[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) Sm[q] = 0.0;
@@ -682,8 +686,8 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi, vj, S[t], 0, 0, 0);
         }
     }
-    // ---- B21 aside (pivot row M-1-k = equation of polynomial coefficient k), identity padding beyond n1, right-hand-side tiles
-    const unsigned m_rhs = slots_where(ivI == kRhsRow);
+    // ---- B21 aside (pivot row M-1-k = equation of polynomial coefficient k), identity padding beyond n1; the first diagonal
+    //      tile to the factor wave's buffer
 #pragma unroll
     for (int t = 0; t < kSlots; ++t) {
         if (FD_SLOT(m_matrix, t)) {
@@ -693,99 +697,142 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 if (row >= n1 && row < M && col < n1) L.B21[4 * col + (M - 1 - row)] = S[t][i];
                 if (row >= n1 || col >= n1) S[t][i] = row == col ? 1.0 : 0.0;
             }
-        } else if (FD_SLOT(m_rhs, t)) {
+        }
+    }
+    {
+        const unsigned m_d0 = slots_where(ivI == 0 && ivJ == 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rhs = g + 4 * i, col = 16 * tJ(t) + c;
-                S[t][i] = (rhs < 3 && col < n1) ? L.F[rhs * kRows + col] : 0.0;
+        for (int t = 0; t < kSlots; ++t) {
+            if (FD_SLOT(m_d0, t)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) L.D[(g + 4 * i) * kPitch + c] = S[t][i];
             }
         }
     }
     __syncthreads();                                 // the overlay (partial sums of Y) is dead: inverse blocks and panel buffer from here
     FD_RSTAMP()
 
-    // ---- blocked Cholesky, 16 columns per step, right-hand sides as tile row 16
+    // ---- blocked Cholesky, 16 columns per step, with LOOK-AHEAD: wave 7 factorises and inverts diagonal block K while the
+    // workers apply panel K - 1 to the rest of the matrix -- the owner of tile (K, K) updates that one first, hands it over
+    // through LDS and raises a flag.  The three right-hand sides live in LDS (F, 3 x 256): wave 7 turns block K of them into
+    // z_K = f_K inv(L_KK)^T once everything before has been applied, and a worker that holds panel tile (I, K) subtracts
+    // z_K L_IK^T from block I when it applies that panel.
     const double tiny = (double)n1 * kEps * amax;
-    double *scr = L.scr + (size_t)wave * 2 * kTileLds;
     PivotStats pst = {INFINITY, 0.0, false};
     for (int K = 0; K < nb; ++K) {
-        // (i) the owner of the diagonal tile: factor + inverse, in its registers (its tile is up to date: it applied every
-        //     earlier panel itself); the inverse goes to LDS for everybody's panel solves and for the back substitution
-        //     (ONE copy of the routine: inlined into the slot loop it was nineteen, and the kernel outgrew the instruction cache)
-        const bool active = ivI < nb || ivI == kRhsRow;       // (tiles outside the projected block: pivot rows only, done with)
-        const unsigned m_diag = slots_where(ivI == K && ivJ == K);
-        const unsigned m_panel = slots_where(ivJ == K && ivI > K && active);
-        const unsigned m_update = slots_where(ivJ > K && ivJ < nb && active);
-        double4_t Td = {0.0, 0.0, 0.0, 0.0};
+        if (worker) {
+            if (K > 0) {
+                const int Kp = K - 1;
+                const unsigned m_diag = slots_where(ivI == K && ivJ == K);
+                const unsigned m_upd = slots_where(ivJ > Kp && ivJ < nb && ivI < nb && !(ivI == K && ivJ == K));
+                const unsigned m_col = slots_where(ivJ == Kp && ivI > Kp && ivI < nb);       // my tiles of panel K - 1: their share of the right-hand sides
+                // the next diagonal tile first: the factor wave is waiting for it
 #pragma unroll
-        for (int t = 0; t < kSlots; ++t) {
-            if (FD_SLOT(m_diag, t)) Td = S[t];
-        }
-        if (m_diag != 0u) {
+                for (int t = 0; t < kSlots; ++t) {
+                    if (FD_SLOT(m_diag, t)) {
+                        const double *pa = L.P + (size_t)K * kTileLds;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const double a = pa[c * kPitch + 4 * s + g];
+                            S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, a, S[t], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) L.D[(g + 4 * i) * kPitch + c] = S[t][i];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(L.flag, K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                // right-hand sides: f_I -= z_Kp L_I,Kp^T for my panel tiles (A = z_Kp as three rows, B = the panel tile from LDS)
+#pragma unroll
+                for (int t = 0; t < kSlots; ++t) {
+                    if (FD_SLOT(m_col, t)) {
+                        const int I = tI(t);
+                        const double *pb = L.P + (size_t)I * kTileLds;
+                        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const double a = c < 3 ? L.Z[c * 256 + 16 * Kp + 4 * s + g] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[c * kPitch + 4 * s + g], acc, 0, 0, 0);
+                        }
+                        if (g < 3) L.F[g * kRows + 16 * I + c] -= acc[0];
+                    }
+                }
+                // the rest of the trailing matrix: C_IJ -= L_I,Kp L_J,Kp^T
+#pragma unroll
+                for (int t = 0; t < kSlots; ++t) {
+                    if (FD_SLOT(m_upd, t)) {
+                        const double *pa = L.P + (size_t)tI(t) * kTileLds, *pb = L.P + (size_t)tJ(t) * kTileLds;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[c * kPitch + 4 * s + g], pb[c * kPitch + 4 * s + g], S[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            if (K > 0) {
+                while (__hip_atomic_load(L.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != K) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            double4_t Td;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Td[i] = L.D[(g + 4 * i) * kPitch + c];
             const int live = n1 - 16 * K < 16 ? n1 - 16 * K : 16;
             const double4_t U = factor_invert_tile(Td, tiny, live, pst, lane);
             double *dst = L.minv + (size_t)K * kTileLds;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = U[i];
         }
-        __syncthreads();
-        if (stamps && blockIdx.z == 0 && tid == 0) stamps[16 + 3 * K] = __builtin_amdgcn_s_memtime() - st_prev;
-        // (ii) the tiles below it (and the right-hand sides): L_IK = C_IK inv(L_KK)^T; into the panel buffer
-        const double *mk = L.minv + (size_t)K * kTileLds;
-        double bop[4];
+        __syncthreads();                              // inverse K is in LDS; panel K - 1 has been applied everywhere
+        if (stamps && blockIdx.z == 0 && tid == 0) stamps[16 + 2 * K] = __builtin_amdgcn_s_memtime() - st_prev;
+        if (worker) {
+            // the tiles below the diagonal block: L_IK = C_IK inv(L_KK)^T, through the tile's own slot of the panel buffer
+            const unsigned m_panel = slots_where(ivJ == K && ivI > K && ivI < nb);
+            const double *mk = L.minv + (size_t)K * kTileLds;
+            double bop[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bop[s] = mk[c * kPitch + 4 * s + g];         // B[k][n] = inv[n][4 s + k]
-        // (a tile's own slot of the panel buffer is its transposition buffer: all of a wave's tiles go in at once, are read
-        // back as operands at once -- independent matrix-instruction chains the scheduler can interleave -- and are replaced
-        // by the results)
+            for (int s = 0; s < 4; ++s) bop[s] = mk[c * kPitch + 4 * s + g];         // B[k][n] = inv[n][4 s + k]
 #pragma unroll
-        for (int t = 0; t < kSlots; ++t) {
-            if (FD_SLOT(m_panel, t)) {
-                double *dst = L.P + (size_t)tI(t) * kTileLds;
+            for (int t = 0; t < kSlots; ++t) {
+                if (FD_SLOT(m_panel, t)) {
+                    double *dst = L.P + (size_t)tI(t) * kTileLds;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = S[t][i];
+                    for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = S[t][i];
+                }
             }
-        }
-        wave_lds_sync();
+            wave_lds_sync();
 #pragma unroll
-        for (int t = 0; t < kSlots; ++t) {
-            if (FD_SLOT(m_panel, t)) {
-                const double *sb = L.P + (size_t)tI(t) * kTileLds;
-                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < kSlots; ++t) {
+                if (FD_SLOT(m_panel, t)) {
+                    const double *sb = L.P + (size_t)tI(t) * kTileLds;
+                    double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[c * kPitch + 4 * s + g], bop[s], acc, 0, 0, 0);
-                S[t] = acc;
+                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[c * kPitch + 4 * s + g], bop[s], acc, 0, 0, 0);
+                    S[t] = acc;
+                }
             }
-        }
-        wave_lds_sync();
+            wave_lds_sync();
 #pragma unroll
-        for (int t = 0; t < kSlots; ++t) {
-            if (FD_SLOT(m_panel, t)) {
-                double *dst = L.P + (size_t)tI(t) * kTileLds;
+            for (int t = 0; t < kSlots; ++t) {
+                if (FD_SLOT(m_panel, t)) {
+                    double *dst = L.P + (size_t)tI(t) * kTileLds;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = S[t][i];
+                    for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = S[t][i];
+                }
             }
-        }
-        __syncthreads();
-        if (stamps && blockIdx.z == 0 && tid == 0) stamps[17 + 3 * K] = __builtin_amdgcn_s_memtime() - st_prev;
-        // (iii) trailing update C_IJ -= L_IK L_JK^T for every tile right of the panel
+        } else if (lane < 48) {
+            // z_K = f_K inv(L_KK)^T: lanes = (right-hand side, column)
+            const int rhs = lane >> 4, n = lane & 15;
+            const double *mk = L.minv + (size_t)K * kTileLds;
+            double z = 0.0;
 #pragma unroll
-        for (int t = 0; t < kSlots; ++t) {
-            if (FD_SLOT(m_update, t)) {
-                const double *pa = L.P + (size_t)tI(t) * kTileLds, *pb = L.P + (size_t)tJ(t) * kTileLds;
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[c * kPitch + 4 * s + g], pb[c * kPitch + 4 * s + g], S[t], 0, 0, 0);
-            }
+            for (int k = 0; k < 16; ++k) z = fma(L.F[rhs * kRows + 16 * K + k], mk[n * kPitch + k], z);
+            L.Z[rhs * 256 + 16 * K + n] = z;
         }
-        // (no barrier: the next panel's tiles are written only after the barrier that follows the next diagonal block)
-        if (stamps && blockIdx.z == 0 && tid == 0) stamps[18 + 3 * K] = __builtin_amdgcn_s_memtime() - st_prev;
+        __syncthreads();                              // panel K and z_K are in LDS
+        if (stamps && blockIdx.z == 0 && tid == 0) stamps[17 + 2 * K] = __builtin_amdgcn_s_memtime() - st_prev;
     }
-    if (lane == 0 && (pst.pmax > 0.0 || pst.pmin < INFINITY || pst.singular)) {
-        // (the owners of the diagonal tiles differ from step to step: min / max through LDS atomics on the bit patterns
-        // of non-negative doubles, which order like the values)
-        __hip_atomic_fetch_min((unsigned long long *)&L.stat[0], (unsigned long long)__double_as_longlong(pst.pmin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max((unsigned long long *)&L.stat[1], (unsigned long long)__double_as_longlong(pst.pmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!worker && lane == 0) {
+        L.stat[0] = pst.pmin; L.stat[1] = pst.pmax;
         if (pst.singular) L.stat[2] = 1.0;
     }
     FD_RSTAMP()
@@ -793,14 +840,6 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     // ---- y^T L = z^T, bottom up, right-looking: one row of tiles per step (a tile is its own B operand).  The wave that owns
     // tile (I, I - 1) subtracts its share from block I - 1 and solves that block right away -- every other contribution to it
     // came before an earlier barrier -- so a step costs one barrier.
-    {
-        const unsigned m_z = slots_where(ivI == kRhsRow && ivJ < nb);
-#pragma unroll
-        for (int t = 0; t < kSlots; ++t) {
-            if (FD_SLOT(m_z, t) && g < 3) L.Z[g * 256 + 16 * tJ(t) + c] = S[t][0];
-        }
-    }
-    __syncthreads();
     auto solve_block = [&](int I) {                   // Y_I = Z_I inv(L_II): lanes 0..47 = (right-hand side, column)
         if (lane < 48) {
             const int rhs = lane >> 4, n = lane & 15;
@@ -811,7 +850,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             L.Y[rhs * 256 + 16 * I + n] = y;
         }
     };
-    if (wave == 0 && nb > 0) solve_block(nb - 1);
+    if (!worker && nb > 0) solve_block(nb - 1);
     __syncthreads();
     for (int I = nb - 1; I >= 1; --I) {
         const unsigned m_row = slots_where(ivI == I && ivJ < I);
@@ -833,8 +872,8 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     }
     FD_RSTAMP()
 
-    // ---- R a = g - B21 y;  w = Q [y; 0] = H_0 .. H_{T-1} [y; 0]: one wave again
-    if (wave == 0) {
+    // ---- R a = g - B21 y;  w = Q [y; 0] = H_0 .. H_{T-1} [y; 0]: wave 7 again
+    if (!worker) {
         double q12[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) q12[e] = 0.0;
@@ -974,8 +1013,8 @@ hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const Poi
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[k_build_reg stamps, shader cycles: table | assembly | tile loads | reflectors + Q^T f | Y = K V | W + rotation + B21 | Cholesky | back substitution | recovery | pack]\n  ");
             for (int q = 0; q < 10; ++q) fprintf(stderr, " %llu", h[q]);
-            fprintf(stderr, "\n   Cholesky steps (cycles since its start: after the diagonal block | after the panel | after the update, as wave 0 sees them):");
-            for (int q = 16; q < 64; ++q) fprintf(stderr, "%s%llu", (q - 16) % 3 ? " " : "\n     ", h[q]);
+            fprintf(stderr, "\n   Cholesky steps (cycles since its start: inverse K in LDS | panel K in LDS, as wave 0 sees them):");
+            for (int q = 16; q < 48; ++q) fprintf(stderr, "%s%llu", (q - 16) % 2 ? " " : "\n     ", h[q]);
             fprintf(stderr, "\n");
         }
     }

@@ -380,7 +380,8 @@ def test_one_workgroup_solver_as_a_context_choice(hip_lib, oracle):
     """fd_config.solver = FD_SOLVER_ONE_WORKGROUP (what bench.py's frame pipeline builds with): per context, no
     environment switch.  Weights against the default solver's (rounding: the same system, another elimination order; the
     default solver's against the oracle: test_cholesky_and_lu_agree_with_each_other_and_the_oracle); a batch of such
-    contexts equals the same models built one at a time bit for bit; a batch that mixes solvers takes the chain."""
+    contexts equals the same models built one at a time bit for bit; a batch that mixes solvers takes the chain
+    (FD_SOLVER_AUTO itself is the register-resident build at this size: tests/test_gpu_register_build.py)."""
     import torch
     M, F = 256, 6
     dev = torch.device("cuda", 0)
@@ -413,7 +414,7 @@ def test_one_workgroup_solver_as_a_context_choice(hip_lib, oracle):
     mixed.set_points_dev([d_rest.data_ptr()] * 2, [d_del.data_ptr(), d_del.data_ptr() + M * 12], M)
     mixed.build_async()
     assert [r.terminationtype for r in mixed.build_result()] == [1, 1]
-    auto2 = engines(capi.SOLVER_AUTO, 1)[0]
+    auto2 = engines(capi.SOLVER_CHAIN, 1)[0]
     auto2.set_points(rest, deltas[0]); auto2.build()
     assert np.array_equal(ow[0].get_weights()[0], auto2.get_weights()[0])               # the chain's bits
     for b in (mixed, batch):
