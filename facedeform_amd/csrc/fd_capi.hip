@@ -130,6 +130,7 @@ struct fd_batch {
     // has finished -- with fd_batch_prepare_shared the next pack runs on the build stream, under the previous evaluation.
     struct SharedSet {
         void *d_wtiles = nullptr, *d_frames = nullptr;
+        unsigned *d_ctr = nullptr;       // {next group, finished waves} of the evaluation's device-wide draw (zero between launches)
         size_t cap_wtiles = 0, cap_frames = 0;
         hipEvent_t packed_ev = nullptr;  // behind the pack kernel that filled the set
         hipEvent_t eval_ev = nullptr;    // behind the last evaluation that read it
@@ -1403,6 +1404,7 @@ void fd_batch_destroy(fd_batch *b)
     for (auto &st : b->sets) {
         if (st.d_wtiles) (void)hipFree(st.d_wtiles);
         if (st.d_frames) (void)hipFree(st.d_frames);
+        if (st.d_ctr) (void)hipFree(st.d_ctr);
         if (st.packed_ev) (void)hipEventDestroy(st.packed_ev);
         if (st.eval_ev) (void)hipEventDestroy(st.eval_ev);
     }
@@ -1726,6 +1728,12 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
         }
         st.cap_wtiles = wb; st.cap_frames = fb;
     }
+    if (!st.d_ctr) {
+        if (hipMalloc((void **)&st.d_ctr, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(st.d_ctr, 0, 2 * sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (st.d_ctr) { (void)hipFree(st.d_ctr); st.d_ctr = nullptr; }      // (the launch then deals the groups out in fixed shares)
+        }
+    }
     // the evaluation that last read this set must be through with it
     if (st.eval_pending && st.eval_ev && hipStreamWaitEvent(stream, st.eval_ev, 0) != hipSuccess) {
         batch_err(b, "shared-rig evaluation: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1826,6 +1834,7 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     a.packed_ev = nullptr;
     a.mode = 2;
     a.max_wgs = b->eval_cus;
+    a.ctr = st.d_ctr;
     hipError_t e = launch_deform_shared(a, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_shared failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
     if (make_event(&st.eval_ev)) {

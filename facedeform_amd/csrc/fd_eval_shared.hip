@@ -93,6 +93,7 @@ struct SharedParams {
                                   // full vertex groups take the branch-free epilogue (below)
     int stagger;                  // waves 4..7 start this many x 8192 cycles late (resident model only)
     unsigned long long *stamps;   // diagnostics (FD_SHARED_STAMPS): shader-clock shares of the phases, per wave of workgroup 0
+    unsigned *ctr;                // 32-row kernel: {next 512-vertex group, waves that have finished} -- device-wide, self-resetting (or null)
 };
 
 struct SharedSlots {              // the models of the frames (kernel argument of the pack kernel)
@@ -934,6 +935,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     // fd_falloff pointers of the straight-line epilogue: store q of a group covers frames 4 q .. 4 q + 3, 16 lanes x 16 B each
     uint64_t *s_ftab = reinterpret_cast<uint64_t *>(s_w + (size_t)kWideW16 * p.kchunk);
     unsigned *s_ticket = reinterpret_cast<unsigned *>(s_ftab + 512);      // next 64-vertex unit of this workgroup
+    int *s_ring = reinterpret_cast<int *>(s_ticket + 4);                  // [16] group of round r at r & 15, [16] its tag r + 1 (0: not fetched yet)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -984,6 +986,13 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         const uint4 *psrc = p.wtiles + (size_t)p.nkb * kWideW16;
         for (int q = tid; q < NT * 64; q += kSharedThreads) s_poly[q] = psrc[q];
         if (tid == 0) *s_ticket = 0u;
+        if (tid < 32) s_ring[tid] = 0;
+        __syncthreads();
+        if (tid < 3 && p.ctr != nullptr) {                 // the groups of rounds 0, 1 and 2 (the waves' first tickets come after a barrier)
+            const unsigned gq = (p.dbg & 8) ? blockIdx.x + (unsigned)tid * gridDim.x : __hip_atomic_fetch_add(p.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ring[tid] = (int)(gq < (unsigned)ngroups ? gq : (unsigned)ngroups);
+            s_ring[16 + tid] = tid + 1;
+        }
         if (p.fast && tid < NSLOT * 16) s_ftab[tid] = (uint64_t)p.frames[4 * (tid >> 6) + ((tid & 63) >> 4)].falloff_out + 16u * (unsigned)(tid & 15);
     }
     if (resident) {
@@ -1014,18 +1023,84 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     // workgroup (VAR bit 3 clear): every workgroup then ends with one or two lone units at a lone wave's pace (0.6 of a
     // round) instead of a few workgroups running a whole extra round beside idle CUs (at 192 CUs: 34 of them).
     constexpr bool POOL = (VAR & 8) == 0;
-    const int whole_rounds = (dynamic && POOL) ? ngroups / (int)gridDim.x : (ngroups + (int)gridDim.x - 1) / (int)gridDim.x;
+    // Groups from a DEVICE-WIDE counter (p.ctr, r3): a workgroup draws its next 512-vertex group when the first unit of the
+    // current one is handed out -- a round ahead of need, one atomic per workgroup and round, published to its eight waves
+    // through a small ring in LDS -- so a launch on all 256 CUs takes whatever the builds of a pipeline leave free: a
+    // workgroup that finds its CU held by a build starts late and simply draws fewer groups.  (r2 dealt the groups out in
+    // fixed shares; the best CU budget for the evaluation was then a cliff: 140 k Mverts/s at 192 CUs, 118 k at 200.  Drawing
+    // every 64-vertex UNIT from a device-wide counter had failed earlier: one atomic per unit from 2 048 waves, and the
+    // eight waves of a workgroup no longer write adjacent pieces of a frame at about the same time.)  The last round is
+    // balanced by the draw itself.  In this mode a "unit" below is its global index.
+    const bool gdyn = dynamic && p.ctr != nullptr;
+    const int whole_rounds = gdyn ? 0 : ((dynamic && POOL) ? ngroups / (int)gridDim.x : (ngroups + (int)gridDim.x - 1) / (int)gridDim.x);
     const int64_t pool0 = (int64_t)whole_rounds * (int64_t)gridDim.x * 8, total_units = (int64_t)ngroups * 8;
     auto unit_global = [&](int u) -> int64_t {          // the 64-vertex unit behind local ticket u (>= total_units: none)
+        if (gdyn) return (int64_t)u;
         if (u < 8 * whole_rounds) return ((int64_t)blockIdx.x + (int64_t)(u >> 3) * (int64_t)gridDim.x) * 8 + (u & 7);
         return pool0 + (int64_t)blockIdx.x + (int64_t)(u - 8 * whole_rounds) * (int64_t)gridDim.x;
     };
     auto unit_group = [&](int u) -> int64_t { const int64_t g = unit_global(u); return g < total_units ? (g >> 3) : (int64_t)ngroups; };
+    // The draw is ISSUED when the first unit of round r is handed out, for round r + 3, and its result is PUBLISHED only at the
+    // end of that wave's current group, behind the epilogue's stores, in straight-line code: a wave's vector-memory operations
+    // retire in order, so waiting for the atomic's return where it is issued would wait for every store before it (the
+    // launch lost a third of its speed that way), while behind ~46 younger operations the wait is vmcnt(46) on a value that
+    // came back a K loop ago.  (Three rounds ahead, not one: tickets are taken a unit ahead of the work, the two waves of a SIMD take the issue priority
+    // in turn, and when the drawer was the slow one the fast waves reached the round before its number was out: 170 -> 245 us
+    // per launch with r + 2.  Rounds 0 to 2 are drawn at the kernel's start.  When the groups run out nobody draws any
+    // more: at most eight tickets are handed out after the first empty one, which reach into the next round at the furthest.)
+    // The atomic is an asm string: written with the builtin the compiler waits for its return value where it is ISSUED
+    // (vmcnt(0): every store in flight), whatever distance the first use is at; the string's result is, to the compiler,
+    // ready at once, so the wait is placed by hand in front of the use: none in the straight-line epilogue (see publish_draw),
+    // vmcnt(0) on the rare other paths.  Likewise the ring is read and written
+    // with ds_ instructions in asm strings: volatile accesses and workgroup-scope fences both came out with vmcnt(0).
+    int pend_round = -1;
+    unsigned pend_val = 0u;
+    int round_taken = 0;                                 // workgroup-local round of the ticket taken last
+    const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int *)s_ring;
+    auto publish_draw = [&](auto strictTag) {
+        if (pend_round >= 0 && lane == 0) {
+            // (value, then tag: a wave's LDS operations execute in order, and the reader takes them in the opposite order)
+            const int r = pend_round;
+            // (strict: wait for everything.  Otherwise NO wait: the caller has just waited for the next group's positions
+            // (`settle`), loads issued AFTER the atomic -- returns come in order, so its value is there.  A wait of its own
+            // with a small count waits for this group's STORES to be acknowledged: 170 -> 249 us per launch when tried.)
+            if constexpr (decltype(strictTag)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned val = pend_val < (unsigned)ngroups ? pend_val : (unsigned)ngroups;
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %2, %3" :: "v"(ring_lds + 4u * (unsigned)(r & 15)), "v"(val),
+                         "v"(ring_lds + 4u * (unsigned)(16 + (r & 15))), "v"((unsigned)(r + 1)) : "memory");
+        }
+        pend_round = -1;
+    };
     auto next_unit = [&](int u) {
         if (!dynamic) return u + 8;
         unsigned v = 0;
         if (lane == 0) v = __hip_atomic_fetch_add(s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return (int)__builtin_amdgcn_readfirstlane(v);
+        const int t = (int)__builtin_amdgcn_readfirstlane(v);
+        round_taken = t >> 3;
+        if (!gdyn) return t;
+        const int r = t >> 3;
+        int grp = 0;
+        if (lane == 0) {
+            unsigned tag, val;
+            for (;;) {
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(tag), "=&v"(val)
+                             : "v"(ring_lds + 4u * (unsigned)(16 + (r & 15))), "v"(ring_lds + 4u * (unsigned)(r & 15)) : "memory");
+                if (tag == (unsigned)(r + 1)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            grp = (int)val;                                 // (read behind its tag: published in the opposite order)
+        }
+        grp = __builtin_amdgcn_readfirstlane(grp);
+        if ((t & 7) == 0 && grp < ngroups) {
+            if (pend_round >= 0) publish_draw(std::true_type{});      // (a wave that drew twice before finishing a group: never leave a round unpublished)
+            if (lane == 0) {
+                unsigned one = 1u;
+                if (p.dbg & 8) pend_val = blockIdx.x + (unsigned)(r + 3) * gridDim.x;          // diagnostics: the fixed shares through the ring
+                else asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pend_val) : "v"(p.ctr), "v"(one) : "memory");
+            }
+            pend_round = r + 3;
+        }
+        return grp < ngroups ? grp * 8 + (t & 7) : (int)total_units;
     };
     auto load_raw = [&](int64_t gu, auto fastTag) {
         constexpr bool FAST = decltype(fastTag)::value;
@@ -1049,11 +1124,13 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         asm volatile("" :: "v"(r.p[0][0]), "v"(r.p[0][1]), "v"(r.p[0][2]), "v"(r.p[1][0]), "v"(r.p[1][1]), "v"(r.p[1][2]));
     };
     GroupRaw nxt;
-    auto do_group = [&](int u, int un, auto fastTag) {
+    auto do_group = [&](int u, int un, int lround, auto fastTag) {
         constexpr bool FAST = decltype(fastTag)::value;
         const int64_t vbase = unit_global(u) * 64;
         const int64_t gu_next = unit_group(un) < ngroups ? unit_global(un) : unit_global(u);       // whose positions to request
-        if ((((u >> 3) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+        // (the workgroup's OWN round counter decides: the global group numbers a workgroup draws all have the parity of its
+        // index -- 256 workgroups draw in step -- and one wave of each SIMD would keep the priority for the whole launch)
+        if (((lround ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
         const GroupRaw cur = nxt;
         // this lane's own vertex in the epilogue is (vt = h, j)
@@ -1364,6 +1441,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 }
             }
             settle(nxt);
+            publish_draw(std::false_type{});
             FD_SSTAMP(3)
             return;
         }
@@ -1404,6 +1482,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 normalize3(a2[0], a2[1], a2[2]);
             }
         }
+        publish_draw(std::true_type{});
 #pragma unroll
         for (int fs = 0; fs < NSLOT; ++fs) {
             const int f = fs;
@@ -1442,6 +1521,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     const bool fast_ok = p.fast && __all(built_here);
     const int nfull = (int)(p.N / kSharedThreads);       // groups in which every wave's 64 vertices exist
     int u = dynamic ? next_unit(0) : wave;
+    int ru = dynamic ? round_taken : 0;
     nxt = load_raw(unit_group(u) < ngroups ? unit_global(u) : 0, std::false_type{});
     settle(nxt);
     // two loops, not one with a branch: where the two kinds of group met at the loop's head the compiler had to assume the
@@ -1449,14 +1529,26 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     if (fast_ok) {
         while (unit_group(u) < nfull) {
             const int un = next_unit(u);     // taken now: its positions are requested a K loop ahead
-            do_group(u, un, std::true_type{});
-            u = un;
+            const int run = dynamic ? round_taken : ru + 1;
+            do_group(u, un, ru, std::true_type{});
+            u = un; ru = run;
         }
     }
     while (unit_group(u) < ngroups) {
         const int un = next_unit(u);
-        do_group(u, un, std::false_type{});
-        u = un;
+        const int run = dynamic ? round_taken : ru + 1;
+        do_group(u, un, ru, std::false_type{});
+        u = un; ru = run;
+    }
+    publish_draw(std::true_type{});
+    if (gdyn && lane == 0) {
+        // the last wave of the launch to finish puts both counters back to zero for the next launch on this scratch set
+        // (every draw of every workgroup has returned by then: a wave stores its draw in the ring before it goes on)
+        const unsigned done = __hip_atomic_fetch_add(p.ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x * (kSharedThreads / 64) - 1) {
+            __hip_atomic_store(p.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.ctr + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (stamp && lane == 0) {
         for (int q = 0; q < 4; ++q) p.stamps[wave * 8 + q] = st_acc[q];
@@ -1539,6 +1631,13 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         p.norm = reinterpret_cast<const float *>(copy + (size_t)2 * nkb * (sizeof(MfmaTileH) / 16));
     }
     p.wtiles = (const uint4 *)a.wtiles; p.frames = (const SharedFrame *)a.frames;
+    // The device-wide draw of the groups (k_deform32_tps_shared_wide, `gdyn`) is built and tested but NOT the default: it
+    // flattens the CU-budget cliff of a pipeline (117-123 k Mverts/s for any budget from 192 to 256 CUs) at a lower level than
+    // the fixed shares reach at their best budget (150 k at 224), because the launch itself is slower with it -- 245 against
+    // 170 us alone at C2 x 32 frames, with or without the atomic (FD_SHARED_DBG=8 deals the fixed shares out through the same
+    // ring); the cause was not found in the time given.  FD_SHARED_DRAW=1 selects it.
+    { static const bool draw = [] { const char *e = getenv("FD_SHARED_DRAW"); return e && atoi(e) != 0; }();
+      p.ctr = (wide && draw) ? a.ctr : nullptr; }
     { static const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
     {
         static const bool no_fast = getenv("FD_SHARED_NO_FAST") != nullptr;       // A/B: general epilogue everywhere
@@ -1564,7 +1663,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
 #else
     p.stamps = nullptr;
 #endif
-    const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)wNT * 64 * 16 + 512 * sizeof(uint64_t) + 16
+    const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)wNT * 64 * 16 + 512 * sizeof(uint64_t) + 16 + 32 * sizeof(int)
                               : sizeof(SharedFrame) * (size_t)shared_slots(nT, dense) + (size_t)nT * 64 * 16;
     const size_t per_kb = wide ? (size_t)1024 + (size_t)wide_w16(wNT) * 16 : 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
     int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);

@@ -238,6 +238,8 @@ struct SharedDeformArgs {
     const double *centres[kMaxBatch];
     int M;
     int *mismatch;
+    unsigned *ctr;                        // two zeroed device words per scratch set: the 32-row kernel draws its groups from a
+                                          // device-wide counter and puts them back to zero itself (null: fixed shares)
 };
 hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream);
 size_t shared_wtile_bytes(int Mpad, int nF);
