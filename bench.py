@@ -94,6 +94,9 @@ def parse_args():
                     help="config c5: rank 0 solves and broadcasts the models (default), or every rank solves them itself")
     ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
                     help="evaluations on one stream for all lanes (default) or on each lane's build stream")
+    ap.add_argument("--group-call", choices=["c", "python"], default="c",
+                    help="shared evaluation: a group is enqueued by ONE foreign call (fd_batch_cook_group, default) or by the five "
+                         "fd_batch_* calls with their pointer tables from Python; the line reports the host time per group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=float, default=3.0e8,
                     help="bound on (vertex, centre) pairs in the CPU baseline sample")
@@ -359,6 +362,39 @@ def masked_streams(torch, dev, n_build_streams, eval_cus, total_cus=256):
     return ev, builds
 
 
+class RawEvents:
+    """Four HIP events of a group, as raw handles: recorded inside fd_batch_cook_group (build start / end on the build
+    stream, evaluation launch start / end on the evaluation stream), read with hipEventElapsedTime."""
+    _hip = None
+
+    def __init__(self, capi):
+        import ctypes
+        if RawEvents._hip is None:
+            RawEvents._hip = ctypes.CDLL("libamdhip64.so")
+            RawEvents._hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+            RawEvents._hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+            RawEvents._hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.h = []
+        for _ in range(4):
+            e = ctypes.c_void_p()
+            if RawEvents._hip.hipEventCreate(ctypes.byref(e)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+            self.h.append(e)
+        self.struct = capi.FdGroupEvents(*[e.value for e in self.h])
+
+    def ms(self, a, b):
+        import ctypes
+        out = ctypes.c_float()
+        rc = RawEvents._hip.hipEventElapsedTime(ctypes.byref(out), self.h[a], self.h[b])
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
+        return float(out.value)
+
+    def close(self):
+        for e in self.h:
+            RawEvents._hip.hipEventDestroy(e)
+
+
 def shared_rows(frames):
     """Rows of the weight operand the shared-rig launch runs for `frames` frames (16 per output tile; mirrors
     launch_deform_shared in csrc/fd_eval.hip: 13 frames and more in blocks of 16, one tile per component;
@@ -426,8 +462,12 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
     if args.eval_cus <= 0:
-        # one-workgroup builds (r2) want 64 CUs to themselves: 192; the register-resident build holds 32 CUs per batch: 224
+        # one-workgroup builds (r2) want 64 CUs to themselves: 192; the register-resident build holds 32 CUs per batch: 224.
+        # A run of a single group (steps <= frames per group: the driver's `--steps 20`) has nothing to build beside its one
+        # evaluation: the whole device.
         args.eval_cus = 192 if (args.build == "one-workgroup" and args.config == "c2") else 224
+        if args.config in ("c2", "c1", "c3") and args.steps <= min(args.inflight, 32):
+            args.eval_cus = 256
     import torch
     import torch.distributed as dist
     from facedeform_amd import capi, synth
@@ -513,7 +553,16 @@ def main():
     shared_eval = args.eval_launch == "shared" and B > 1
     batched_eval = (args.eval_launch == "batched" and B > 1) or shared_eval
 
+    host_s = [0.0, 0]                                  # host time spent enqueueing timed groups, groups
+
     def group(g, first, count, ev=None):
+        th0 = time.perf_counter()
+        _group(g, first, count, ev)
+        if ev is not None:
+            host_s[0] += time.perf_counter() - th0
+            host_s[1] += 1
+
+    def _group(g, first, count, ev=None):
         """Cook steps first .. first+count-1 (count <= B frames) on lane g % n_lanes."""
         ln = lanes[g % n_lanes]
         ln["used"] = max(ln.get("used", 0), count)
@@ -523,6 +572,20 @@ def main():
             ln["batches"][count].set_eval_cus(args.eval_cus)
         batch = ln["batches"][count]
         frames = [((first + k) * world + rank) % N_FRAMES for k in range(count)]
+        es = eval_stream if args.eval_stream == "shared" else stream
+        if shared_eval and args.group_call == "c":
+            # ONE foreign call per group (fd_batch_cook_group): wait_consumed, set-up, builds, packing, the evaluation.
+            key = (count, frames[0])
+            tabs = ln.setdefault("tables", {})
+            if key not in tabs:
+                tabs[key] = batch.group_tables([d_deltas.data_ptr() + f * delta_stride for f in frames],
+                                               [o.data_ptr() for o in ln["out"][:count]], [f.data_ptr() for f in ln["fall"][:count]])
+            # timed groups: four raw HIP events recorded INSIDE the call, around the builds and around the evaluation launch
+            batch.cook_group(stream.cuda_stream, es.cuda_stream, d_rest.data_ptr(), n_ctrl, n_verts, d_P.data_ptr(), tabs[key],
+                             events=ev[first].struct if ev else None)
+            ln["last_shared"] = batch
+            ln["evals_done"].record(es)
+            return
         # The lane's previous group must be done with its models before they are overwritten.  The shared-rig
         # launch copies what it reads of them in its first small kernel (fd_batch_wait_consumed): the next group's
         # assemble + solve then runs while the previous one is still being evaluated.  The other launch styles
@@ -538,7 +601,6 @@ def main():
         batch.build_async(stream.cuda_stream)
         if ev:
             ev[first][1].record(stream)
-        es = eval_stream if args.eval_stream == "shared" else stream
         if shared_eval:
             # the weights become fp16 tiles right here, on the build stream (fd_batch_prepare_shared): the evaluation
             # stream then runs evaluation launches back to back
@@ -602,7 +664,11 @@ def main():
         run_steps(args.steps % B, g0=args.steps // B)
     check_builds()
 
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    c_groups = shared_eval and args.group_call == "c"
+    if c_groups:
+        events = {i: RawEvents(capi) for i in range(0, args.steps, B)}          # one set per group, recorded inside the C call
+    else:
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     # One HIP event pair per run of `event_every` consecutive evaluations of a group (the pair's
     # own cost, ~4 us of launch hand-over, is spread over the run), never starting on the first
     # evaluation of a group: that one also waits for the group's build.
@@ -663,12 +729,14 @@ def main():
 
     # a batched build is timed once per group (events on the group's first step)
     group_firsts = list(range(0, args.steps, B))
-    build_group_ms = float(np.mean([events[i][0].elapsed_time(events[i][1]) for i in group_firsts]))
+    def ev_ms(i, a, b):
+        return events[i].ms(a, b) if c_groups else events[i][a].elapsed_time(events[i][b])
+    build_group_ms = float(np.mean([ev_ms(i, 0, 1) for i in group_firsts]))
     build_ms = build_group_ms / min(B, args.steps)
     if batched_eval:
         # one event pair per evaluation launch; a launch covers the frames of its group
         g_counts = [min(B, args.steps - i) for i in group_firsts]
-        g_ms = [events[i][2].elapsed_time(events[i][3]) for i in group_firsts]
+        g_ms = [ev_ms(i, 2, 3) for i in group_firsts]
         eval_ms = float(np.sum(g_ms) / np.sum(g_counts))                 # per frame
         full = [m for m, c in zip(g_ms, g_counts) if c == max(g_counts)]
         frames_per_launch = int(max(g_counts))
@@ -684,7 +752,7 @@ def main():
         gaps = np.array([events[a][3].elapsed_time(events[b][2]) * 1e3 for a, b in pairs])
         print(f"[gaps us] idle between consecutive timed runs within a group: mean {gaps.mean():.1f} median {np.median(gaps):.1f} "
               f"max {gaps.max():.1f}", file=sys.stderr, flush=True)
-    if rank == 0 and os.environ.get("FD_BENCH_GAPS"):
+    if rank == 0 and os.environ.get("FD_BENCH_GAPS") and not c_groups:
         base = events[0][0]
         first = range(0, args.steps, B)
         for i in list(first[:6]) + list(first[40:52]):
@@ -810,6 +878,10 @@ def main():
                                "frac_batched": (n_ctrl - 4) ** 3 / 3.0 / (build_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
                                "note": "a chain of dependent launches on a small matrix: latency, not flops, bounds it (DESIGN.md 4.2b/4.2c)"},
             "ranks": ranks,
+            # host side of the pipeline: wall time the rank's Python thread spends enqueueing one group (fd_batch_cook_group: one
+            # foreign call; --group-call python: five calls with pointer tables built per group)
+            "host": {"group_call": args.group_call if shared_eval else "python", "us_per_group": host_s[0] / max(1, host_s[1]) * 1e6,
+                     "groups_timed": host_s[1]},
             "phases_ms": {"build_per_frame_batched": build_ms, "build_batch": build_group_ms,
                           "evaluate": eval_ms, "single_cook_latency": latency_ms, "single_build": single_build_ms},
             "eval_only_mverts_s": n_verts / (eval_ms * 1e-3) / 1e6,

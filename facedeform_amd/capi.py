@@ -62,7 +62,7 @@ EXPORTS = [
     "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
     "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
     "fd_morph_get_qr",
-    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error", "fd_batch_wait_consumed", "fd_batch_prepare_shared", "fd_batch_set_eval_cus",
+    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error", "fd_batch_wait_consumed", "fd_batch_prepare_shared", "fd_batch_set_eval_cus", "fd_batch_cook_group",
     "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result", "fd_batch_deform_dev",
     "fd_batch_deform_shared_dev",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
@@ -146,6 +146,7 @@ def load() -> C.CDLL:
     L.fd_batch_wait_consumed.argtypes = [vp, vp]; L.fd_batch_wait_consumed.restype = i32
     L.fd_batch_prepare_shared.argtypes = [vp, vp, vp, vp]; L.fd_batch_prepare_shared.restype = i32
     L.fd_batch_set_eval_cus.argtypes = [vp, i32]; L.fd_batch_set_eval_cus.restype = i32
+    L.fd_batch_cook_group.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp]; L.fd_batch_cook_group.restype = i32
     L.fd_batch_last_error.argtypes = [vp]; L.fd_batch_last_error.restype = C.c_char_p
     L.fd_batch_set_points_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32]
     L.fd_batch_set_points_dev.restype = i32
@@ -397,6 +398,11 @@ class Engine:
 MAX_BATCH = 32
 
 
+class FdGroupEvents(C.Structure):
+    """fd_group_events: raw hipEvent_t handles (ints) a caller owns; NULL members are skipped."""
+    _fields_ = [("before_build", C.c_void_p), ("after_build", C.c_void_p), ("before_eval", C.c_void_p), ("after_eval", C.c_void_p)]
+
+
 class _PinnedBlock:
     def __init__(self, L, ptr):
         self.L, self.ptr = L, ptr
@@ -513,6 +519,22 @@ class Batch:
     def set_eval_cus(self, n_cus: int):
         """fd_batch_set_eval_cus: CUs this batch's shared-rig evaluation launches may occupy (0: all)."""
         self._check(self.L.fd_batch_set_eval_cus(self.h, int(n_cus)))
+
+    def group_tables(self, d_delta_ptrs, d_P_out, d_falloff=None):
+        """The pointer tables of fd_batch_cook_group, built once and reused by a pipeline whose arrays do not move."""
+        n = len(self.engines)
+        vp = C.c_void_p
+        return ((vp * n)(*d_delta_ptrs), (vp * n)(*d_P_out), None if d_falloff is None else (vp * n)(*d_falloff))
+
+    def cook_group(self, build_stream: int, eval_stream: int, d_rest: int, M: int, N: int, d_P_in: int, tables, events=None):
+        """fd_batch_cook_group: one group of frames of a shot -- set-up, builds, packing and the shared-rig evaluation --
+        enqueued by ONE foreign call.  tables = group_tables(...); events: an FdGroupEvents of raw hipEvent_t handles or None."""
+        deltas, outs, falls = tables
+        vp = C.c_void_p
+        self._check(self.L.fd_batch_cook_group(self.h, vp(build_stream or 0), vp(eval_stream or 0), vp(d_rest), deltas, M, N,
+                                               vp(d_P_in), outs, falls, C.byref(events) if events is not None else None))
+        for e in self.engines:
+            e.M = M
 
     def wait_consumed(self, stream_ptr=None):
         """fd_batch_wait_consumed: `stream_ptr` waits until the last shared-rig evaluation has its own copy of

@@ -150,6 +150,7 @@ struct fd_batch {
     float *prep_fall[kMaxBatch] = {nullptr};
     bool prep_has_fall = false;
     hipEvent_t fallback_ev = nullptr;    // behind the per-frame launches when the shared launch does not apply
+    hipEvent_t group_ev = nullptr;       // fd_batch_cook_group: behind the group's builds, for the evaluation stream
     char err[512] = {0};
 };
 
@@ -295,6 +296,8 @@ static int sync_slot(fd_ctx *ctx)
     t.rec32 = ctx->d_rec32; t.rec64 = ctx->d_rec64; t.tiles = ctx->d_tiles; t.tiles16 = ctx->d_tiles16;
     t.model = ctx->d_model;
     t.ns = ctx->d_ns;
+    t.host_status = nullptr;
+    if (ctx->h_status && hipHostGetDevicePointer((void **)&t.host_status, ctx->h_status, 0) != hipSuccess) { (void)hipGetLastError(); t.host_status = nullptr; }
     if (ctx->alloc_gen != 0 && memcmp(&t, &ctx->h_slot, sizeof(t)) == 0) return FD_OK;
     // a buffer moved: hipFree in dev_alloc has drained the device, nothing reads the old table
     FD_HIP(ctx, hipMemcpy(ctx->d_slot, &t, sizeof(t), hipMemcpyHostToDevice));
@@ -697,6 +700,12 @@ int fd_build_async(fd_ctx *ctx)
         ctx->built = false;
         ctx->have_report = false;
         ctx->sticky_rc = FD_OK;
+        if (ctx->h_slot.host_status) {
+            // the build's own last thread has posted the status word: the event behind the build is the one to poll
+            ctx->status_poll = ctx->ev1;
+            ctx->status_inflight = true;
+            return FD_OK;
+        }
         return post_status(ctx, st);
     }
     if (make_lookahead(&ctx->lu_stream, ctx->lu_events)) {
@@ -1394,7 +1403,7 @@ void fd_batch_destroy(fd_batch *b)
             c->wait_event = nullptr; c->wait_stream = nullptr; c->wait_batch = nullptr;
         }
         if (c && c->tev0 == b->ev0) { c->tev0 = c->ev0; c->tev_mid = c->ev_mid; c->tev1 = c->ev1; }
-        if (c && c->status_poll == b->status_ev) { c->status_poll = c->status_ev; c->status_inflight = false; }
+        if (c && (c->status_poll == b->status_ev || c->status_poll == b->ev1)) { c->status_poll = c->status_ev; c->status_inflight = false; }
     }
     if (b->status_ev) (void)hipEventDestroy(b->status_ev);
     if (b->exec) (void)hipGraphExecDestroy(b->exec);
@@ -1409,6 +1418,7 @@ void fd_batch_destroy(fd_batch *b)
         if (st.eval_ev) (void)hipEventDestroy(st.eval_ev);
     }
     if (b->fallback_ev) (void)hipEventDestroy(b->fallback_ev);
+    if (b->group_ev) (void)hipEventDestroy(b->group_ev);
     if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
@@ -1564,7 +1574,12 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     }
     // the statuses of all contexts: one launch, one event (recorded on every context's own event
     // object would cost a stream operation each)
-    {
+    bool posted_in_kernel = bb.reg != 0;
+    for (int i = 0; i < b->n; ++i) posted_in_kernel = posted_in_kernel && b->ctxs[i]->h_slot.host_status != nullptr;
+    if (posted_in_kernel) {
+        // (the register-resident build posts every context's status word itself: no status kernel behind it)
+        for (int i = 0; i < b->n; ++i) { b->ctxs[i]->status_poll = b->ev1; b->ctxs[i]->status_inflight = true; }
+    } else {
         StatusTable st{};
         bool ok = true;
         for (int i = 0; i < b->n && ok; ++i) {
@@ -1595,9 +1610,13 @@ static int batch_poll(fd_batch *b)
     for (int i = 0; i < b->n; ++i) any = any || b->ctxs[i]->status_inflight || b->ctxs[i]->sticky_rc != FD_OK;
     if (!any) return FD_OK;
     bool shared_pending = false;
-    for (int i = 0; i < b->n; ++i) shared_pending = shared_pending || (b->ctxs[i]->status_inflight && b->ctxs[i]->status_poll == b->status_ev);
+    hipEvent_t shared_ev = nullptr;
+    for (int i = 0; i < b->n; ++i)
+        if (b->ctxs[i]->status_inflight && (b->ctxs[i]->status_poll == b->status_ev || b->ctxs[i]->status_poll == b->ev1)) {
+            shared_pending = true; shared_ev = b->ctxs[i]->status_poll;
+        }
     if (shared_pending) {
-        const hipError_t q = hipEventQuery(b->status_ev);
+        const hipError_t q = hipEventQuery(shared_ev);
         if (q == hipErrorNotReady) { (void)hipGetLastError(); return FD_OK; }
     }
     for (int i = 0; i < b->n; ++i) {
@@ -1861,6 +1880,38 @@ int fd_batch_wait_consumed(fd_batch *b, void *hip_stream)
         return FD_E_DEVICE;
     }
     return FD_OK;
+}
+
+int fd_batch_cook_group(fd_batch *b, void *build_stream, void *eval_stream, const float *d_rest_xyz,
+                        const float *const *d_delta_xyz, int M, int64_t N, const float *d_P_in, float *const *d_P_out,
+                        float *const *d_falloff_out, const fd_group_events *events)
+{
+    if (!b || !d_rest_xyz || !d_delta_xyz || !d_P_out) return FD_E_INVALID;
+    fd_ctx *c0 = b->ctxs[0];
+    hipStream_t bs = build_stream ? (hipStream_t)build_stream : cur_stream(c0);
+    hipStream_t es = eval_stream ? (hipStream_t)eval_stream : bs;
+    auto mark = [&](void *ev, hipStream_t st) { if (ev && hipEventRecord((hipEvent_t)ev, st) != hipSuccess) (void)hipGetLastError(); };
+    int rc = fd_batch_wait_consumed(b, build_stream);
+    if (rc) return rc;
+    const float *rest[kMaxBatch];
+    for (int i = 0; i < b->n; ++i) rest[i] = d_rest_xyz;
+    if ((rc = fd_batch_set_points_dev(b, rest, d_delta_xyz, M))) return rc;
+    if (events) mark(events->before_build, bs);
+    if ((rc = fd_batch_build_async(b, build_stream))) return rc;
+    if (events) mark(events->after_build, bs);
+    if ((rc = fd_batch_prepare_shared(b, build_stream, d_P_out, d_falloff_out))) return rc;
+    if (es != bs) {
+        // (the evaluation waits for the pack kernel's event inside fd_batch_deform_shared_dev when the set was prepared; the
+        // per-frame fallback -- other kernels -- needs the builds themselves)
+        if (!make_event(&b->group_ev) || hipEventRecord(b->group_ev, bs) != hipSuccess || hipStreamWaitEvent(es, b->group_ev, 0) != hipSuccess) {
+            batch_err(b, "fd_batch_cook_group: ordering the evaluation stream failed: %s", hipGetErrorString(hipGetLastError()));
+            return FD_E_DEVICE;
+        }
+    }
+    if (events) mark(events->before_eval, es);
+    rc = fd_batch_deform_shared_dev(b, es, N, d_P_in, d_P_out, nullptr, d_falloff_out, nullptr, nullptr, nullptr, 1.0f, 1.0f);
+    if (events) mark(events->after_eval, es);
+    return rc;
 }
 
 int fd_batch_set_eval_cus(fd_batch *b, int n_cus)

@@ -121,6 +121,8 @@ struct BatchSlot {
     MfmaTileH *tiles16;               // the fp16 form of the same tiles
     DevModel *model;
     double *ns;                       // null-space solver state (fd_nullspace.hip): ns_doubles(M) doubles
+    int *host_status;                 // the context's page-locked status word as the device sees it (or null): the packing code
+                                      // posts terminationtype there itself, so a one-launch build needs no status kernel behind it
 };
 
 // Caller-owned device arrays of control points, one pair per model of a batch (kernel argument).

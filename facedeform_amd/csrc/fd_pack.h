@@ -162,6 +162,7 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
             if (model->dup_flag) tt = -5;
         }
         model->terminationtype = tt;
+        if (slot.host_status) *slot.host_status = tt;        // page-locked: the host polls it behind the build's event (fd_capi.hip)
     }
 }
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 6   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus (additions only) */
+#define FD_ABI_VERSION 7   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN (additions only) */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -358,6 +358,25 @@ int fd_batch_prepare_shared(fd_batch *batch, void *hip_stream, float *const *d_P
  * leave some CUs to those builds.  n_cus <= 0 or >= the device's CU count: all of them (the default).  Per batch, not
  * per process: two nodes cooking side by side choose independently (round 2 read an environment variable once). */
 int fd_batch_set_eval_cus(fd_batch *batch, int n_cus);
+/* One GROUP of frames of a shot in one call -- what a frame pipeline enqueues per group, in the order it must be enqueued:
+ *   fd_batch_wait_consumed(batch, build_stream)            the batch's previous evaluation has its own copy of the models
+ *   fd_batch_set_points_dev(batch, d_rest, d_delta, M)      (the SAME rest array for every context: frames of one rig)
+ *   fd_batch_build_async(batch, build_stream)               every frame's model: assembled, factorised, solved
+ *   fd_batch_prepare_shared(batch, build_stream, ...)       weights -> fp16 tiles, beside the builds
+ *   eval_stream waits for build_stream;  fd_batch_deform_shared_dev(batch, eval_stream, ...)
+ * build_stream / eval_stream: the caller's HIP streams (eval_stream NULL: the evaluation goes on build_stream).  d_rest_xyz:
+ * the one rest rig; d_delta_xyz: n pointers, one per context.  No d_dist2 / tangent frames: a group that needs them
+ * makes the calls above itself.  Replaces, for n frames, n cooks of reference src/SOP_FaceDeform.cpp:268-287, 331-368, 404-439.
+ * A host language pays for ONE foreign call per group instead of five with pointer tables (bench.py reports both).
+ * events (may be NULL): four caller-owned hipEvent_t handles recorded around the builds (on build_stream) and around the
+ * evaluation launch (on eval_stream), for callers that time the pieces; NULL members are skipped. */
+typedef struct fd_group_events {
+    void *before_build, *after_build;      /* hipEvent_t, recorded on build_stream */
+    void *before_eval, *after_eval;        /* hipEvent_t, recorded on eval_stream, around the evaluation launch alone */
+} fd_group_events;
+int fd_batch_cook_group(fd_batch *batch, void *build_stream, void *eval_stream, const float *d_rest_xyz,
+                        const float *const *d_delta_xyz, int M, int64_t N, const float *d_P_in, float *const *d_P_out,
+                        float *const *d_falloff_out, const fd_group_events *events);
 
 /* ---- dist2 producer (next row N2) ---------------------------------------------
  * The per-point body of ProximityCapture::capture (src/capture.cpp:58-97) on the

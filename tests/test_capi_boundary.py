@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(hip_lib):
 
 
 def test_abi_version(hip_lib):
-    assert hip_lib.fd_abi_version() == 6   # 6: fd_batch_set_eval_cus; 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres; 4: fd_mesh_capture + the capture inputs of fdsop_geo; 5: fd_batch_wait_consumed
+    assert hip_lib.fd_abi_version() == 7   # 7: fd_batch_cook_group + the solver names; 6: fd_batch_set_eval_cus; 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres; 4: fd_mesh_capture + the capture inputs of fdsop_geo; 5: fd_batch_wait_consumed
 
 
 def test_struct_layouts_match_header():
