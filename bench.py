@@ -775,10 +775,31 @@ def main():
                 tj = {}
 
         def measured_traffic(kernel):
+            """HBM bytes of one launch from the COMMITTED counter passes -- not a measurement of this run, and only quoted when
+            this run's launches carry as many frames as the profiled ones did (no extrapolation to another frame count)."""
+            k = tj.get(kernel)
+            if not k or k.get("frames_per_launch", 1) != frames_per_launch:
+                return None
+            return k.get("hbm_bytes_per_launch", k["hbm_bytes_fixed_per_launch"] + k["hbm_bytes_per_frame"] * frames_per_launch)
+
+        def committed_pmc(kernel):
             k = tj.get(kernel)
             if not k:
                 return None
-            return k["hbm_bytes_fixed_per_launch"] + k["hbm_bytes_per_frame"] * frames_per_launch
+            return {"source": f"profiles/traffic_{args.config}.json", "round": k.get("round"), "frames_measured": k.get("frames_per_launch"),
+                    "hbm_bytes_per_launch_measured": k.get("hbm_bytes_per_launch"),
+                    "hbm_bytes_fixed_per_launch": k.get("hbm_bytes_fixed_per_launch"), "hbm_bytes_per_frame": k.get("hbm_bytes_per_frame"),
+                    "mfma_busy_frac": k.get("mfma_busy_frac"), "wait_inst_frac": k.get("wait_inst_frac"),
+                    "note": "rocprofv3 --pmc passes of an earlier run of this command (profiles/), not counters of this run"}
+
+        # the kernel that takes most GPU time in the committed kernel trace of this command, and where it stands against its roof
+        dominant = None
+        dpath = os.path.join(ROOT, "profiles", f"dominant_{args.config}.json")
+        if os.path.exists(dpath):
+            try:
+                dominant = json.load(open(dpath))
+            except Exception:
+                dominant = None
         mfma_eval = precision == capi.EVAL_FP32 and n_ctrl >= 49
         use_shared = shared_eval and mfma_eval and n_ctrl >= 32
         if use_shared:
@@ -798,9 +819,7 @@ def main():
                         "frac": flops_launch / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS, "flops_per_launch": flops_launch,
                         "executed": {"achieved": mfma_exec / secs / 1e12, "frac": mfma_exec / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                                      "note": "what the pipe runs: fp16 x 2 split = three products"},
-                        # from the committed PMC passes of this kernel (profiles/r02_pmc_shared_c2.txt): share of SIMD-cycles the
-                        # matrix pipe is busy, share of wave-cycles spent waiting for an instruction to issue
-                        "pmc": {k: tj.get(kern, {}).get(k) for k in ("mfma_busy_frac", "wait_inst_frac")}}
+                        }
             hbm_alg = {"achieved": bytes_launch / secs / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": bytes_launch / secs / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": bytes_launch}
             # Which roof binds is the roofline model's answer at the launch's ALGORITHMIC intensity: below the
@@ -811,7 +830,8 @@ def main():
             first, second, key = (hbm_alg, mfma_alg, "mfma") if intensity < ridge else (mfma_alg, hbm_alg, "hbm")
             roof = {"bound": "hbm" if intensity < ridge else "mfma", "kernel": kern,
                     "achieved": first["achieved"], "peak": first["peak"], "unit": first["unit"], "frac": first["frac"],
-                    "traffic": measured_traffic(kern), "avg_launch_ms": launch_ms, "frames_per_launch": Fl,
+                    "traffic": measured_traffic(kern), "committed_pmc": committed_pmc(kern), "dominant_by_gpu_time": dominant,
+                    "avg_launch_ms": launch_ms, "frames_per_launch": Fl,
                     "intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
                     "bytes_per_launch": bytes_launch, "flops_per_launch": flops_launch, key: second,
                     ("hbm" if key == "mfma" else "mfma"): first}
@@ -825,7 +845,8 @@ def main():
                 # ~90-100 % of busy cycles, MFMA pipe busy 13-17 %).  Roof: 157.3 TFLOP/s fp32 vector.
                 "bound": "valu_fp32", "kernel": kern,
                 "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": measured_traffic(kern),
+                "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": measured_traffic(kern), "committed_pmc": committed_pmc(kern),
+                "dominant_by_gpu_time": dominant,
                 # a launch evaluates frames_per_launch frames (algorithmic flops per frame x frames)
                 "flops_per_launch": flops * frames_per_launch, "avg_launch_ms": launch_ms,
                 "frames_per_launch": frames_per_launch,

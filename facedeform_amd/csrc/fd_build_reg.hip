@@ -210,10 +210,12 @@ __device__ __forceinline__ RegLds carve(double *base, int)
 //   3. rows below -= L_rb rows_b: the multipliers L_rb = (S_rb L_bb^-T) are the transpose of what step 2 left in the T part
 //      (the Schur complement is symmetric) -- lane (m, k) of that result holds L[m][4 b + k]: the A operand as it sits.
 // After four rounds U = inv(L).  Pivots at or below `tiny` (or NaN) are flagged and their rows zeroed, as everywhere else.
-struct PivotStats { double pmin, pmax; bool singular; };
-__device__ __forceinline__ double4_t factor_invert_tile(double4_t Tt, double tiny, int live_cols, PivotStats &st, int lane)
+// `piv`: lane (c, .) comes back with the pivot of column c as it was met (the caller keeps the statistics per lane and
+// reduces them once, after the last block).
+__device__ __forceinline__ double4_t factor_invert_tile(double4_t Tt, int lane, double &piv)
 {
     const int c = lane & 15, g = lane >> 4;
+    piv = 0.0;
     double4_t U;
 #pragma unroll
     for (int i = 0; i < 4; ++i) U[i] = (g + 4 * i == c) ? 1.0 : 0.0;
@@ -243,15 +245,8 @@ __device__ __forceinline__ double4_t factor_invert_tile(double4_t Tt, double tin
                 l[p][k] = v * inv[k];
             }
         }
-        // pivot statistics, off the chain
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool live = 4 * b + k < live_cols;
-            const double ad = fabs(dk[k]);
-            st.singular = st.singular || (live && !(dk[k] > tiny));
-            st.pmin = (live && ad < st.pmin) ? ad : st.pmin;
-            st.pmax = (live && ad > st.pmax) ? ad : st.pmax;
-        }
+        for (int k = 0; k < 4; ++k) piv = c == 4 * b + k ? dk[k] : piv;
         // inverse of the 4 x 4 factor (lower triangular): m[p][q]
         double m[4][4];
 #pragma unroll
@@ -283,6 +278,18 @@ __device__ __forceinline__ double4_t factor_invert_tile(double4_t Tt, double tin
     return U;
 }
 
+// Which worker holds tile (I, J) of the lower triangle.  Column J is dealt round-robin from a per-column offset, and diagonal
+// tile (J, J) sits with the tile left of it, (J, J - 1): in the factorisation that wave solves (J, J - 1) first, applies it
+// to the diagonal tile at once and hands that to the factor wave, which then works beside everything else of the step.
+// The offsets (three bits per column) balance the load: at 16 x 16 tiles the workers hold 19 or 20 each, and no more than
+// kSlots for any smaller triangle.  Correctness does not rest on the co-location (see the hand-over in the step loop).
+__device__ __forceinline__ int tile_owner(int I, int J)
+{
+    constexpr unsigned long long kOffsets = 0x161675511c9bull;
+    if (I == J) return J == 0 ? 0 : (J + (int)((kOffsets >> (3 * (J - 1))) & 7ull)) % kWorkers;
+    return (I + (int)((kOffsets >> (3 * J)) & 7ull)) % kWorkers;
+}
+
 __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab, const PointSrc src, int use_src, int M, int T, int npad,
                                                             int kind, int Mpad, double lambda, double gauss_R, unsigned long long *stamps)
 {
@@ -303,12 +310,25 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     __builtin_amdgcn_s_setprio(3);
 
     // ---- control table (reference :268-287, widened to fp64), status reset, tile table
-    // tile q: column J of the lower triangle top to bottom (I = J .. nbk - 1); worker q % 7, slot q / 7
+    // Worker wave w lists its own tiles (tile_owner) in column-major order of the lower triangle: slot t of wave w is
+    // L.tab[w * kSlots + t] = I | J << 8 | q << 16 (0xffff: none).  Ranks by ballot: three rounds of 64 tiles.
     const int ntiles = nbk * (nbk + 1) / 2;
-    if (tid < ntiles) {
-        int q = tid, J = 0;
-        while (q >= nbk - J) { q -= nbk - J; ++J; }
-        L.tab[tid] = (J + q) | (J << 8);
+    int nmine = 0;
+    if (worker) {
+        if (lane < kSlots) L.tab[wave * kSlots + lane] = 0xffff;
+        wave_lds_sync();
+        for (int q0 = 0; q0 < ntiles; q0 += 64) {
+            int q = q0 + lane, J = 0;
+            const bool in = q < ntiles;
+            while (in && q >= nbk - J) { q -= nbk - J; ++J; }
+            const int I = J + q;
+            const bool mine = in && tile_owner(I, J) == wave;
+            const unsigned long long mask = __ballot(mine);
+            const int rank = nmine + __popcll(mask & ((1ull << lane) - 1ull));
+            if (mine) L.tab[wave * kSlots + rank] = I | (J << 8) | ((q0 + lane) << 16);   // (+ its column-major number: staging index)
+            nmine += __popcll(mask);
+        }
+        nmine = __builtin_amdgcn_readfirstlane(nmine);
     }
     {
         const float *rest = use_src ? src.rest[blockIdx.z] : slot.rest;
@@ -331,7 +351,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             if (e < 3 * kRows && e >= 3 * M) L.cen[e] = 0.0;
         }
     }
-    if (tid == 0) { L.stat[0] = INFINITY; L.stat[1] = 0.0; L.stat[2] = 0.0; L.stat[3] = 0.0; *L.flag = 0; }
+    if (tid == 0) { L.stat[0] = INFINITY; L.stat[1] = 0.0; L.stat[2] = 0.0; L.stat[3] = 0.0; L.flag[0] = 0; L.flag[1] = 0; L.flag[2] = 0; L.flag[3] = 0; }
     __syncthreads();
     // Lane t of `ijv` holds the coordinates of the wave's slot t (I | J << 8; 0xffff: no tile).  Which slots a phase touches
     // is ONE ballot over that register (a bit mask, then a bit test per slot); a slot's coordinates come out with one
@@ -340,12 +360,12 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     // the coordinates visibly loop-invariant the compiler hoists every tile's LDS addresses out of the step loop -- 40 more
     // live registers beside those of the tiles, and spills.)
     int ijv = 0xffff;
-    if (worker && lane < kSlots && wave + kWorkers * lane < ntiles) ijv = L.tab[wave + kWorkers * lane];
-    const int ivI = ijv & 0xff, ivJ = ijv >> 8;
+    if (worker && lane < kSlots) ijv = L.tab[wave * kSlots + lane];
+    const int ivI = ijv & 0xff, ivJ = (ijv >> 8) & 0xff;
     auto slots_where = [&](bool cond) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__ballot(cond && lane < kSlots)); };
     const unsigned m_matrix = slots_where(ivI < kMaxBlocks);              // the wave's tiles
 #define tI(t) (opaque_s(__builtin_amdgcn_readlane(ijv, t)) & 0xff)
-#define tJ(t) (opaque_s(__builtin_amdgcn_readlane(ijv, t)) >> 8)
+#define tJ(t) ((opaque_s(__builtin_amdgcn_readlane(ijv, t)) >> 8) & 0xff)
 #define FD_SLOT(m, t) (((m) >> (t)) & 1u)
     FD_RSTAMP()
 
@@ -360,9 +380,9 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         double amax_w = 0.0;
         bool dup = false;
 #pragma nounroll
-        for (int q = wave; q < ntiles; q += kWorkers) {
-            const int ij = __builtin_amdgcn_readfirstlane(L.tab[q]);
-            const int I = ij & 0xff, J = ij >> 8;
+        for (int t = 0; t < nmine; ++t) {
+            const int ij = __builtin_amdgcn_readfirstlane(L.tab[wave * kSlots + t]);
+            const int I = ij & 0xff, J = (ij >> 8) & 0xff, q = ij >> 16;
             const int col = 16 * J + c;
             const double cx = L.cen[3 * col], cy = L.cen[3 * col + 1], cz = L.cen[3 * col + 2];
             double d2[4], e[4];
@@ -538,7 +558,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         gcdouble *stage = as_global(slot.A);
 #pragma unroll
         for (int t = 0; t < kSlots; ++t) {
-            const int q = wave + kWorkers * t;
+            const int q = __builtin_amdgcn_readlane(ijv, t) >> 16;
             S[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
             if (FD_SLOT(m_matrix, t)) {                      // (a wave reads back what it stored itself)
 #pragma unroll
@@ -718,31 +738,21 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     // z_K = f_K inv(L_KK)^T once everything before has been applied, and a worker that holds panel tile (I, K) subtracts
     // z_K L_IK^T from block I when it applies that panel.
     const double tiny = (double)n1 * kEps * amax;
-    PivotStats pst = {INFINITY, 0.0, false};
+    double piv_min = INFINITY, piv_max = 0.0;         // (wave 7, per lane = per column of the block; reduced after the loop)
+    bool piv_bad = false;
+    // flag[0]: diagonal block handed to wave 7; [1]: z blocks written; [2]: panel tile (K+1, K) in LDS; [3]: workers past a step
+#define FD_SPIN_UNTIL(cond) { int spin_ = 0; while (!(cond) && ++spin_ < (1 << 20)) __builtin_amdgcn_s_sleep(1); \
+                              if (spin_ >= (1 << 20) && lane == 0) L.stat[2] = 1.0; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#define FD_FLAG(i) __hip_atomic_load(L.flag + (i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define FD_POST(i, v) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) __hip_atomic_store(L.flag + (i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     for (int K = 0; K < nb; ++K) {
         if (worker) {
             if (K > 0) {
                 const int Kp = K - 1;
-                const unsigned m_diag = slots_where(ivI == K && ivJ == K);
-                const unsigned m_upd = slots_where(ivJ > Kp && ivJ < nb && ivI < nb && !(ivI == K && ivJ == K));
+                const unsigned m_upd = slots_where(ivJ > Kp && ivJ < nb && ivI < nb && !(ivI == K && ivJ == K));   // (the diagonal tile went ahead in the last step)
                 const unsigned m_col = slots_where(ivJ == Kp && ivI > Kp && ivI < nb);       // my tiles of panel K - 1: their share of the right-hand sides
-                // the next diagonal tile first: the factor wave is waiting for it
-#pragma unroll
-                for (int t = 0; t < kSlots; ++t) {
-                    if (FD_SLOT(m_diag, t)) {
-                        const double *pa = L.P + (size_t)K * kTileLds;
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const double a = pa[c * kPitch + 4 * s + g];
-                            S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, a, S[t], 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) L.D[(g + 4 * i) * kPitch + c] = S[t][i];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) __hip_atomic_store(L.flag, K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
                 // right-hand sides: f_I -= z_Kp L_I,Kp^T for my panel tiles (A = z_Kp as three rows, B = the panel tile from LDS)
+                if (m_col) FD_SPIN_UNTIL(FD_FLAG(1) >= K)
 #pragma unroll
                 for (int t = 0; t < kSlots; ++t) {
                     if (FD_SLOT(m_col, t)) {
@@ -757,7 +767,8 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                         if (g < 3) L.F[g * kRows + 16 * I + c] -= acc[0];
                     }
                 }
-                // the rest of the trailing matrix: C_IJ -= L_I,Kp L_J,Kp^T
+                // the trailing matrix: C_IJ -= L_I,Kp L_J,Kp^T.  (Fetching the operands of slot t + 1 before the matrix instructions
+                // of slot t -- two register sets -- was tried: 34 more spilled registers, and every step slower, 198k -> 225k cycles.)
 #pragma unroll
                 for (int t = 0; t < kSlots; ++t) {
                     if (FD_SLOT(m_upd, t)) {
@@ -769,28 +780,72 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 }
             }
         } else {
-            if (K > 0) {
-                while (__hip_atomic_load(L.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != K) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
+            if (K > 0) FD_SPIN_UNTIL(FD_FLAG(0) >= K)
             double4_t Td;
 #pragma unroll
             for (int i = 0; i < 4; ++i) Td[i] = L.D[(g + 4 * i) * kPitch + c];
-            const int live = n1 - 16 * K < 16 ? n1 - 16 * K : 16;
-            const double4_t U = factor_invert_tile(Td, tiny, live, pst, lane);
+            double piv;
+            const double4_t U = factor_invert_tile(Td, lane, piv);
             double *dst = L.minv + (size_t)K * kTileLds;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = U[i];
+            const bool live = 16 * K + c < n1;
+            const double ad = fabs(piv);
+            piv_bad = piv_bad || (live && !(piv > tiny));
+            piv_min = (live && ad < piv_min) ? ad : piv_min;
+            piv_max = (live && ad > piv_max) ? ad : piv_max;
         }
         __syncthreads();                              // inverse K is in LDS; panel K - 1 has been applied everywhere
         if (stamps && blockIdx.z == 0 && tid == 0) stamps[16 + 2 * K] = __builtin_amdgcn_s_memtime() - st_prev;
         if (worker) {
-            // the tiles below the diagonal block: L_IK = C_IK inv(L_KK)^T, through the tile's own slot of the panel buffer
-            const unsigned m_panel = slots_where(ivJ == K && ivI > K && ivI < nb);
+            // the tiles below the diagonal block: L_IK = C_IK inv(L_KK)^T, through the tile's own slot of the panel buffer.
+            // Tile (K + 1, K) first and alone; its wave applies it to diagonal tile K + 1 straight away and hands that over:
+            // wave 7 factorises block K + 1 beside the rest of this step and the updates of the next.
+            const bool more = K + 1 < nb;
+            const unsigned m_crit = slots_where(more && ivJ == K && ivI == K + 1);
+            const unsigned m_next = slots_where(more && ivJ == K + 1 && ivI == K + 1);
+            const unsigned m_panel = slots_where(ivJ == K && ivI > K + 1 && ivI < nb);
             const double *mk = L.minv + (size_t)K * kTileLds;
             double bop[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) bop[s] = mk[c * kPitch + 4 * s + g];         // B[k][n] = inv[n][4 s + k]
+            if (m_crit) {
+                double *pk = L.P + (size_t)(K + 1) * kTileLds;
+#pragma unroll
+                for (int t = 0; t < kSlots; ++t) {
+                    if (FD_SLOT(m_crit, t)) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pk[(g + 4 * i) * kPitch + c] = S[t][i];
+                        wave_lds_sync();
+                        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pk[c * kPitch + 4 * s + g], bop[s], acc, 0, 0, 0);
+                        S[t] = acc;
+                        wave_lds_sync();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pk[(g + 4 * i) * kPitch + c] = acc[i];
+                    }
+                }
+                FD_POST(2, K + 1)
+            }
+            if (m_next) {
+                // (the same wave by tile_owner's construction, and then the flag is already up; any other map waits here)
+                FD_SPIN_UNTIL(FD_FLAG(2) >= K + 1)
+                const double *pa = L.P + (size_t)(K + 1) * kTileLds;
+#pragma unroll
+                for (int t = 0; t < kSlots; ++t) {
+                    if (FD_SLOT(m_next, t)) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const double a = pa[c * kPitch + 4 * s + g];
+                            S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, a, S[t], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) L.D[(g + 4 * i) * kPitch + c] = S[t][i];
+                    }
+                }
+                FD_POST(0, K + 1)
+            }
 #pragma unroll
             for (int t = 0; t < kSlots; ++t) {
                 if (FD_SLOT(m_panel, t)) {
@@ -819,21 +874,31 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                     for (int i = 0; i < 4; ++i) dst[(g + 4 * i) * kPitch + c] = S[t][i];
                 }
             }
-        } else if (lane < 48) {
+            // the workers meet (wave 7 is already on the next block): panel K is in LDS for everybody
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(L.flag + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FD_SPIN_UNTIL(FD_FLAG(3) >= kWorkers * (K + 1))
+        } else {
             // z_K = f_K inv(L_KK)^T: lanes = (right-hand side, column)
-            const int rhs = lane >> 4, n = lane & 15;
-            const double *mk = L.minv + (size_t)K * kTileLds;
-            double z = 0.0;
+            if (lane < 48) {
+                const int rhs = lane >> 4, n = lane & 15;
+                const double *mk = L.minv + (size_t)K * kTileLds;
+                double z = 0.0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) z = fma(L.F[rhs * kRows + 16 * K + k], mk[n * kPitch + k], z);
-            L.Z[rhs * 256 + 16 * K + n] = z;
+                for (int k = 0; k < 16; ++k) z = fma(L.F[rhs * kRows + 16 * K + k], mk[n * kPitch + k], z);
+                L.Z[rhs * 256 + 16 * K + n] = z;
+            }
+            FD_POST(1, K + 1)
         }
-        __syncthreads();                              // panel K and z_K are in LDS
         if (stamps && blockIdx.z == 0 && tid == 0) stamps[17 + 2 * K] = __builtin_amdgcn_s_memtime() - st_prev;
     }
-    if (!worker && lane == 0) {
-        L.stat[0] = pst.pmin; L.stat[1] = pst.pmax;
-        if (pst.singular) L.stat[2] = 1.0;
+    if (!worker) {
+        piv_min = -wave_max(-piv_min); piv_max = wave_max(piv_max);
+        const bool bad = __any(piv_bad);
+        if (lane == 0) {
+            L.stat[0] = piv_min; L.stat[1] = piv_max;
+            if (bad) L.stat[2] = 1.0;
+        }
     }
     FD_RSTAMP()
 
