@@ -34,7 +34,8 @@ class FdConfig(C.Structure):
 class FdReport(C.Structure):
     _fields_ = [("terminationtype", C.c_int), ("iterationscount", C.c_int), ("n", C.c_int),
                 ("reserved", C.c_int), ("pivot_ratio", C.c_double), ("t_assemble_ms", C.c_float),
-                ("t_solve_ms", C.c_float)]
+                ("t_solve_ms", C.c_float), ("fp32_error", C.c_double), ("cancellation", C.c_double),
+                ("delta_min", C.c_double), ("delta_max", C.c_double), ("extent", C.c_double)]
 
 
 class FdsopGeo(C.Structure):
@@ -52,7 +53,7 @@ class FdsopGeo(C.Structure):
 
 # every symbol include/facedeform_hip.h declares
 EXPORTS = [
-    "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_points",
+    "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_eval_precision", "fd_fp32_holds", "fd_set_points",
     "fd_set_points_dev", "fd_set_deltas", "fd_set_deltas_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_centres", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
@@ -94,6 +95,8 @@ def load() -> C.CDLL:
     L.fd_last_error.argtypes = [vp]; L.fd_last_error.restype = C.c_char_p
     L.fd_abi_version.argtypes = []; L.fd_abi_version.restype = i32
     L.fd_set_stream.argtypes = [vp, vp]; L.fd_set_stream.restype = i32
+    L.fd_set_eval_precision.argtypes = [vp, i32]; L.fd_set_eval_precision.restype = i32
+    L.fd_fp32_holds.argtypes = [C.POINTER(FdReport), C.c_double]; L.fd_fp32_holds.restype = i32
     L.fd_set_points.argtypes = [vp, vp, vp, i32]; L.fd_set_points.restype = i32
     L.fd_set_points_dev.argtypes = [vp, vp, vp, i32]; L.fd_set_points_dev.restype = i32
     L.fd_set_deltas.argtypes = [vp, vp, i32]; L.fd_set_deltas.restype = i32
@@ -220,6 +223,14 @@ class Engine:
 
     def set_stream(self, stream_ptr: int | None):
         self._check(self.L.fd_set_stream(self.ctx, C.c_void_p(stream_ptr or 0)))
+
+    def set_eval_precision(self, precision: int):
+        """EVAL_FP32 / EVAL_FP64 for the evaluations from here on (a built model carries both records)."""
+        self._check(self.L.fd_set_eval_precision(self.ctx, precision))
+
+    def fp32_holds(self, report: "FdReport", tol: float = 1e-5) -> bool:
+        """fd_fp32_holds: is the fp32 evaluation of the reported model expected to hold tol of every vertex's displacement?"""
+        return bool(self.L.fd_fp32_holds(C.byref(report), tol))
 
     def set_points(self, rest, delta):
         rest = np.ascontiguousarray(rest, np.float32).reshape(-1, 3)

@@ -788,6 +788,8 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
         memcpy(&pmax, &ctx->h_model->pivmax_bits, 8);
         r.pivot_ratio = (pmax > 0.0 && pmin <= pmax) ? pmin / pmax : 0.0;
         float ms = 0.f;
+        r.fp32_error = ctx->h_model->fp32_error; r.cancellation = ctx->h_model->cancellation;
+        r.delta_min = ctx->h_model->delta_min; r.delta_max = ctx->h_model->delta_max; r.extent = ctx->h_model->extent;
         if (hipEventElapsedTime(&ms, ctx->tev0, ctx->tev_mid) == hipSuccess) r.t_assemble_ms = ms;
         if (hipEventElapsedTime(&ms, ctx->tev_mid, ctx->tev1) == hipSuccess) r.t_solve_ms = ms;
         ctx->report = r;
@@ -812,6 +814,22 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
     if (ctx->report.terminationtype == -5) { set_err(ctx, "fd_build: coincident control points"); return FD_E_DUPLICATE; }
     set_err(ctx, "fd_build: singular system (terminationtype %d)", ctx->report.terminationtype);
     return FD_E_SINGULAR;
+}
+
+int fd_fp32_holds(const fd_report *report, double tol)
+{
+    if (!report || report->terminationtype != 1) return 0;
+    if (!(report->delta_max > 0.0)) return 1;             // nothing to measure against (imported model, or no displacement at all)
+    const double ulp = 5.9604644775390625e-08 * (report->extent + report->delta_max);
+    return report->fp32_error <= tol * 0.5 * report->delta_min + ulp ? 1 : 0;     // (vertices between control points move less than the least of those)
+}
+
+int fd_set_eval_precision(fd_ctx *ctx, int eval_precision)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (eval_precision != FD_EVAL_FP32 && eval_precision != FD_EVAL_FP64) { set_err(ctx, "fd_set_eval_precision: unknown precision %d", eval_precision); return FD_E_INVALID; }
+    ctx->eval_precision = eval_precision;
+    return FD_OK;
 }
 
 int fd_build(fd_ctx *ctx, fd_report *report)

@@ -75,6 +75,9 @@ struct DevModel {
     // kappa * sum_j w_j |x' - c'_j|^2 that the change of length unit brings (kappa = s^2 ln s).
     float norm32[4];
     float poly32[15];
+    float pad0;
+    // what the packing code estimates about the fp32 evaluation of this model (fd_pack.h; fd_report carries them)
+    double fp32_error, cancellation, delta_min, delta_max, extent;
 };
 
 // Blob header for fd_export_model / fd_import_model.

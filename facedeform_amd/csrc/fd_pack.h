@@ -38,6 +38,36 @@ __device__ __forceinline__ double block_max(double v, double *scratch, int tid)
     return a > b ? a : b;
 }
 
+// N sums (or maxima) with ONE pair of barriers: every value goes down its wave by the same butterfly and across the four
+// waves in the same order as block_sum / block_max take it -- bit-identical to N calls of those, at a fifteenth of the
+// barriers (the packing of the one-launch builds sits on their critical path).
+template <int N, bool MAX>
+__device__ __forceinline__ void block_reduce_many(double (&v)[N], double *scratch /* 4 N */, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(v[q], off);
+            if (MAX) v[q] = o > v[q] ? o : v[q]; else v[q] += o;
+        }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) scratch[(tid >> 6) * N + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        if (MAX) {
+            const double a = scratch[q] > scratch[N + q] ? scratch[q] : scratch[N + q];
+            const double b = scratch[2 * N + q] > scratch[3 * N + q] ? scratch[2 * N + q] : scratch[3 * N + q];
+            v[q] = a > b ? a : b;
+        } else {
+            v[q] = scratch[q] + scratch[N + q] + scratch[2 * N + q] + scratch[3 * N + q];
+        }
+    }
+}
+
 // (256 threads; a kernel of its own in fd_build.hip, the last phase of the one-launch build in fd_nullspace.hip)
 __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M, int Mpad, int T, int kind, int from_w, int layers)
 {
@@ -48,7 +78,7 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
     Rec64 *rec64 = slot.rec64;
     DevModel *model = slot.model;
     __shared__ int s_bad;
-    __shared__ double s_red[4];
+    __shared__ double s_red[4 * 18];
     const int tid = threadIdx.x;
     if (tid == 0) s_bad = 0;
     __syncthreads();
@@ -60,17 +90,31 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
     //      origin), s = power of two nearest to their largest distance from x0
     double sx = 0.0, sy = 0.0, sz = 0.0;
     for (int j = tid; j < M; j += 256) { sx += centres[3 * j]; sy += centres[3 * j + 1]; sz += centres[3 * j + 2]; }
-    double cenx = block_sum(sx, s_red, tid) / M, ceny = block_sum(sy, s_red, tid) / M, cenz = block_sum(sz, s_red, tid) / M;
+    double csum[3] = {sx, sy, sz};
+    block_reduce_many<3, false>(csum, s_red, tid);
+    double cenx = csum[0] / M, ceny = csum[1] / M, cenz = csum[2] / M;
     double r2 = 0.0, r2o = 0.0;
+    // (beside the extent: the largest and the smallest |delta_i| of the control table, for the fp32 estimate below;
+    //  the smallest as a maximum of its negative)
+    const float *dl = from_w ? nullptr : slot.delta;
+    double dmax2 = 0.0, ndmin2 = -INFINITY;
     for (int j = tid; j < M; j += 256) {
         const double x = centres[3 * j], y = centres[3 * j + 1], z = centres[3 * j + 2];
         const double d = (x - cenx) * (x - cenx) + (y - ceny) * (y - ceny) + (z - cenz) * (z - cenz);
         r2 = d > r2 ? d : r2;
         const double o = x * x + y * y + z * z;
         r2o = o > r2o ? o : r2o;
+        if (dl) {
+            const double a = dl[3 * j], b = dl[3 * j + 1], c2 = dl[3 * j + 2];
+            const double dd = a * a + b * b + c2 * c2;
+            dmax2 = dd > dmax2 ? dd : dmax2;
+            ndmin2 = -dd > ndmin2 ? -dd : ndmin2;
+        }
     }
-    const double rad_c = sqrt(block_max(r2, s_red, tid));
-    const double rad_o = sqrt(block_max(r2o, s_red, tid));
+    double ext[4] = {r2, r2o, dmax2, ndmin2};
+    block_reduce_many<4, true>(ext, s_red, tid);
+    const double rad_c = sqrt(ext[0]);
+    const double rad_o = sqrt(ext[1]);
     const double cen = sqrt(cenx * cenx + ceny * ceny + cenz * cenz);
     double x0[3] = {0.0, 0.0, 0.0};
     double rad = rad_o;
@@ -89,9 +133,9 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
 
     // ---- records + moments of the weights in normalised coordinates
     bool bad = false;
-    double m[15];   // per output c: m0, m1x, m1y, m1z, m2
+    double m[18];   // per output c: m0, m1x, m1y, m1z, m2; then per output the sum of |w| as the fp32 evaluation carries it
 #pragma unroll
-    for (int q = 0; q < 15; ++q) m[q] = 0.0;
+    for (int q = 0; q < 18; ++q) m[q] = 0.0;
     for (int j = tid; j < Mpad; j += 256) {
         Rec32 r32 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         Rec64 r64 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -116,6 +160,7 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
                 m[5 * c + 2] += w[c] * cn[1];
                 m[5 * c + 3] += w[c] * cn[2];
                 m[5 * c + 4] += w[c] * cc2;
+                m[15 + c] += fabs(w[c] * w32);
             }
         }
         // multilayer model: W is layer-major (record l * Mc + c), the evaluation wants the layers of
@@ -125,8 +170,7 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
         rec32[jo] = r32;
         rec64[jo] = r64;
     }
-#pragma unroll
-    for (int q = 0; q < 15; ++q) m[q] = block_sum(m[q], s_red, tid);
+    block_reduce_many<18, false>(m, s_red, tid);
 
     // ---- affine part: W rows M..M+3 = const, x, y, z (raw coordinates)
     __shared__ double s_aff[12];
@@ -153,6 +197,27 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
         model->norm32[c] = (float)x0[c];
     }
     if (tid == 0) {
+        // ---- what the fp32 evaluation can be trusted with (fd_report.fp32_error / cancellation / delta_min).  It adds up
+        // M terms w_j phi(d_j) whose magnitudes sum to S = sum_j |w_j| max phi over the rig's extent (normalised
+        // coordinates: distances up to 2) plus the polynomial; each carries a relative 2^-24, so the displacement comes out
+        // with an ABSOLUTE error of the order of 2^-24 S whatever its own size (measured: 0.3 .. 0.4 of that; 2^-25 S is reported).  The deltas that S answers to are of size
+        // delta_max (cancellation = S / delta_max, the verdict's figure); the reference's 1e-5 is asked of every vertex
+        // against its OWN displacement, and the control table's smallest |delta| says how small those get.
+        const double phimax = kind == FD_KERNEL_THIN_PLATE ? 8.0 : (kind == FD_KERNEL_CUBIC ? 8.0 : (kind == FD_KERNEL_BIHARMONIC ? 2.0 : 1.0));
+        double S = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double *a = s_aff + 4 * c;
+            const double poly = fabs(a[0]) + (fabs(a[1]) + fabs(a[2]) + fabs(a[3])) * (rad_o > 0.0 ? rad_o : 1.0) + 4.0 * fabs(kappa * m[5 * c]);
+            const double v = m[15 + c] * phimax + poly;
+            S = v > S ? v : S;
+        }
+        const double dmax = sqrt(ext[2]), dmin = dl ? sqrt(-ext[3]) : 0.0;
+        model->fp32_error = S * 2.98023223876953125e-08;       // 2^-25 S: the kernels measure at 0.3 .. 0.4 of the worst case 2^-24 S
+        model->cancellation = dmax > 0.0 ? S / dmax : 0.0;
+        model->delta_min = dmin;
+        model->delta_max = dmax;
+        model->extent = rad_o;
         model->norm32[3] = (float)inv_s;
         int tt = 1;
         if (from_w == 1) {

@@ -54,7 +54,7 @@ const ParmDef kParms[] = {
     // -- additions
     {"kernel", P_ORD, 0, 0, "Kernel"},        // 0 = per `model` (Gaussian), 1 thin-plate, 2 biharmonic, 3 cubic
     {"smoothing", P_FLOAT, 0, 0, "Smoothing"},  // diagonal lambda for kernel != 0 and for QNN
-    {"precision", P_ORD, 0, 0, "Evaluation precision"},  // 0 fp32, 1 fp64
+    {"precision", P_ORD, 0, 0, "Evaluation precision"},  // 0 fp32 while its error estimate holds the tolerance (else fp64 for that cook), 1 fp64, 2 fp32 always
     {"device", P_INT, -1, 0, "GPU device"},
 };
 constexpr int kNumParms = (int)(sizeof(kParms) / sizeof(kParms[0]));
@@ -235,7 +235,8 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     node->e_layers = layers; node->e_maxedges = max_edges;
     const int kernel_ext = node->ord(find_parm("kernel"));
     const double smoothing = node->fval[find_parm("smoothing")][0];
-    const int precision = node->ord(find_parm("precision")) == 1 ? FD_EVAL_FP64 : FD_EVAL_FP32;
+    const int precision_parm = node->ord(find_parm("precision"));
+    const int precision = precision_parm == 1 ? FD_EVAL_FP64 : FD_EVAL_FP32;
     const int device = (int)node->fval[find_parm("device")][0];
 
     // :268-287 -- M x 6 table: rest position and fp32 delta
@@ -286,8 +287,8 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
         node->add(FDSOP_WARNING, "No blendshapes found. Ignoring morphspace deformation.");
     }
 
-    // engine (re)creation when the device or the precision parm changed
-    if (!node->engine || node->engine_precision != precision || node->engine_device != device) {
+    // engine (re)creation when the device changed (the precision is set per cook, below)
+    if (!node->engine || node->engine_device != device) {
         if (node->engine) { fd_destroy(node->engine); node->engine = nullptr; }
         fd_config cfg = node->cfg;
         cfg.struct_size = (int)sizeof(fd_config);
@@ -389,6 +390,18 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
         node->add(FDSOP_ERROR, "Can't solve the problem.");
         return node->severity;
     }
+    // The reference evaluates in fp64 inside ALGLIB (:404-439); the fp32 evaluation has an absolute error floor that the
+    // build reports (fd_report.fp32_error).  Where that floor exceeds the reference's 1e-5 of the smallest displacements of
+    // the control table, this cook is evaluated in fp64 -- unless the artist asked for fp32 outright (precision = 2).
+    int cook_precision = precision;
+    if (precision_parm == 0 && !fd_fp32_holds(&report, 1e-5)) {
+        cook_precision = FD_EVAL_FP64;
+        char t[240];
+        snprintf(t, sizeof(t), "fp32 evaluation would not hold 1e-5 of this rig's displacements (error ~%.2g, smallest delta %.2g): "
+                               "evaluating in fp64.", report.fp32_error, report.delta_min);
+        node->add(FDSOP_WARNING, t);
+    }
+    fd_set_eval_precision(ctx, cook_precision);
     // :370-373
     char info[200];
     snprintf(info, sizeof(info), "Termination type: %d, Iterations: %d", report.terminationtype, report.iterationscount);

@@ -61,7 +61,7 @@ static PRM_Name sModel[] = {PRM_Name("0", "QNN"), PRM_Name("1", "Multilayer"), P
 static PRM_Name sTerm[] = {PRM_Name("0", "Linear"), PRM_Name("1", "Constant"), PRM_Name("2", "Zero"), PRM_Name(0)};
 static PRM_Name sKernel[] = {PRM_Name("0", "Gaussian (per Model)"), PRM_Name("1", "Thin plate"),
                              PRM_Name("2", "Biharmonic"), PRM_Name("3", "Cubic"), PRM_Name(0)};
-static PRM_Name sPrecision[] = {PRM_Name("0", "fp32"), PRM_Name("1", "fp64"), PRM_Name(0)};
+static PRM_Name sPrecision[] = {PRM_Name("0", "fp32 (fp64 where fp32 cannot hold 1e-5)"), PRM_Name("1", "fp64"), PRM_Name("2", "fp32 always"), PRM_Name(0)};
 static PRM_ChoiceList sModelMenu(PRM_CHOICELIST_SINGLE, sModel), sTermMenu(PRM_CHOICELIST_SINGLE, sTerm),
     sKernelMenu(PRM_CHOICELIST_SINGLE, sKernel), sPrecisionMenu(PRM_CHOICELIST_SINGLE, sPrecision);
 static PRM_Range sRadiusRange(PRM_RANGE_RESTRICTED, 0.0, PRM_RANGE_UI, 10.0);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 7   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN (additions only) */
+#define FD_ABI_VERSION 8   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -134,7 +134,25 @@ typedef struct fd_report {
     double pivot_ratio;  /* min|pivot| / max|pivot| of the LU (cheap rcond proxy) */
     float t_assemble_ms; /* device time: prepare + kernel-matrix assembly        */
     float t_solve_ms;    /* device time: factorisation + substitution + pack     */
+    /* What the fp32 evaluation (FD_EVAL_FP32) can be trusted with for THIS model.  It adds up M terms w_j phi(d_j) whose
+     * magnitudes sum to S = sum_j |w_j| max phi over the rig's extent (+ the polynomial); each carries a relative 2^-24,
+     * so a displacement comes out with an absolute error of up to 2^-24 S whatever its own size; the kernels measure at
+     * 0.3 .. 0.4 of that and fp32_error = 2^-25 S is what is reported.  The
+     * reference (fp64 inside ALGLIB, src/SOP_FaceDeform.cpp:404-439) has no such floor.  fd_fp32_holds() turns these into
+     * the decision fdsop_cook takes; 0 in all four for imported models (no control table to measure against). */
+    double fp32_error;   /* ~ absolute error of an fp32-evaluated displacement, in position units        */
+    double cancellation; /* S / max_i |delta_i|: how much larger the summed terms are than what they add up to */
+    double delta_min;    /* smallest |delta_i| of the control table                                       */
+    double delta_max;    /* largest                                                                       */
+    double extent;       /* largest |rest_i|: the size of the positions the displacement is added to     */
 } fd_report;
+
+/* 1 when the fp32 evaluation of the reported model is expected to hold `tol` (the reference's 1e-5) of every
+ * vertex's own displacement: fp32_error <= tol * delta_min / 2 (vertices between control points move less than the
+ * least of those) + one fp32 ulp of the positions (both sides round P + d to
+ * fp32, :438, which shelters errors below that).  0: evaluate this model with FD_EVAL_FP64 (fd_set_eval_precision).
+ * Conservative where the displacement field has zeros between control points -- no estimate from M points sees those. */
+int fd_fp32_holds(const fd_report *report, double tol);
 
 /* ---- lifetime ---------------------------------------------------------------
  * fd_create replaces `alglib::rbfmodel model; alglib::rbfcreate(3, 3, model)`
@@ -148,6 +166,10 @@ int fd_abi_version(void);
 /* Launch everything on `hip_stream` (a hipStream_t) instead of the context's
  * own stream.  NULL restores the context's stream. */
 int fd_set_stream(fd_ctx *ctx, void *hip_stream);
+
+/* FD_EVAL_FP32 / FD_EVAL_FP64 for the evaluations from here on (fd_config.eval_precision is the initial value).  A built
+ * model carries the records of both: no rebuild.  fdsop_cook switches per cook on fd_fp32_holds(). */
+int fd_set_eval_precision(fd_ctx *ctx, int eval_precision);
 
 /* ---- model set-up -----------------------------------------------------------
  * fd_set_points replaces alglib::rbfsetpoints(model, xy) with the M x 6 table

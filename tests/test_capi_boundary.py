@@ -28,12 +28,12 @@ def test_header_symbols_all_exported(hip_lib):
 
 
 def test_abi_version(hip_lib):
-    assert hip_lib.fd_abi_version() == 7   # 7: fd_batch_cook_group + the solver names; 6: fd_batch_set_eval_cus; 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres; 4: fd_mesh_capture + the capture inputs of fdsop_geo; 5: fd_batch_wait_consumed
+    assert hip_lib.fd_abi_version() == 8   # 8: fd_report carries the fp32 estimate, fd_set_eval_precision, fd_fp32_holds; 7: fd_batch_cook_group + the solver names; 6: fd_batch_set_eval_cus; 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres; 4: fd_mesh_capture + the capture inputs of fdsop_geo; 5: fd_batch_wait_consumed
 
 
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.FdConfig) == 32
-    assert C.sizeof(capi.FdReport) == 32
+    assert C.sizeof(capi.FdReport) == 72 and capi.FdReport.fp32_error.offset == 32   # ABI 8: the fp32 estimate behind the ABI-7 fields
     assert capi.FdsopGeo.mesh_unchanged.offset == 20 * 8 + 4   # (the two trailing int flags of ABI 3 share a slot)
     assert capi.FdsopGeo.edge_offsets.offset == 21 * 8
     assert C.sizeof(capi.FdsopGeo) == 26 * 8   # 13 mesh/rig fields + 7 morph-space fields + the flags + 5 capture fields

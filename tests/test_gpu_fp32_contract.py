@@ -1,0 +1,107 @@
+"""GPU: the fp32 evaluation's contract is visible.
+
+The reference evaluates inside ALGLIB in fp64 (src/SOP_FaceDeform.cpp:404-439).  The fp32 kernels add up M terms whose
+magnitudes sum to S = sum_j |w_j| max phi, so a displacement carries an ABSOLUTE error of the order of 2^-24 S whatever its
+own size -- on rigs whose displacement field has small values beside large ones that exceeds the reference's 1e-5 of a
+vertex's own displacement (profiles/r02_scaled_delta_parity.txt: frame 19 scaled x8 fails 2-4x in every fp32 kernel, fp64
+holds it).  The build now reports that floor (fd_report.fp32_error / cancellation / delta_min / delta_max / extent),
+fd_fp32_holds() turns it into a decision, and fdsop_cook takes it: fp64 for that cook, with a warning, unless the artist
+set precision = 2."""
+import numpy as np
+import pytest
+
+from conftest import l2_parity, l2_parity_ulp, parity_ratio
+from facedeform_amd import capi, synth
+from facedeform_amd.sop import FaceDeformSOP
+from oracle import fd_oracle as fo
+
+pytestmark = pytest.mark.gpu
+M, N = 256, 70_000
+
+
+def _rig(frame, scale):
+    rest = synth.control_points(M, "head")
+    delta = (synth.smooth_deltas(rest, frame) * np.float32(scale)).astype(np.float32)
+    return rest, delta, (rest + delta).astype(np.float32)
+
+
+def _mesh():
+    return synth.head_mesh(100_000)[:: 100_000 // N][:N].copy()
+
+
+def _oracle_out(oracle, rest, deform, P):
+    table = oracle.control_table(rest, deform)
+    rc, tt, W, radii = oracle.build(table, fo.KERNEL_THIN_PLATE, [], fo.TERM_LINEAR)
+    assert tt == 1
+    ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
+    return ref, np.asarray(W, np.float64).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("frame,scale,holds", [(19, 8.0, False), (19, 32.0, False), (5, 100.0, True), (0, 1.0, True)])
+def test_the_report_carries_the_fp32_floor_and_the_decision(hip_lib, oracle, frame, scale, holds):
+    rest, delta, deform = _rig(frame, scale)
+    _, W = _oracle_out(oracle, rest, deform, _mesh()[:16])
+    e = capi.Engine()
+    e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR); e.set_points(rest, delta)
+    rep = e.build()
+    # S from the oracle's weights: normalised coordinates (s = 1 here: the head rig has radius ~1), thin-plate as the fp32
+    # kernel evaluates it, (ln 2 / 2) w d'^2 log2 d'^2 with d' up to 2, plus the linear term over the rig's extent
+    ext = np.linalg.norm(rest.astype(np.float64), axis=1).max()
+    S = max(np.abs(W[:M, c]).sum() * 0.5 * np.log(2.0) * 8.0 + abs(W[M, c]) + np.abs(W[M + 1:, c]).sum() * ext for c in range(3))
+    dn = np.linalg.norm(delta.astype(np.float64), axis=1)
+    assert rep.fp32_error == pytest.approx(S * 2.0 ** -25, rel=0.02)
+    assert rep.delta_max == pytest.approx(dn.max(), rel=1e-6) and rep.delta_min == pytest.approx(dn.min(), rel=1e-6)
+    assert rep.cancellation == pytest.approx(S / dn.max(), rel=0.02)
+    assert rep.extent == pytest.approx(ext, rel=1e-6)
+    assert 30.0 < rep.cancellation < 80.0                      # this rig: the terms are ~50x what they add up to
+    assert e.fp32_holds(rep, 1e-5) is holds
+    e.close()
+
+
+def test_fdsop_cook_with_defaults_holds_1e5_on_the_rig_that_fp32_cannot(hip_lib, oracle):
+    """The x8 frame-19 rig of tests/tools/scaled_delta_parity.py through fdsop_cook with the node's defaults."""
+    rest, delta, deform = _rig(19, 8.0)
+    P = _mesh()
+    ref, _ = _oracle_out(oracle, rest, deform, P)
+    sop = FaceDeformSOP()
+    sop.set("kernel", 1)
+    res = sop.cook(P, rest, deform)
+    assert not res.errors, res.messages
+    assert [w for w in res.warnings if "evaluating in fp64" in w], res.messages
+    assert l2_parity(res.P, ref, P) <= 1e-5
+    assert l2_parity_ulp(res.P, ref, P, 1e-5) <= 1.0 and parity_ratio(res.P, ref, P, 1e-5) <= 1.0
+    fp64_out = res.P.copy()
+    # precision = 2: fp32 whatever the estimate says -- no warning, and the fp32 kernel's (different) numbers
+    sop.set("precision", 2)
+    res2 = sop.cook(P, rest, deform)
+    assert not res2.errors and not [w for w in res2.warnings if "fp64" in w], res2.messages
+    assert not np.array_equal(res2.P, fp64_out)
+    assert l2_parity(res2.P, ref, P) > 1e-5                    # (what the default protects against)
+    # back to the default on a rig fp32 holds: no warning, fp32 numbers
+    sop.set("precision", 0)
+    rest5, delta5, deform5 = _rig(5, 100.0)
+    ref5, _ = _oracle_out(oracle, rest5, deform5, P)
+    res3 = sop.cook(P, rest5, deform5)
+    assert not res3.errors and not [w for w in res3.warnings if "fp64" in w], res3.messages
+    assert l2_parity_ulp(res3.P, ref5, P, 1e-5) <= 1.0
+    sop.close()
+
+
+def test_single_and_batched_builds_report_the_same_estimate(hip_lib):
+    rest, delta, _ = _rig(19, 8.0)
+    e = capi.Engine()
+    e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR); e.set_points(rest, delta)
+    rep = e.build()
+    engines = []
+    for _ in range(3):
+        b = capi.Engine(); b.set_kernel(capi.KERNEL_THIN_PLATE); b.set_term(capi.TERM_LINEAR); b.set_points(rest, delta)
+        engines.append(b)
+    batch = capi.Batch(engines)
+    batch.build_async()
+    reps = batch.build_result()
+    for r in reps:
+        assert (r.fp32_error, r.cancellation, r.delta_min, r.delta_max) == (rep.fp32_error, rep.cancellation, rep.delta_min, rep.delta_max)
+    batch.close()
+    for b in engines:
+        b.close()
+    e.close()
