@@ -20,6 +20,7 @@ KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERN
 TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
 EVAL_FP32, EVAL_FP64 = 0, 1
 SOLVER_AUTO, SOLVER_LU, SOLVER_ONE_WORKGROUP, SOLVER_REGISTER, SOLVER_CHAIN = 0, 1, 2, 3, 4
+SOLVER_LU_NOPIVOT = 5          # a value of fd_report.solver_used only
 FDSOP_OK, FDSOP_MESSAGE, FDSOP_WARNING, FDSOP_ERROR = range(4)
 
 _f32p = C.POINTER(C.c_float)
@@ -33,7 +34,7 @@ class FdConfig(C.Structure):
 
 class FdReport(C.Structure):
     _fields_ = [("terminationtype", C.c_int), ("iterationscount", C.c_int), ("n", C.c_int),
-                ("reserved", C.c_int), ("pivot_ratio", C.c_double), ("t_assemble_ms", C.c_float),
+                ("solver_used", C.c_int), ("pivot_ratio", C.c_double), ("t_assemble_ms", C.c_float),
                 ("t_solve_ms", C.c_float), ("fp32_error", C.c_double), ("cancellation", C.c_double),
                 ("delta_min", C.c_double), ("delta_max", C.c_double), ("extent", C.c_double)]
 

@@ -154,6 +154,47 @@ __global__ void k_qnn_cap(const BatchSlot *tab, int M, double z)
     if (radii[i] > cap) radii[i] = cap;
 }
 
+// The three steps above in ONE launch of one workgroup per model, up to 1024 centres: centres and radii in LDS (the separate
+// kernels walk global memory M times per thread: 37 + 22 + 5 us at M = 256, a sixth of the QNN build).  Same arithmetic.
+__global__ __launch_bounds__(1024) void k_qnn_radii_small(const BatchSlot *tab, int M, double q, double z)
+{
+    const double *centres = tab[blockIdx.z].centres;
+    double *radii = tab[blockIdx.z].radii;
+    __shared__ double s_c[3 * 1024];
+    __shared__ double s_r[1024];
+    __shared__ double s_median;
+    const int i = threadIdx.x;
+    for (int e = i; e < 3 * M; e += blockDim.x) s_c[e] = centres[e];
+    __syncthreads();
+    double r = 0.0;
+    if (i < M) {
+        const double x = s_c[3 * i], y = s_c[3 * i + 1], zz = s_c[3 * i + 2];
+        double best = INFINITY;
+        for (int j = 0; j < M; ++j) {
+            if (j == i) continue;
+            const double dx = x - s_c[3 * j], dy = y - s_c[3 * j + 1], dz = zz - s_c[3 * j + 2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            best = d2 < best ? d2 : best;
+        }
+        r = M > 1 ? q * sqrt(best) : q;
+        s_r[i] = r;
+    }
+    __syncthreads();
+    if (i < M) {
+        int rank = 0;
+        for (int j = 0; j < M; ++j) {
+            const double o = s_r[j];
+            rank += (o < r) || (o == r && j < i);
+        }
+        if (rank == M / 2) s_median = r;
+    }
+    __syncthreads();
+    if (i < M) {
+        const double cap = z * s_median;
+        radii[i] = r > cap ? cap : r;
+    }
+}
+
 // ---- assembly -----------------------------------------------------------------
 // A workgroup fills a (16 TS) x (16 TS) tile, 16 x 16 elements at a time (consecutive threads
 // walk a column: coalesced), and contributes ONE atomicMax to max|A|: with a 16 x 16 tile per
@@ -468,6 +509,103 @@ __global__ __launch_bounds__(TMAX) void k_lu_panel(const BatchSlot *tab, int lda
     }
     FD_STAMP(9)
     FD_STAMP_FLUSH
+}
+
+// ---- the same panel WITHOUT pivot search (QNN model at the SOP's defaults) ---------------------------------
+// With R_j = q * (distance to the nearest neighbour), q <= 1, every off-diagonal entry of column j of the QNN kernel block is
+// at most e^-1 of its diagonal one and the elimination keeps it so: partial pivoting never interchanges, on any rig measured
+// (profiles/r02_qnn_pivot_stats.txt) -- and then the 32 barriers, wave maxima and LDS atomics of the search buy nothing.
+// Here wave 0 factorises the 32 x 32 diagonal block in registers (row j comes from lane j by v_readlane; its lanes 32..63 --
+// rows below the block -- ride along), puts U and 1 / u_jj in LDS, and after ONE barrier every other row runs down its own
+// forward substitution.  Operation for operation the arithmetic is k_lu_panel's with the diagonal row as the pivot: the factors
+// are bit-identical to the pivoted ones whenever that kernel would not interchange.  The largest |multiplier| is recorded; above
+// kMaxMultiplier (or with a pivot at or below the threshold) the model is flagged, reports -4, and the host repeats the build
+// with k_lu_panel (fd_capi.hip: prefer_lu).  One row per thread: order <= 1024.
+constexpr double kMaxMultiplier = 4.0;
+template <int TMAX>
+__global__ __launch_bounds__(TMAX) void k_lu_panel_np(const BatchSlot *tab, int lda, int npad, int n_real, int k0, int step)
+{
+    constexpr int NB = 32;
+    double *A = tab[blockIdx.z].A;
+    int *moves = tab[blockIdx.z].moves + (size_t)step * kMovesStride;
+    DevModel *model = tab[blockIdx.z].model;
+    __shared__ __attribute__((aligned(16))) double s_U[NB][NB];
+    __shared__ double s_inv[NB];
+    __shared__ double s_mult[TMAX / 64];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrem = npad - k0;
+    const bool in = tid < nrem;
+    double a[NB];
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NB; ++c) a[c] = in ? A[(size_t)(k0 + c) * lda + k0 + tid] : 0.0;
+    const double amax = __longlong_as_double((long long)model->amax_bits);
+    const double tiny = (double)n_real * kEps * amax;
+    double mmax = 0.0;
+    if (wave == 0) {
+        double pmin = INFINITY, pmax = 0.0;
+        bool singular = false;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NB; ++j) {
+            double prow[NB];
+#pragma clang loop unroll(full)
+            for (int c = j; c < NB; ++c) prow[c] = readlane_f64(a[c], j);
+            const double piv = prow[j];
+            const double gbest = fabs(piv);
+            const bool ok = gbest > tiny;            // false for NaN as well
+            if (k0 + j < n_real) {
+                if (!ok) singular = true;
+                pmin = gbest < pmin ? gbest : pmin;
+                pmax = gbest > pmax ? gbest : pmax;
+            }
+            const double inv = ok ? fast_rcp(piv) : 0.0;
+            if (lane == j) s_inv[j] = inv;
+            if (lane > j && in) {
+                const double l = a[j] * inv;
+                a[j] = l;
+                mmax = fabs(l) > mmax ? fabs(l) : mmax;
+#pragma clang loop unroll(full)
+                for (int c = j + 1; c < NB; ++c) a[c] = fma(-l, prow[c], a[c]);
+            }
+        }
+        if (lane < NB) {
+#pragma clang loop unroll(full)
+            for (int c = 0; c < NB; ++c) s_U[lane][c] = a[c];
+        }
+        if (lane == 0) {
+            const int done = (k0 + NB < n_real ? k0 + NB : n_real);
+            model->iterations = done;
+            if (singular) model->sing_flag = 1;
+            if (pmax > 0.0 || pmin < INFINITY) {
+                atomicMin(&model->pivmin_bits, (unsigned long long)__double_as_longlong(pmin));
+                atomicMax(&model->pivmax_bits, (unsigned long long)__double_as_longlong(pmax));
+            }
+            moves[0] = 0;
+        }
+    }
+    __syncthreads();
+    if (wave != 0 && in) {
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NB; ++j) {
+            const double l = a[j] * s_inv[j];
+            a[j] = l;
+            mmax = fabs(l) > mmax ? fabs(l) : mmax;
+#pragma clang loop unroll(full)
+            for (int c = j + 1; c < NB; ++c) a[c] = fma(-l, s_U[j][c], a[c]);
+        }
+    }
+    if (in) {
+#pragma clang loop unroll(full)
+        for (int c = 0; c < NB; ++c) A[(size_t)(k0 + c) * lda + k0 + tid] = a[c];
+    }
+    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(mmax, off); mmax = o > mmax ? o : mmax; }
+    if (lane == 0) s_mult[wave] = mmax;
+    __syncthreads();
+    if (tid == 0) {
+        double m = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = s_mult[w] > m ? s_mult[w] : m;
+        if (m > kMaxMultiplier) model->sing_flag = 2;      // partial pivoting would have interchanged: the pivoted LU has to do this one
+    }
 }
 
 // Row interchanges of elimination step `step` applied to the 16 columns starting at c0 and
@@ -795,7 +933,11 @@ void lu_step(const BuildBuffers &b, int k0, int step, LuStreams &st)
     const unsigned nb = (unsigned)b.nbatch;
     int threads = round_up((nrem + R - 1) / R, 64);
     if (threads < 64) threads = 64;
-    if (threads <= 512)
+    if (b.nopivot && NB == 32 && threads <= 512)
+        hipLaunchKernelGGL((k_lu_panel_np<512>), dim3(1, 1, nb), dim3(threads), 0, st.main, b.d_slots, b.lda, b.npad, b.n, k0, step);
+    else if (b.nopivot && NB == 32)
+        hipLaunchKernelGGL((k_lu_panel_np<1024>), dim3(1, 1, nb), dim3(threads), 0, st.main, b.d_slots, b.lda, b.npad, b.n, k0, step);
+    else if (threads <= 512)
         hipLaunchKernelGGL((k_lu_panel<NB, 512>), dim3(1, 1, nb), dim3(threads), 0, st.main, b.d_slots, b.lda,
                            b.npad, b.n, k0, step);
     else
@@ -860,7 +1002,11 @@ void launch_panel(const BuildBuffers &b, int kk, int step, hipStream_t stream)
     const int nrem = b.npad - kk;
     int threads = round_up((nrem + R - 1) / R, 64);
     if (threads < 64) threads = 64;
-    if (threads <= 512)
+    if (b.nopivot && W == 32 && threads <= 512)
+        hipLaunchKernelGGL((k_lu_panel_np<512>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad, b.n, kk, step);
+    else if (b.nopivot && W == 32)
+        hipLaunchKernelGGL((k_lu_panel_np<1024>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad, b.n, kk, step);
+    else if (threads <= 512)
         hipLaunchKernelGGL((k_lu_panel<W, 512>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad, b.n, kk, step);
     else
         hipLaunchKernelGGL((k_lu_panel<W, 1024>), dim3(1, 1, nb), dim3(threads), 0, stream, b.d_slots, b.lda, b.npad, b.n, kk, step);
@@ -970,6 +1116,10 @@ hipError_t launch_prepare(const BuildBuffers &b, hipStream_t stream, const Point
 hipError_t launch_qnn_radii(const BuildBuffers &b, hipStream_t stream)
 {
     const unsigned nb = (unsigned)b.nbatch;
+    if (b.M <= 1024) {
+        hipLaunchKernelGGL(k_qnn_radii_small, dim3(1, 1, nb), dim3(round_up(b.M, 64)), 0, stream, b.d_slots, b.M, b.qnn_q, b.qnn_z);
+        return hipGetLastError();
+    }
     const int threads = 256, mb = (b.M + threads - 1) / threads;
     hipLaunchKernelGGL(k_qnn_nearest, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, b.M, b.qnn_q);
     hipLaunchKernelGGL(k_qnn_median, dim3(mb, 1, nb), dim3(threads), 0, stream, b.d_slots, b.M);

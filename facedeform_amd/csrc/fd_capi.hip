@@ -24,6 +24,7 @@ struct fd_ctx {
     unsigned long long model_gen = 0; // counts the models this context has held (every enqueued build, every import): what a
                                      // batch's packed copy of the weights is checked against before it is reused
     bool last_spd = false;           // the build in flight / last finished took the Cholesky path
+    bool last_nopivot = false;       // ... the LU without pivot search (QNN): a -4 from it is answered with the pivoted LU, like the Cholesky's
     bool last_reg = false;           // ... in its register-resident form (no factorisation is kept: fd_set_deltas builds again)
 
     // model configuration
@@ -588,6 +589,15 @@ static bool use_spd(const fd_ctx *ctx)
     return spd_applicable(ctx->kind, ctx->term, ctx_lambda(ctx), ctx->M);
 }
 
+// The QNN model's kernel block without pivot search (fd_build.hip k_lu_panel_np): one row per thread, order <= 1024; not once
+// a build of this rig has asked for the pivoted LU (prefer_lu), nor under FD_SOLVER_LU.
+static bool use_nopivot(const fd_ctx *ctx)
+{
+    static const char *env = getenv("FD_SOLVER");
+    if ((env && strcmp(env, "lu") == 0) || ctx->solver == FD_SOLVER_LU || ctx->prefer_lu) return false;
+    return ctx->kind == FD_KERNEL_GAUSSIAN_QNN && round_up(ctx->M, 32) <= 1024;
+}
+
 // The register-resident one-launch build (fd_build_reg.hip): what FD_SOLVER_AUTO takes on the definite path up to 256
 // control points; FD_SOLVER_CHAIN keeps the launch chain, FD_SOLVER_ONE_WORKGROUP the round-2 one-workgroup build
 // (FD_REG_BUILD=0 in the environment: never, for A/B measurements).
@@ -620,6 +630,7 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.spd = use_spd(ctx) ? 1 : 0;
     b.small = ctx->solver == FD_SOLVER_ONE_WORKGROUP ? 1 : 0;
     b.reg = (b.spd && use_reg(ctx)) ? 1 : 0;
+    b.nopivot = use_nopivot(ctx) ? 1 : 0;
     b.aux_stream = nullptr;
     for (hipEvent_t &e : b.aux_events) e = nullptr;
 }
@@ -692,7 +703,7 @@ int fd_build_async(fd_ctx *ctx)
         ctx->wait_event = ctx->ev1; ctx->wait_stream = st; ctx->wait_batch = nullptr;
         ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
         ctx->have_factor = true;          // (fd_set_deltas is allowed: it builds again, see above)
-        ctx->last_spd = true; ctx->last_reg = true;
+        ctx->last_spd = true; ctx->last_reg = true; ctx->last_nopivot = false;
         ctx->factor_grouped = false;
         ctx->deltas_only = false;
         ctx->build_pending = true;
@@ -718,7 +729,7 @@ int fd_build_async(fd_ctx *ctx)
         FD_HIP(ctx, hipMemsetAsync(ctx->d_A, 0, sizeof(double) * (size_t)ctx->cap_npad * cols, cur_stream(ctx)));
     }
     fd_ctx::GraphKey key{};
-    key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term | (b.spd << 9) | (b.reg << 11); key.nparams = ctx->nparams;
+    key.M = ctx->M; key.kind = ctx->kind; key.term = ctx->term | (b.spd << 9) | (b.reg << 11) | (b.nopivot << 12); key.nparams = ctx->nparams;
     memcpy(key.params, ctx->params, sizeof(key.params));
     key.A = ctx->d_A; key.rest = ctx->d_rest; key.rec32 = ctx->d_rec32;
     if (ctx->use_graph && (!ctx->build_exec || memcmp(&key, &ctx->graph_key, sizeof(key)) != 0)) {
@@ -758,6 +769,7 @@ int fd_build_async(fd_ctx *ctx)
     ctx->have_factor = b.ml_layers == 0;     // the multilayer model keeps no single factorisation to reuse
     ctx->last_spd = b.spd != 0;
     ctx->last_reg = b.spd != 0 && b.reg != 0;
+    ctx->last_nopivot = b.nopivot != 0;
     ctx->factor_grouped = false;
     ctx->deltas_only = false;
     ctx->build_pending = true;
@@ -783,6 +795,9 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
         r.terminationtype = ctx->h_model->terminationtype;
         r.iterationscount = ctx->h_model->iterations;
         r.n = order_of(ctx);
+        r.solver_used = ctx->last_reg ? FD_SOLVER_REGISTER
+                        : ctx->last_spd ? (ctx->solver == FD_SOLVER_ONE_WORKGROUP ? FD_SOLVER_ONE_WORKGROUP : FD_SOLVER_CHAIN)
+                        : ctx->last_nopivot ? FD_SOLVER_LU_NOPIVOT : FD_SOLVER_LU;
         double pmin, pmax;
         memcpy(&pmin, &ctx->h_model->pivmin_bits, 8);
         memcpy(&pmax, &ctx->h_model->pivmax_bits, 8);
@@ -800,7 +815,7 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
         // pivoting sees (1e-12 vs 2e-7 of the largest at 1e-7 apart), and a wide fixed-radius
         // Gaussian loses definiteness to rounding before the LU gives up.  Nothing that the LU
         // accepts may fail here: build again with it, and keep it for this rig.
-        if (r.terminationtype == -4 && ctx->last_spd && ctx->points_set) {
+        if (r.terminationtype == -4 && (ctx->last_spd || ctx->last_nopivot) && ctx->points_set) {
             ctx->prefer_lu = true;
             ctx->have_factor = false;
             ctx->deltas_only = false;
@@ -859,7 +874,7 @@ static int poll_status(fd_ctx *ctx)
     if (q != hipSuccess) { (void)hipGetLastError(); return FD_OK; }
     const int tt = *ctx->h_status;
     if (tt == 1 || tt == 0) return FD_OK;
-    if (tt == -4 && ctx->last_spd && ctx->points_set) {
+    if (tt == -4 && (ctx->last_spd || ctx->last_nopivot) && ctx->points_set) {
         // the Cholesky lost definiteness on this rig (header: FD_SOLVER_AUTO): the LU now, enqueued on
         // the context's stream ahead of whatever the caller is about to enqueue
         ctx->prefer_lu = true;
@@ -1525,6 +1540,8 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     for (int i = 0; i < b->n; ++i)
         if (!use_reg(b->ctxs[i])) bb.reg = 0;                                  // ... and so is the register-resident one
     if (!bb.spd) bb.reg = 0;
+    for (int i = 0; i < b->n; ++i)
+        if (!use_nopivot(b->ctxs[i])) bb.nopivot = 0;
     if (bb.reg && reg_build_init() != hipSuccess) { (void)hipGetLastError(); bb.reg = 0; }
     static const bool no_groups = getenv("FD_NO_PANEL_PAIRS") != nullptr;
     bb.group_panels = (b->n >= 4 && !no_groups && !getenv("FD_LOOKAHEAD")) ? 1 : 0;
@@ -1534,7 +1551,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     }
 
     fd_batch::Key key{};
-    key.M = c0->M; key.kind = c0->kind; key.term = c0->term | (bb.spd << 9) | (bb.small << 10) | (bb.reg << 11); key.nparams = c0->nparams;
+    key.M = c0->M; key.kind = c0->kind; key.term = c0->term | (bb.spd << 9) | (bb.small << 10) | (bb.reg << 11) | (bb.nopivot << 12); key.nparams = c0->nparams;
     memcpy(key.params, c0->params, sizeof(key.params));
     if (!bb.reg && b->use_graph && (!b->exec || memcmp(&key, &b->key, sizeof(key)) != 0)) {
         if (b->exec) { (void)hipGraphExecDestroy(b->exec); b->exec = nullptr; }
@@ -1583,6 +1600,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         c->factor_grouped = bb.group_panels != 0;
         c->last_spd = bb.spd != 0;
         c->last_reg = bb.spd != 0 && bb.reg != 0;
+        c->last_nopivot = bb.nopivot != 0;
         c->deltas_only = false;
         c->build_pending = true;
         ++c->model_gen;

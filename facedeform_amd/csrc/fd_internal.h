@@ -153,6 +153,9 @@ struct BuildBuffers {
     int small;                        // FD_SOLVER_ONE_WORKGROUP: k_build_small where it applies
     int reg;                          // the register-resident one-launch build (fd_build_reg.hip) where it applies: M <= 256 on the definite path
     int spd;
+    // QNN model, order <= 1024: the LU of its kernel block WITHOUT pivot search (fd_build.hip k_lu_panel_np); a multiplier
+    // above kMaxMultiplier or a pivot below the threshold ends the build with -4 and the host repeats it with the pivoted LU.
+    int nopivot;
     // Multilayer Gaussian model (FD_KERNEL_GAUSSIAN_ML, fd_nullspace.hip launch_build_ml): number of
     // layers, 0 for every other kind.  `kind` is then FD_KERNEL_GAUSSIAN (what the assembly evaluates).
     int ml_layers;

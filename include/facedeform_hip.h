@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 8   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds */
+#define FD_ABI_VERSION 8   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds, fd_report.reserved becomes solver_used */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -112,7 +112,12 @@ enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
  * choice for a pipeline that keeps evaluating on the other CUs while the next frames' models are solved (bench.py).
  * Same arithmetic within this choice for single and batched builds (bit-identical weights); against AUTO the
  * weights agree to rounding (1e-12 relative). */
-enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1, FD_SOLVER_ONE_WORKGROUP = 2, FD_SOLVER_REGISTER = 3, FD_SOLVER_CHAIN = 4 };
+/* QNN model (FD_KERNEL_GAUSSIAN_QNN, the SOP's default: rbfsetalgoqnn, src/SOP_FaceDeform.cpp:342-345), up to 1024 control
+ * points, under AUTO: the LU of its kernel block runs WITHOUT pivot search -- with q <= 1 partial pivoting never interchanges
+ * (profiles/r02_qnn_pivot_stats.txt) and the factors are bit-identical to the pivoted ones.  A multiplier above 4 or a pivot
+ * below the threshold ends that build with -4 and the pivoted LU repeats it, through the same path as above (q = 2 rigs).
+ * FD_SOLVER_LU_NOPIVOT is a value of fd_report.solver_used only, not a choice. */
+enum { FD_SOLVER_AUTO = 0, FD_SOLVER_LU = 1, FD_SOLVER_ONE_WORKGROUP = 2, FD_SOLVER_REGISTER = 3, FD_SOLVER_CHAIN = 4, FD_SOLVER_LU_NOPIVOT = 5 };
 
 typedef struct fd_ctx fd_ctx;
 
@@ -130,7 +135,7 @@ typedef struct fd_report {
     int terminationtype; /* 1 ok; -5 coincident centres; -4 solver failure       */
     int iterationscount; /* unknowns eliminated by the direct solver (n when done) */
     int n;               /* order of the solved system (M + term columns)        */
-    int reserved;
+    int solver_used;     /* FD_SOLVER_* the build actually ran (FD_SOLVER_LU after a fallback; FD_SOLVER_LU_NOPIVOT: QNN) */
     double pivot_ratio;  /* min|pivot| / max|pivot| of the LU (cheap rcond proxy) */
     float t_assemble_ms; /* device time: prepare + kernel-matrix assembly        */
     float t_solve_ms;    /* device time: factorisation + substitution + pack     */
