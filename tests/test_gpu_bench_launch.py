@@ -1,8 +1,9 @@
 """GPU: the benchmark's OWN launch held to the oracle.
 
 bench.py cooks C2 -- N = 1M vertices, M = 256 control points, thin-plate, linear term -- in groups: one batched build
-with the one-workgroup-per-model solver of its lanes, fd_batch_prepare_shared on the build stream, ONE
-fd_batch_deform_shared_dev per group on another stream, on a CU budget of 192, over its 64 frame phases
+with the solver of its lanes (round 2: one workgroup per model, evaluation on 192 CUs; round 3: the register-resident
+build, evaluation on 224 CUs), fd_batch_prepare_shared on the build stream, ONE
+fd_batch_deform_shared_dev per group on another stream, on that CU budget, over its 64 frame phases
 (synth.smooth_deltas(rest, f), f = 0..63, unscaled).  Round 2's tests drew f % 8 only, never ran the 32-row kernel's
 multi-round path (units from the LDS counter, the "pool" of single units after the last whole round: more groups than
 workgroups, i.e. N > 131 072 at 256 CUs) against the oracle, and never took the 192-CU grid.  Here the launch is exactly
@@ -29,7 +30,6 @@ from oracle import fd_oracle as fo
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 N, M = 1_000_000, 256
-EVAL_CUS = 192          # bench.py's CU budget for the evaluation (the rest is left to the next groups' builds)
 
 
 def _sample_indices(n, grid):
@@ -71,33 +71,35 @@ def _report(lines):
         fh.write("\n".join(lines) + "\n")
 
 
-@pytest.mark.parametrize("F", [32, 20])
-def test_the_benchmarks_own_launch_matches_the_oracle_for_all_64_phases(hip_lib, oracle, c2, F):
+# (frames per launch, the lanes' solver, the evaluation's CU budget): bench.py's default since round 3 -- the register-resident
+# build (FD_SOLVER_AUTO) beside an evaluation on 224 CUs -- at 32 frames and at the driver's 20, and round 2's pipeline
+@pytest.mark.parametrize("F,solver,cus", [(32, capi.SOLVER_AUTO, 224), (20, capi.SOLVER_AUTO, 224), (32, capi.SOLVER_ONE_WORKGROUP, 192)])
+def test_the_benchmarks_own_launch_matches_the_oracle_for_all_64_phases(hip_lib, oracle, c2, F, solver, cus):
     dev, P, rest, deltas = c2["dev"], c2["P"], c2["rest"], c2["deltas"]
     d_P, d_rest, d_deltas = c2["d_P"], c2["d_rest"], c2["d_deltas"]
     build_stream, eval_stream = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     engines = []
     for _ in range(F):
-        e = capi.Engine(solver=capi.SOLVER_ONE_WORKGROUP)          # bench.py's lane_solver
+        e = capi.Engine(solver=solver)          # bench.py's lane_solver
         e.set_stream(build_stream.cuda_stream)
         e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
         engines.append(e)
     batches = {}
     outs = [torch.empty_like(d_P) for _ in range(F)]
     falls = [torch.zeros(N, device=dev, dtype=torch.float32) for _ in range(F)]
-    idx = _sample_indices(N, EVAL_CUS)
+    idx = _sample_indices(N, cus)
     assert idx.size >= 4000
     Ps = np.ascontiguousarray(P[idx])
     built = torch.cuda.Event()
-    lines = [f"# bench.py's launch: N = {N}, M = {M}, thin-plate + linear, one-workgroup batched build, prepare_shared + "
-             f"deform_shared_dev, F = {F}, {EVAL_CUS} CUs; {idx.size} sampled vertices per frame (round seams, pool units, centres)",
+    lines = [f"# bench.py's launch: N = {N}, M = {M}, thin-plate + linear, batched build (solver {solver}: 0 = register-resident, 2 = one workgroup), "
+             f"prepare_shared + deform_shared_dev, F = {F}, {cus} CUs; {idx.size} sampled vertices per frame (round seams, pool units, centres)",
              "# phase  frames_in_launch  l2_parity_ulp  l2_parity_raw  parity_ratio"]
     worst = 0.0
     for first in range(0, 64, F):
         count = min(F, 64 - first)
         if count not in batches:
             batches[count] = capi.Batch(engines[:count])
-            batches[count].set_eval_cus(EVAL_CUS)
+            batches[count].set_eval_cus(cus)
         batch = batches[count]
         frames = list(range(first, first + count))
         with torch.cuda.stream(build_stream):
@@ -130,7 +132,7 @@ def test_the_benchmarks_own_launch_matches_the_oracle_for_all_64_phases(hip_lib,
         # every vertex of every frame was written (the NaN fill is gone), whatever unit it belonged to
         for k in range(count):
             assert not torch.isnan(outs[k]).any().item(), (first, k)
-    lines.append(f"# worst l2_parity_ulp over 64 phases at F = {F}: {worst:.3f}")
+    lines.append(f"# worst l2_parity_ulp over 64 phases at F = {F}, solver {solver}, {cus} CUs: {worst:.3f}")
     _report(lines)
     for b in batches.values():
         b.close()
