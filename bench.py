@@ -572,7 +572,9 @@ def main():
             ln["batches"][count].set_eval_cus(args.eval_cus)
         batch = ln["batches"][count]
         frames = [((first + k) * world + rank) % N_FRAMES for k in range(count)]
-        es = eval_stream if args.eval_stream == "shared" else stream
+        # (a run of ONE group -- the driver's `--steps 20` -- has nothing to overlap: its evaluation goes on the build stream,
+        #  behind the packing kernel without a cross-stream event between them)
+        es = eval_stream if (args.eval_stream == "shared" and args.steps > B) else stream
         if shared_eval and args.group_call == "c":
             # ONE foreign call per group (fd_batch_cook_group): wait_consumed, set-up, builds, packing, the evaluation.
             key = (count, frames[0])
@@ -660,8 +662,9 @@ def main():
     g_next = run_steps(args.warmup)
     if args.warmup < B * n_lanes:                      # touch every lane and capture its graph once
         g_next = run_steps(B * n_lanes, g0=g_next)
-    if args.steps % B:                                 # the ragged last group has its own batch object
-        run_steps(args.steps % B, g0=args.steps // B)
+    if args.steps % B:                                 # the ragged last group has its own batch object (primed twice: a batch
+        for _ in range(2):                             # alternates between two packed sets, each allocated on first use)
+            run_steps(args.steps % B, g0=args.steps // B)
     check_builds()
 
     c_groups = shared_eval and args.group_call == "c"

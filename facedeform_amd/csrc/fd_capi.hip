@@ -74,6 +74,7 @@ struct fd_ctx {
     // rebuilt with the LU right away, on the stream, before whatever the call enqueues; a failure
     // the LU confirms becomes a sticky error that fd_deform* returns until the next set-up call.
     int *h_status = nullptr;
+    int *d_status_alias = nullptr;      // the same word as the device sees it (looked up once: hipHostGetDevicePointer costs a runtime call per build)
     hipEvent_t status_ev = nullptr;
     hipEvent_t status_poll = nullptr;   // the event that says h_status is in: status_ev, or the one of the batch that built the model
     bool status_inflight = false;
@@ -297,8 +298,7 @@ static int sync_slot(fd_ctx *ctx)
     t.rec32 = ctx->d_rec32; t.rec64 = ctx->d_rec64; t.tiles = ctx->d_tiles; t.tiles16 = ctx->d_tiles16;
     t.model = ctx->d_model;
     t.ns = ctx->d_ns;
-    t.host_status = nullptr;
-    if (ctx->h_status && hipHostGetDevicePointer((void **)&t.host_status, ctx->h_status, 0) != hipSuccess) { (void)hipGetLastError(); t.host_status = nullptr; }
+    t.host_status = ctx->d_status_alias;
     if (ctx->alloc_gen != 0 && memcmp(&t, &ctx->h_slot, sizeof(t)) == 0) return FD_OK;
     // a buffer moved: hipFree in dev_alloc has drained the device, nothing reads the old table
     FD_HIP(ctx, hipMemcpy(ctx->d_slot, &t, sizeof(t), hipMemcpyHostToDevice));
@@ -335,8 +335,8 @@ __global__ void k_post_status_batch(const StatusTable t, int n)
 
 static int post_status(fd_ctx *ctx, hipStream_t s)
 {
-    int *dword = nullptr;
-    if (hipHostGetDevicePointer((void **)&dword, ctx->h_status, 0) != hipSuccess) { (void)hipGetLastError(); return FD_OK; }
+    int *dword = ctx->d_status_alias;
+    if (!dword) return FD_OK;
     hipLaunchKernelGGL(k_post_status, dim3(1), dim3(1), 0, s, ctx->d_model, dword);
     if (hipGetLastError() != hipSuccess || hipEventRecord(ctx->status_ev, s) != hipSuccess) { (void)hipGetLastError(); return FD_OK; }
     ctx->status_poll = ctx->status_ev;
@@ -397,6 +397,7 @@ fd_ctx *fd_create(const fd_config *cfg)
     ok = ok && hipHostMalloc((void **)&ctx->h_model, sizeof(DevModel), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_header, sizeof(ModelHeader), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&ctx->h_status, sizeof(int), hipHostMallocDefault) == hipSuccess;
+    if (ok && hipHostGetDevicePointer((void **)&ctx->d_status_alias, ctx->h_status, 0) != hipSuccess) { (void)hipGetLastError(); ctx->d_status_alias = nullptr; }
     ok = ok && hipEventCreateWithFlags(&ctx->status_ev, hipEventDisableTiming) == hipSuccess;
     if (ok) ok = hipMemset(ctx->d_model, 0, sizeof(DevModel)) == hipSuccess;
     if (!ok) {
@@ -1620,8 +1621,8 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         bool ok = true;
         for (int i = 0; i < b->n && ok; ++i) {
             st.model[i] = b->ctxs[i]->d_model;
-            int *dword = nullptr;
-            ok = hipHostGetDevicePointer((void **)&dword, b->ctxs[i]->h_status, 0) == hipSuccess;
+            int *dword = b->ctxs[i]->d_status_alias;
+            ok = dword != nullptr;
             st.host_word[i] = dword;
         }
         if (ok) {

@@ -171,9 +171,7 @@ __global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, co
         const int f = f0 + q;
         float m = 0.f;
         if (f < nF) {
-            const Rec32 *r = slots.rec32[f];
-            for (int j = l; j < Mpad; j += per) m = fmaxf(m, fmaxf(fabsf(r[j].wx), fmaxf(fabsf(r[j].wy), fabsf(r[j].wz))));
-            if (l < 15) m = fmaxf(m, fabsf(slots.model[f]->poly32[l]));
+            m = slots.model[f]->wmax32;          // (left there by the packing code of the build: fd_pack.h)
         }
         for (int off = per / 2; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));      // per is 16 or 64: inside a wave
         const bool same_rig = (kb == 0 && (!dense || T % 3 == 0)) ? rig_matches(slots, f, nF, l, per) : true;
@@ -828,19 +826,9 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
         const int f = threadIdx.x >> 3, l = threadIdx.x & 7;
         float m = 0.f;
         if (f < nslot) {
-            // eight weight triples in flight per lane (one 16-byte load each; one at a time this scan was most of the
-            // kernel's 12 us, and the kernel sits on the build stream between a group's solve and the next one's)
-            const f32x4 *w = reinterpret_cast<const f32x4 *>(slots.rec32[f]) + 1;       // {wx, wy, wz, pad} of record 0; stride 2
-            int q = l;
-            for (; q + 56 < Mpad; q += 64) {
-                f32x4 v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = w[2 * (q + 8 * e)];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(fabsf(v[e][0]), fmaxf(fabsf(v[e][1]), fabsf(v[e][2]))));
-            }
-            for (; q < Mpad; q += 8) { const f32x4 v = w[2 * q]; m = fmaxf(m, fmaxf(fabsf(v[0]), fmaxf(fabsf(v[1]), fabsf(v[2])))); }
-            for (int e = l; e < 15; e += 8) m = fmaxf(m, fabsf(slots.model[f]->poly32[e]));
+            // (the packing code of every build leaves the largest |weight| / |coefficient| of the fp32 records in the model:
+            // scanning the records here -- every workgroup all frames -- was most of this kernel's 30 us)
+            m = slots.model[f]->wmax32;
         }
         for (int off = 4; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         const bool same_rig = (kb == 0 && T == 0) ? rig_matches(slots, f, nslot, l, 8) : true;

@@ -75,7 +75,7 @@ struct DevModel {
     // kappa * sum_j w_j |x' - c'_j|^2 that the change of length unit brings (kappa = s^2 ln s).
     float norm32[4];
     float poly32[15];
-    float pad0;
+    float wmax32;          // largest |weight| or |polynomial coefficient| as the fp32 records carry them: the shared-rig launch scales by it
     // what the packing code estimates about the fp32 evaluation of this model (fd_pack.h; fd_report carries them)
     double fp32_error, cancellation, delta_min, delta_max, extent;
 };

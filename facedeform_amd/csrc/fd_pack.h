@@ -133,6 +133,7 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
 
     // ---- records + moments of the weights in normalised coordinates
     bool bad = false;
+    float wmax = 0.f;      // largest |weight| of the fp32 records (k_pack_shared* scale a frame's rows by it)
     double m[18];   // per output c: m0, m1x, m1y, m1z, m2; then per output the sum of |w| as the fp32 evaluation carries it
 #pragma unroll
     for (int q = 0; q < 18; ++q) m[q] = 0.0;
@@ -152,6 +153,7 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
             r32.cx = (float)cn[0]; r32.cy = (float)cn[1]; r32.cz = (float)cn[2];
             r32.s = gauss ? (float)(-kLog2e * sc * sc / (R * R)) : 0.f;
             r32.wx = (float)(w[0] * w32); r32.wy = (float)(w[1] * w32); r32.wz = (float)(w[2] * w32);
+            wmax = fmaxf(wmax, fmaxf(fabsf(r32.wx), fmaxf(fabsf(r32.wy), fabsf(r32.wz))));
             const double cc2 = cn[0] * cn[0] + cn[1] * cn[1] + cn[2] * cn[2];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -171,6 +173,8 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
         rec64[jo] = r64;
     }
     block_reduce_many<18, false>(m, s_red, tid);
+    double wm[1] = {(double)wmax};
+    block_reduce_many<1, true>(wm, s_red, tid);
 
     // ---- affine part: W rows M..M+3 = const, x, y, z (raw coordinates)
     __shared__ double s_aff[12];
@@ -196,7 +200,15 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
         model->poly32[5 * c + 4] = (float)(kappa * m[5 * c]);
         model->norm32[c] = (float)x0[c];
     }
+    // (threads 0..2 sit in one wave: the largest polynomial coefficient joins the largest weight without a barrier)
+    float pmax = 0.f;
+    if (tid < 3) {
+#pragma unroll
+        for (int e = 0; e < 5; ++e) pmax = fmaxf(pmax, fabsf(model->poly32[5 * tid + e]));
+    }
+    pmax = fmaxf(pmax, fmaxf(__shfl(pmax, 1), __shfl(pmax, 2)));
     if (tid == 0) {
+        model->wmax32 = fmaxf((float)wm[0], pmax);
         // ---- what the fp32 evaluation can be trusted with (fd_report.fp32_error / cancellation / delta_min).  It adds up
         // M terms w_j phi(d_j) whose magnitudes sum to S = sum_j |w_j| max phi over the rig's extent (normalised
         // coordinates: distances up to 2) plus the polynomial; each carries a relative 2^-24, so the displacement comes out
