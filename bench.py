@@ -92,11 +92,15 @@ def parse_args():
                          "it selects makes up for the staging)")
     ap.add_argument("--c5-solve", choices=["broadcast", "redundant"], default="broadcast",
                     help="config c5: rank 0 solves and broadcasts the models (default), or every rank solves them itself")
-    ap.add_argument("--eval-stream", choices=["shared", "lane"], default="shared",
-                    help="evaluations on one stream for all lanes (default) or on each lane's build stream")
+    ap.add_argument("--eval-stream", choices=["shared", "lane", "per-lane"], default="shared",
+                    help="evaluations on one stream for all lanes (default), on each lane's build stream (the same: 158 k), or on an "
+                         "evaluation stream per lane (worse, 147 k: two persistent launches then share the CUs and each takes twice as long)")
     ap.add_argument("--group-call", choices=["c", "python"], default="c",
                     help="shared evaluation: a group is enqueued by ONE foreign call (fd_batch_cook_group, default) or by the five "
                          "fd_batch_* calls with their pointer tables from Python; the line reports the host time per group")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="shared evaluation, one call per group: every n-th group carries the four HIP events that time its build and "
+                         "its evaluation launch (runs of fewer than 16 groups time every group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=float, default=3.0e8,
                     help="bound on (vertex, centre) pairs in the CPU baseline sample")
@@ -520,6 +524,7 @@ def main():
     B = max(1, min(args.inflight, capi.MAX_BATCH))
     n_lanes = max(1, args.lanes)
     eval_stream = torch.cuda.Stream(device=dev)
+    lane_eval_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
     build_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
     cu_split = "none"
     if args.cu_split == "mask" and args.eval_launch == "shared" and B > 1 and 0 < args.eval_cus < 256 and not rehearse:
@@ -527,6 +532,8 @@ def main():
         if ms is not None:
             eval_stream, build_streams = ms
             cu_split = "mask"
+            if args.eval_stream == "per-lane":
+                args.eval_stream = "shared"            # (one masked evaluation stream)
     # the pipeline's models: one workgroup per model where that applies (M <= 512; config c3 takes the chain either way)
     lane_solver = (capi.SOLVER_ONE_WORKGROUP if (args.build == "one-workgroup" and B > 1) else
                    capi.SOLVER_CHAIN if args.build == "chain" else capi.SOLVER_AUTO)      # AUTO: the register-resident one-launch build up to 256 control points
@@ -574,7 +581,7 @@ def main():
         frames = [((first + k) * world + rank) % N_FRAMES for k in range(count)]
         # (a run of ONE group -- the driver's `--steps 20` -- has nothing to overlap: its evaluation goes on the build stream,
         #  behind the packing kernel without a cross-stream event between them)
-        es = eval_stream if (args.eval_stream == "shared" and args.steps > B) else stream
+        es = stream if (args.eval_stream == "lane" or args.steps <= B) else (eval_stream if args.eval_stream == "shared" else lane_eval_streams[g % n_lanes])
         if shared_eval and args.group_call == "c":
             # ONE foreign call per group (fd_batch_cook_group): wait_consumed, set-up, builds, packing, the evaluation.
             key = (count, frames[0])
@@ -584,9 +591,11 @@ def main():
                                                [o.data_ptr() for o in ln["out"][:count]], [f.data_ptr() for f in ln["fall"][:count]])
             # timed groups: four raw HIP events recorded INSIDE the call, around the builds and around the evaluation launch
             batch.cook_group(stream.cuda_stream, es.cuda_stream, d_rest.data_ptr(), n_ctrl, n_verts, d_P.data_ptr(), tabs[key],
-                             events=ev[first].struct if ev else None)
+                             events=ev[first].struct if (ev and first in ev) else None)
             ln["last_shared"] = batch
-            ln["evals_done"].record(es)
+            # (no event of ours behind the evaluation: the lane's next build is ordered by fd_batch_wait_consumed inside the call,
+            #  its next evaluation by the evaluation stream itself -- every event record or wait is a barrier packet on that stream,
+            #  and four of them per group kept it idle for 40 us between two 171 us launches)
             return
         # The lane's previous group must be done with its models before they are overwritten.  The shared-rig
         # launch copies what it reads of them in its first small kernel (fd_batch_wait_consumed): the next group's
@@ -669,7 +678,11 @@ def main():
 
     c_groups = shared_eval and args.group_call == "c"
     if c_groups:
-        events = {i: RawEvents(capi) for i in range(0, args.steps, B)}          # one set per group, recorded inside the C call
+        # one set of four events per TIMED group, recorded inside the C call; every `--time-every`-th group is timed (all of them
+        # when there are few): the event packets are not free on the evaluation stream (see _group)
+        n_groups = (args.steps + B - 1) // B
+        stride = 1 if n_groups < 16 else max(1, args.time_every)
+        events = {i: RawEvents(capi) for i in range(0, args.steps, B * stride)}
     else:
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     # One HIP event pair per run of `event_every` consecutive evaluations of a group (the pair's
@@ -731,7 +744,7 @@ def main():
     elapsed = float(t.item())
 
     # a batched build is timed once per group (events on the group's first step)
-    group_firsts = list(range(0, args.steps, B))
+    group_firsts = sorted(events) if c_groups else list(range(0, args.steps, B))
     def ev_ms(i, a, b):
         return events[i].ms(a, b) if c_groups else events[i][a].elapsed_time(events[i][b])
     build_group_ms = float(np.mean([ev_ms(i, 0, 1) for i in group_firsts]))

@@ -112,8 +112,21 @@ __device__ __forceinline__ bool rig_matches(const SharedSlots &slots, int f, int
 {
     bool same = true;
     if (f > 0 && f < nF && slots.centres[f] != slots.centres[0]) {
+        // (eight pairs in flight per lane and no short circuit: one pair at a time behind `same &&` this comparison was
+        //  the packing kernel's 30 us -- 96 dependent round trips per lane at 8 lanes per frame)
         const double *a = slots.centres[f], *b0 = slots.centres[0];
-        for (int e = l; e < 3 * slots.M; e += per) same = same && a[e] == b0[e];
+        const int n = 3 * slots.M;
+        bool diff = false;
+        int e = l;
+        for (; e + 7 * per < n; e += 8 * per) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { va[u] = a[e + u * per]; vb[u] = b0[e + u * per]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) diff |= !(va[u] == vb[u]);
+        }
+        for (; e < n; e += per) diff |= !(a[e] == b0[e]);
+        same = !diff;
     }
     for (int off = per / 2; off >= 1; off >>= 1) same = (__shfl_xor((int)same, off) != 0) && same;
     if (!same && l == 0 && slots.mismatch) *slots.mismatch = (f < slots.nreal ? f : slots.nreal - 1) + 1;
