@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     DevModel FD_GLOBAL *model = as_global(slot.model);
     unsigned long long st_prev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     int st_k = 0;
-#define FD_RSTAMP() if (stamps && blockIdx.z == 0 && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps[st_k++] = t_ - st_prev; st_prev = t_; }
+#define FD_RSTAMP() if (stamps && blockIdx.z == 0 && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamps[st_k] = t_ - st_prev; atomicAdd(&stamps[84 + st_k], t_ - st_prev); if (st_k == 0) atomicAdd(&stamps[83], 1ull); ++st_k; st_prev = t_; }
     __builtin_amdgcn_s_setprio(3);
 
     // ---- control table (reference :268-287, widened to fp64), status reset, tile table
@@ -1069,11 +1069,27 @@ hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const Poi
     static unsigned long long *d_stamps = nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     static const bool stamps_env = getenv("FD_REG_STAMPS") != nullptr;
+    static const bool stamps_late = stamps_env && atoi(getenv("FD_REG_STAMPS")) == 2;      // 2: no read-back per launch (the pipeline stays a pipeline); the last launch's stamps at exit
     const bool want_stamps = stamps_env && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-    if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 80 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 80 * sizeof(unsigned long long)); }
+    if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 96 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 96 * sizeof(unsigned long long)); }
     hipLaunchKernelGGL(k_build_reg, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,
                        b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, want_stamps ? d_stamps : nullptr);
-    if (want_stamps && d_stamps) {
+    if (want_stamps && d_stamps && stamps_late) {
+        static bool registered = false;
+        static unsigned long long *d_keep = nullptr;
+        d_keep = d_stamps;
+        if (!registered) {
+            registered = true;
+            atexit([] {
+                unsigned long long h[96];
+                if (d_keep && hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, d_keep, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[83]) {
+                    fprintf(stderr, "[k_build_reg stamps, MEAN over %llu launches (no read-back per launch): table | assembly | tile loads | reflectors | KV | W + rotation | Cholesky | back substitution | recovery | pack]\n  ", h[83]);
+                    for (int q = 0; q < 10; ++q) fprintf(stderr, " %llu", h[84 + q] / h[83]);
+                    fprintf(stderr, "\n");
+                }
+            });
+        }
+    } else if (want_stamps && d_stamps) {
         unsigned long long h[80];
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[k_build_reg stamps, shader cycles: table | assembly | tile loads | reflectors + Q^T f | Y = K V | W + rotation + B21 | Cholesky | back substitution | recovery | pack]\n  ");

@@ -1677,7 +1677,9 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     // One persistent workgroup per CU (150 KiB of LDS, two 240-register waves per SIMD: nothing else fits beside it).
     // a.max_wgs < 256 (fd_batch_set_eval_cus) leaves the other CUs to whatever runs on other streams -- the builds of the
     // next frames in a pipeline (bench.py).
-    const int64_t max_wgs = (a.max_wgs > 0 && a.max_wgs < kNumCU) ? a.max_wgs : kNumCU;
+    // More than 256: the workgroups beyond the resident ones go out as CUs come free -- shorter shares, so a workgroup that had to
+    // wait for a CU a build holds delays the launch by less.
+    const int64_t max_wgs = a.max_wgs > 0 ? (a.max_wgs < 4096 ? a.max_wgs : 4096) : kNumCU;
     const unsigned grid = (unsigned)(ngroups < max_wgs ? ngroups : max_wgs);
 #define FD_SHARED_CASE(NTV, DNS, GSS)                                                                                \
     {                                                                                                                \

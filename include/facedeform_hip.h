@@ -382,7 +382,9 @@ int fd_batch_wait_consumed(fd_batch *batch, void *hip_stream);
 int fd_batch_prepare_shared(fd_batch *batch, void *hip_stream, float *const *d_P_out, float *const *d_falloff_out);
 /* CU budget of this batch's shared-rig evaluation launches: fd_batch_deform_shared_dev runs one persistent workgroup per
  * CU (it needs a CU's whole LDS), and a pipeline that builds the next group's models beside the evaluation may want to
- * leave some CUs to those builds.  n_cus <= 0 or >= the device's CU count: all of them (the default).  Per batch, not
+ * leave some CUs to those builds.  n_cus <= 0: one workgroup per CU (the default).  More than the device's CU count
+ * oversubscribes: shares get shorter and the workgroups beyond the resident ones start as CUs come free (measured: no gain over
+ * 224 of 256 beside three batches of builds).  Per batch, not
  * per process: two nodes cooking side by side choose independently (round 2 read an environment variable once). */
 int fd_batch_set_eval_cus(fd_batch *batch, int n_cus);
 /* One GROUP of frames of a shot in one call -- what a frame pipeline enqueues per group, in the order it must be enqueued:
