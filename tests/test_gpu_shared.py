@@ -496,3 +496,27 @@ def test_fall_off_arrays_that_are_not_16_byte_aligned_take_the_general_epilogue(
         assert np.allclose(falls[f].cpu().numpy(), ref_fall, rtol=2e-6, atol=1e-7)
         assert float(big[f, 0]) == 7.0 and float(big[f, N + 1]) == 7.0      # nothing written outside the view
     _close(engines, batch)
+
+
+@pytest.mark.parametrize("F,kind,params", [(20, capi.KERNEL_THIN_PLATE, ()), (32, capi.KERNEL_THIN_PLATE, ()), (12, capi.KERNEL_THIN_PLATE, ()),
+                                          (24, capi.KERNEL_GAUSSIAN_QNN, (1.0, 5.0, 0.0))])
+def test_the_workgroup_budget_changes_the_schedule_not_the_bits(hip_lib, F, kind, params):
+    """fd_batch_set_eval_cus: fewer workgroups than CUs (CUs left to builds), one per CU, and more than CUs (oversubscribed:
+    shorter shares, later workgroups start as CUs come free) walk the vertex groups in different orders and shares -- every
+    vertex's arithmetic is the same, so the outputs are bit-identical."""
+    N = 300_037
+    dev, P, rest, deltas, d_P, keep, engines, batch = _setup(256, N, F, kind, params)
+    ref = None
+    for cus in (0, 97, 224, 448, 1500):
+        batch.set_eval_cus(cus)
+        outs = [torch.full_like(d_P, float("nan")) for _ in range(F)]
+        falls = [torch.zeros(N, device=dev) for _ in range(F)]
+        batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs], d_falloff=[f.data_ptr() for f in falls])
+        torch.cuda.synchronize()
+        got = torch.stack(outs)
+        assert not torch.isnan(got).any().item(), cus
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got, ref), cus
+    _close(engines, batch)
