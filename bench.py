@@ -677,6 +677,7 @@ def main():
     check_builds()
 
     c_groups = shared_eval and args.group_call == "c"
+    stride = 1
     if c_groups:
         # one set of four events per TIMED group, recorded inside the C call; every `--time-every`-th group is timed (all of them
         # when there are few): the event packets are not free on the evaluation stream (see _group)
@@ -895,6 +896,8 @@ def main():
                 "frames_per_batched_build": B, "frames_per_evaluation_launch": frames_per_launch,
                 "evaluation": args.eval_launch if B > 1 else "single",
                 "evaluation_cus": args.eval_cus or 256,
+                "evaluation_stream": "the group's build stream (a single group: nothing to overlap)" if args.steps <= B else args.eval_stream,
+                "timed_groups": f"HIP event pairs around the build and the evaluation launch of every {stride}-th group" if c_groups else "every group",
                 "cu_split": cu_split,
                 "pipeline_build": ("one workgroup per model, matrix in L2 (FD_SOLVER_ONE_WORKGROUP)" if lane_solver == capi.SOLVER_ONE_WORKGROUP
                                    else "launch chain (FD_SOLVER_CHAIN)" if lane_solver == capi.SOLVER_CHAIN
