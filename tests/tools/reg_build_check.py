@@ -1,7 +1,7 @@
 """Register-resident build (fd_build_reg.hip) against the oracle and the launch chain: weights, timing.
-   python tools/reg_build_check.py            (FD_REG_STAMPS=1 for the phase cycles of the kernel)"""
+   python tests/tools/reg_build_check.py            (FD_REG_STAMPS=1 for the phase cycles of the kernel)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from facedeform_amd import capi, synth
 from oracle import fd_oracle as fo

@@ -30,7 +30,7 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_reg_fetch -o fetch -- python3 tools/build_profile.py 256 cholesky 40 > $OUT/pmc_reg_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_reg_write -o write -- python3 tools/build_profile.py 256 cholesky 40 > $OUT/pmc_reg_write.log 2>&1
 echo "register build passes done"
-FD_REG_STAMPS=1 python3 tools/reg_build_check.py > $OUT/reg_build_check.txt 2>&1
+FD_REG_STAMPS=1 python3 tests/tools/reg_build_check.py > $OUT/reg_build_check.txt 2>&1
 python3 tests/tools/shared_eval_timing.py c2 8,16,20,24,32 > $OUT/shared_timing_c2.txt 2>&1
 python3 tests/tools/shared_eval_timing.py c2 8,32 qnn >> $OUT/shared_timing_c2.txt 2>&1
 python3 tools/build_latency.py 256,512,2048 11 > $OUT/solver_latency.txt 2>&1
