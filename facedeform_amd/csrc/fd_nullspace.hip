@@ -1519,7 +1519,9 @@ void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, i
             // bulk steps update everything beyond the next panel, the others one column pair
             // deferring the bulk pays where the trailing matrix is large; a small system updates
             // everything every step and keeps its LDS footprint at the panel work's
-            const int bulk_every = npc > 512 ? kBulk : 1;
+            // (a batch defers twice as long: its updates are bound by the traffic of 32 trailing matrices, a lone system by the chain
+            //  of launches -- C3: batched +4 % at 8, single build 4 % slower)
+            const int bulk_every = npc > 512 ? (nb >= 4 ? 2 * kBulk : kBulk) : 1;
             const bool bulk = ((k0 >> 5) % bulk_every) == bulk_every - 1;
             const int nreg = ncb > 2 ? (bulk ? (ncb / 2 - 1) * nchunk : nchunk) : 0;
             const size_t lds = (size_t)bulk_every * 8192 > kStepPanelLds ? (size_t)bulk_every * 8192 : kStepPanelLds;
