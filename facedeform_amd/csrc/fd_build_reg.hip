@@ -9,31 +9,37 @@
 //     [ P^T 0 ] [ a ] = [ 0 ]     n1 = M - T),    R a = (Q^T f)_2 - B21 y,           w = Q [y; 0]
 //
 // Why another kernel.  Round 2's one-launch build (k_build_small) kept the matrix in L2: every phase was a handful of
-// dependent ~1 us round trips that four waves could not overlap -- 0.37 ms at M = 256 against 0.25 ms for the launch chain,
-// whose nine step launches cost ~4 us of launch floor each.  Here the lower triangle lives in the accumulator registers of
-// eight waves and never leaves the CU:
+// dependent ~1 us round trips that four waves could not overlap -- 0.37 ms at M = 256 against 0.25 ms for the launch chain.
+// Here the lower triangle lives in the accumulator registers of a workgroup's waves and never leaves the CU:
 //
-//   * 16 x 16 tiles in the v_mfma_f64_16x16x4_f64 C/D layout (lane (c, g) = (lane & 15, lane >> 4) holds rows g, g + 4, g + 8,
-//     g + 12 of column c: 4 doubles); order 256 = 136 lower tiles + 16 tiles that carry the three right-hand sides as extra
-//     ROWS (so the forward substitution rides along) = 152 tiles = 19 per wave, dealt out round robin down the columns so that
-//     every suffix of columns -- what is left at step K -- is spread evenly;
-//   * the kernel matrix is ASSEMBLED into those registers (fp64 phi of the centre distances, 34 per lane): no assembly launch,
-//     no matrix in memory at all;
-//   * per 16 columns: the wave that owns the diagonal tile factorises it and inverts the factor IN ITS REGISTERS, four
-//     columns at a time -- the 4 x 4 pivot block goes to every lane by v_readlane and is factorised and inverted redundantly
-//     (no cross-lane traffic inside it), then [T | I] <- row operations as matrix instructions: rows_b <- inv(L_bb) rows_b and
-//     the rows below -= L_rb rows_b, whose multipliers ARE the transposed result of the first (the Schur complement is
-//     symmetric), in exactly the operand layout: no LDS round trip per column (a first version with one took 640 cycles
-//     per column, 10 k per block); the tiles below become L_IK = C_IK inv(L_KK)^T as four matrix instructions each, go
-//     through LDS once as the operands of the trailing update, and C_IJ -= L_IK L_JK^T is four more per tile;
-//   * back substitution in row form (y^T L = z^T), right-looking: a tile is its own B operand; the wave that owns tile
+//   * 512 threads = 8 waves, two per SIMD, 256 registers each.  Waves 0..6 (the WORKERS) hold the 16 x 16 tiles of the lower
+//     triangle in the v_mfma_f64_16x16x4_f64 C/D layout (lane (c, g) = (lane & 15, lane >> 4) holds rows g, g + 4, g + 8, g + 12
+//     of column c: 4 doubles = 8 registers per tile), up to 20 tiles = 160 registers per wave; order 256 = 136 tiles.  Wave 7
+//     holds none: it runs what is sequential BESIDE the workers -- the reflectors of P with Q^T f folded in, the small 4 x 4
+//     algebra of W, the factorisation of every diagonal block, the forward-substituted right-hand sides, the recovery of a
+//     and w = Q [y; 0] -- with DPP reductions and no workgroup barrier of its own;
+//   * tile (I, J) -> worker by tile_owner(): column J dealt round robin from a per-column offset, the diagonal tile with the
+//     tile left of it (the look-ahead below needs them on one wave); slots in column-major order;
+//   * the kernel matrix is assembled tile by tile in a ROLLED loop (one copy of the fp64 logarithm) and staged through the
+//     context's otherwise unused matrix buffer -- 272 KB that come back from L2 by unconditional loads: with the resident tiles'
+//     registers carried through that loop the compiler spilled them around every iteration;
+//   * per 16 columns, with LOOK-AHEAD: wave 7 factorises diagonal block K and inverts the factor IN ITS REGISTERS, four columns
+//     at a time -- the 4 x 4 pivot block goes to every lane by v_readlane and is factorised and inverted redundantly (no
+//     cross-lane traffic inside it), then [T | I] <- row operations as matrix instructions: rows_b <- inv(L_bb) rows_b and the
+//     rows below -= L_rb rows_b, whose multipliers ARE the transposed result of the first (the Schur complement is symmetric),
+//     in exactly the operand layout; the workers turn the tiles below into L_IK = C_IK inv(L_KK)^T (four matrix instructions
+//     each, through the tile's own slot of the LDS panel buffer), the owner of (K + 1, K) applies it to diagonal tile K + 1 at
+//     once and hands that to wave 7, which factorises block K + 1 while the workers apply panel K to the rest
+//     (C_IJ -= L_IK L_JK^T, four instructions per tile);
+//   * the three right-hand sides live in LDS and ride along (z_K by wave 7, f_I -= z_K L_IK^T by the owners of the panel tiles);
+//     back substitution in row form (y^T L = z^T), right-looking: a tile is its own B operand; the wave that owns tile
 //     (I, I - 1) also solves block I - 1, so a step costs ONE barrier;
-//   * the O(M) pieces -- reflectors of P with Q^T f folded in, V^T Y, the recovery of a and w = Q [y; 0] -- run on ONE wave
-//     with DPP reductions (no barriers; with 512 threads and a barrier pair per sum they were a third of the kernel), while
-//     Y = K V, the rotation and B21 work on the tiles in place.
+//   * Y = K V, the rotation to B = K - V W^T - W V^T and B21 work on the tiles in place; packing (fd_pack.h) is the last phase
+//     and posts the status word itself.
 //
 // Roof: the fp64 matrix pipe (78.6 TFLOP/s); algorithmic work (1/3) n1^3 = 5.3 MFLOP at M = 256.  What bounds it is the
-// factorisation's critical path -- 256 dependent pivots -- not flops: see DESIGN.md 4.2d.
+// factorisation's critical path -- 256 dependent pivots -- and the register budget (160 of a wave's 256 registers are tiles),
+// not flops: DESIGN.md 4.2d has the phase stamps, the counters and what was tried.
 // fd_set_deltas on a context built this way simply builds again (no factor is kept; the build is faster than the stored-
 // factor path was), bit-identical by construction.
 #include <cstdio>
