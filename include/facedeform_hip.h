@@ -91,8 +91,11 @@ enum { FD_EVAL_FP32 = 0, FD_EVAL_FP64 = 1 };
  * of the order its polynomial term covers (thin-plate and cubic with the linear term, biharmonic
  * with a constant or linear term, the fixed-radius Gaussian with any term; lambda >= 0, M >= 16)
  * the polynomial constraints are eliminated with Householder reflectors and the projected kernel
- * block is Cholesky-factorised -- no pivot search; everything else (QNN radii make Phi
- * non-symmetric) goes through LU with partial pivoting.  LU forces the latter everywhere.  A
+ * block is Cholesky-factorised -- no pivot search; up to 256 control points that whole build is ONE
+ * launch of one workgroup per model with the matrix in registers (FD_SOLVER_REGISTER names it; FD_SOLVER_CHAIN
+ * keeps the launch chain at any size: same mathematics, weights equal to rounding, 1e-12);
+ * everything else (QNN radii make Phi non-symmetric) goes through LU (the QNN model without the pivot
+ * search where that is exact, see below).  LU forces the partially pivoted LU everywhere.  A
  * system on which the Cholesky loses definiteness to rounding (centres one fp32 step apart, a
  * fixed-radius Gaussian wider than the rig) is rebuilt with the LU before anything is reported,
  * and the context keeps the LU until its kernel, term or M change: nothing the LU accepts fails.
