@@ -45,6 +45,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSharedThreads = 512;
+// waves per workgroup of the 32-row kernel: 8 (two per SIMD, up to 256 registers each) or 12 (three per SIMD, 168 registers:
+// 87 spilled, none inside the K loop -- measured r3: the 32-frame launch alone 189 -> 206 us, bench.py 155-161 k -> 142 k Mverts/s)
+constexpr int kWideWaves = 8;
 constexpr size_t kSharedLdsBudget = 158 * 1024;   // of 160 KiB (one workgroup per CU)
 
 // Two row layouts of the output tiles (16 rows x 16 vertices each):
@@ -915,10 +918,12 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 //   bit 5  the positions read with the non-temporal hint
 // Instantiated: 49 only (r2 kept eight for A/B runs; the others lost and are gone from the library).
 // NT row tiles of 32 (2 or 3), NSLOT frame slots (20: NT = 2; 24, 28, 32: NT = 3) -- see wide_slots / wide_tiles.
-template <int VAR, bool GAUSS, int NT, int NSLOT>
-__global__ __launch_bounds__(kSharedThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int VAR, bool GAUSS, int NT, int NSLOT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4)))
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 {
+    // WAVES per workgroup (8 or 12: two or three per SIMD), 64 vertices each per group
+    constexpr int THREADS = 64 * WAVES;
     static_assert(NSLOT % 4 == 0 && NSLOT <= kWideSlots && 3 * NSLOT <= 32 * NT, "frame slots in fours, three rows each");
     constexpr int kWideW16 = wide_w16(NT);
     constexpr bool SKEWED = (VAR & 1) != 0;
@@ -954,7 +959,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(p.ctiles) + (size_t)kb0 * 64;
             uint4 *dst = reinterpret_cast<uint4 *>(s_ct);
-            for (int q = tid; q < nk * 64; q += kSharedThreads) dst[q] = src[q];
+            for (int q = tid; q < nk * 64; q += THREADS) dst[q] = src[q];
         }
         {
             // eight loads in flight per thread (one at a time the copy of a resident model took 14 round trips to L2,
@@ -964,13 +969,13 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             u32x4 *dst = reinterpret_cast<u32x4 *>(s_w);
             const int n16 = nk * kWideW16;
             int q = tid;
-            for (; q + 7 * kSharedThreads < n16; q += 8 * kSharedThreads) {
-                const u32x4 v0 = src[q], v1 = src[q + kSharedThreads], v2 = src[q + 2 * kSharedThreads], v3 = src[q + 3 * kSharedThreads];
-                const u32x4 v4 = src[q + 4 * kSharedThreads], v5 = src[q + 5 * kSharedThreads], v6 = src[q + 6 * kSharedThreads], v7 = src[q + 7 * kSharedThreads];
-                dst[q] = v0; dst[q + kSharedThreads] = v1; dst[q + 2 * kSharedThreads] = v2; dst[q + 3 * kSharedThreads] = v3;
-                dst[q + 4 * kSharedThreads] = v4; dst[q + 5 * kSharedThreads] = v5; dst[q + 6 * kSharedThreads] = v6; dst[q + 7 * kSharedThreads] = v7;
+            for (; q + 7 * THREADS < n16; q += 8 * THREADS) {
+                const u32x4 v0 = src[q], v1 = src[q + THREADS], v2 = src[q + 2 * THREADS], v3 = src[q + 3 * THREADS];
+                const u32x4 v4 = src[q + 4 * THREADS], v5 = src[q + 5 * THREADS], v6 = src[q + 6 * THREADS], v7 = src[q + 7 * THREADS];
+                dst[q] = v0; dst[q + THREADS] = v1; dst[q + 2 * THREADS] = v2; dst[q + 3 * THREADS] = v3;
+                dst[q + 4 * THREADS] = v4; dst[q + 5 * THREADS] = v5; dst[q + 6 * THREADS] = v6; dst[q + 7 * THREADS] = v7;
             }
-            for (; q < n16; q += kSharedThreads) dst[q] = src[q];
+            for (; q < n16; q += THREADS) dst[q] = src[q];
         }
         __syncthreads();
     };
@@ -983,9 +988,9 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.frames);
         uint4 *dst = reinterpret_cast<uint4 *>(s_frames);
-        for (int q = tid; q < kSlots * (int)(sizeof(SharedFrame) / 16); q += kSharedThreads) dst[q] = src[q];
+        for (int q = tid; q < kSlots * (int)(sizeof(SharedFrame) / 16); q += THREADS) dst[q] = src[q];
         const uint4 *psrc = p.wtiles + (size_t)p.nkb * kWideW16;
-        for (int q = tid; q < NT * 64; q += kSharedThreads) s_poly[q] = psrc[q];
+        for (int q = tid; q < NT * 64; q += THREADS) s_poly[q] = psrc[q];
         if (tid == 0) *s_ticket = 0u;
         if (tid < 32) s_ring[tid] = 0;
         __syncthreads();
@@ -1034,13 +1039,13 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     // balanced by the draw itself.  In this mode a "unit" below is its global index.
     const bool gdyn = dynamic && p.ctr != nullptr;
     const int whole_rounds = gdyn ? 0 : ((dynamic && POOL) ? ngroups / (int)gridDim.x : (ngroups + (int)gridDim.x - 1) / (int)gridDim.x);
-    const int64_t pool0 = (int64_t)whole_rounds * (int64_t)gridDim.x * 8, total_units = (int64_t)ngroups * 8;
+    const int64_t pool0 = (int64_t)whole_rounds * (int64_t)gridDim.x * WAVES, total_units = (int64_t)ngroups * WAVES;
     auto unit_global = [&](int u) -> int64_t {          // the 64-vertex unit behind local ticket u (>= total_units: none)
         if (gdyn) return (int64_t)u;
-        if (u < 8 * whole_rounds) return ((int64_t)blockIdx.x + (int64_t)(u >> 3) * (int64_t)gridDim.x) * 8 + (u & 7);
-        return pool0 + (int64_t)blockIdx.x + (int64_t)(u - 8 * whole_rounds) * (int64_t)gridDim.x;
+        if (u < WAVES * whole_rounds) return ((int64_t)blockIdx.x + (int64_t)(u / WAVES) * (int64_t)gridDim.x) * WAVES + (u % WAVES);
+        return pool0 + (int64_t)blockIdx.x + (int64_t)(u - WAVES * whole_rounds) * (int64_t)gridDim.x;
     };
-    auto unit_group = [&](int u) -> int64_t { const int64_t g = unit_global(u); return g < total_units ? (g >> 3) : (int64_t)ngroups; };
+    auto unit_group = [&](int u) -> int64_t { const int64_t g = unit_global(u); return g < total_units ? (g / WAVES) : (int64_t)ngroups; };
     // The draw is ISSUED when the first unit of round r is handed out, for round r + 3, and its result is PUBLISHED only at the
     // end of that wave's current group, behind the epilogue's stores, in straight-line code: a wave's vector-memory operations
     // retire in order, so waiting for the atomic's return where it is issued would wait for every store before it (the
@@ -1073,13 +1078,13 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         pend_round = -1;
     };
     auto next_unit = [&](int u) {
-        if (!dynamic) return u + 8;
+        if (!dynamic) return u + WAVES;
         unsigned v = 0;
         if (lane == 0) v = __hip_atomic_fetch_add(s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int t = (int)__builtin_amdgcn_readfirstlane(v);
-        round_taken = t >> 3;
+        round_taken = t / WAVES;
         if (!gdyn) return t;
-        const int r = t >> 3;
+        const int r = t / WAVES;
         int grp = 0;
         if (lane == 0) {
             unsigned tag, val;
@@ -1092,7 +1097,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             grp = (int)val;                                 // (read behind its tag: published in the opposite order)
         }
         grp = __builtin_amdgcn_readfirstlane(grp);
-        if ((t & 7) == 0 && grp < ngroups) {
+        if ((t % WAVES) == 0 && grp < ngroups) {
             if (pend_round >= 0) publish_draw(std::true_type{});      // (a wave that drew twice before finishing a group: never leave a round unpublished)
             if (lane == 0) {
                 unsigned one = 1u;
@@ -1101,7 +1106,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             }
             pend_round = r + 3;
         }
-        return grp < ngroups ? grp * 8 + (t & 7) : (int)total_units;
+        return grp < ngroups ? grp * WAVES + (t % WAVES) : (int)total_units;
     };
     auto load_raw = [&](int64_t gu, auto fastTag) {
         constexpr bool FAST = decltype(fastTag)::value;
@@ -1131,8 +1136,16 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         const int64_t gu_next = unit_group(un) < ngroups ? unit_global(un) : unit_global(u);       // whose positions to request
         // (the workgroup's OWN round counter decides: the global group numbers a workgroup draws all have the parity of its
         // index -- 256 workgroups draw in step -- and one wave of each SIMD would keep the priority for the whole launch)
-        if (((lround ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
+        if constexpr (WAVES == 8) {
+            if (((lround ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        } else {
+            // three waves per SIMD: the priority goes round
+            const int turn = (lround + (wave >> 2)) % 3;
+            if (turn == 0) __builtin_amdgcn_s_setprio(2);
+            else if (turn == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const GroupRaw cur = nxt;
         // this lane's own vertex in the epilogue is (vt = h, j)
         const float pos[3] = {h ? cur.p[1][0] : cur.p[0][0], h ? cur.p[1][1] : cur.p[0][1], h ? cur.p[1][2] : cur.p[0][2]};
@@ -1520,7 +1533,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         if (idx < NSLOT * 8 && (idx & 7) == 1) built_here = built_here && tab[q] != 0u;
     }
     const bool fast_ok = p.fast && __all(built_here);
-    const int nfull = (int)(p.N / kSharedThreads);       // groups in which every wave's 64 vertices exist
+    const int nfull = (int)(p.N / THREADS);       // groups in which every wave's 64 vertices exist
     int u = dynamic ? next_unit(0) : wave;
     int ru = dynamic ? round_taken : 0;
     nxt = load_raw(unit_group(u) < ngroups ? unit_global(u) : 0, std::false_type{});
@@ -1546,17 +1559,17 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         // the last wave of the launch to finish puts both counters back to zero for the next launch on this scratch set
         // (every draw of every workgroup has returned by then: a wave stores its draw in the ring before it goes on)
         const unsigned done = __hip_atomic_fetch_add(p.ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x * (kSharedThreads / 64) - 1) {
+        if (done == gridDim.x * (THREADS / 64) - 1) {
             __hip_atomic_store(p.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(p.ctr + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (stamp && lane == 0) {
+    if (stamp && lane == 0 && wave < 8) {
         for (int q = 0; q < 4; ++q) p.stamps[wave * 8 + q] = st_acc[q];
         p.stamps[wave * 8 + 4] = __builtin_amdgcn_s_memtime() - st_t0;          // shader clock against the 100 MHz reference
         p.stamps[wave * 8 + 5] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
-    if (p.stamps != nullptr && lane == 0) {      // every wave's first and last tick of the 100 MHz clock: the spread over the workgroups
+    if (p.stamps != nullptr && lane == 0 && wave < 8) {      // every wave's first and last tick of the 100 MHz clock: the spread over the workgroups
         p.stamps[64 + ((size_t)blockIdx.x * 8 + wave) * 2] = st_r0;
         p.stamps[64 + ((size_t)blockIdx.x * 8 + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
     }
@@ -1672,7 +1685,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (kchunk > nkb) kchunk = nkb;
     p.kchunk = kchunk;
     const size_t lds = fixed + per_kb * (size_t)kchunk;
-    const int64_t per = kSharedThreads / 64 * 64;          // vertices per workgroup and group
+    const int64_t per = wide ? 64 * kWideWaves : kSharedThreads / 64 * 64;          // vertices per workgroup and group
     const int64_t ngroups = (a.N + per - 1) / per;
     // One persistent workgroup per CU (150 KiB of LDS, two 240-register waves per SIMD: nothing else fits beside it).
     // a.max_wgs < 256 (fd_batch_set_eval_cus) leaves the other CUs to whatever runs on other streams -- the builds of the
@@ -1692,9 +1705,9 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
 #define FD_WIDE_CASE(GSS, NTW, NSL)                                                                                  \
     {                                                                                                                \
         static LdsAttrOnce once;                                                                                     \
-        hipError_t e = once.ensure((const void *)k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL>, 160 * 1024); \
+        hipError_t e = once.ensure((const void *)k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL, kWideWaves>, 160 * 1024); \
         if (e != hipSuccess) return e;                                                                               \
-        hipLaunchKernelGGL((k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL>), dim3(grid), dim3(kSharedThreads), lds, stream, p, (int)ngroups); \
+        hipLaunchKernelGGL((k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL, kWideWaves>), dim3(grid), dim3(64 * kWideWaves), lds, stream, p, (int)ngroups); \
     }
 #define FD_WIDE_KIND(NTW, NSL) { if (gauss) FD_WIDE_CASE(true, NTW, NSL) else FD_WIDE_CASE(false, NTW, NSL) }
     if (wide) {
