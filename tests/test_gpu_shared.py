@@ -140,12 +140,13 @@ def test_shared_needs_one_rest_rig_and_falls_back_for_other_kernels(hip_lib):
     _close(engines, batch)
 
 
-def test_contexts_may_be_rebuilt_once_the_launch_has_its_copy(hip_lib, oracle):
+@pytest.mark.parametrize("F", [16, 32])       # 16: the 16-row kernel; 32: the 32-row kernel (what bench.py's pipeline launches)
+def test_contexts_may_be_rebuilt_once_the_launch_has_its_copy(hip_lib, oracle, F):
     """fd_batch_wait_consumed: the shared-rig launch reads the contexts' models only in its first small kernel (weights,
     centre tiles and normalisation go into the batch's scratch).  A lane that waits for that point -- not for the
     evaluation -- and then builds the NEXT group's models on the same contexts must leave the evaluation in flight
     untouched: its frames still match the oracle for the FIRST group's deltas, and the second evaluation the second's."""
-    N, M, F = 400_000, 256, 16
+    N, M = 400_000, 256
     dev = torch.device("cuda", 0)
     P = synth.head_mesh(N)
     rest = synth.control_points(M, "head")
@@ -232,13 +233,14 @@ def test_shared_frames_of_the_gaussian_models(hip_lib, oracle, kind, okind, para
     _close(engines, batch)
 
 
-def test_prepared_sets_give_the_same_bits_and_survive_a_pipeline(hip_lib):
+@pytest.mark.parametrize("F", [16, 32])
+def test_prepared_sets_give_the_same_bits_and_survive_a_pipeline(hip_lib, F):
     """fd_batch_prepare_shared packs the models on the build stream; the evaluation that follows with the same
     outputs launches alone.  Three groups cooked back to back on ONE batch, as a lane of bench.py cooks them (build,
     prepare on the lane stream; evaluate on another stream that only waits for the lane), must equal the same
     groups cooked one at a time with the launch packing for itself -- bit for bit: the two scratch sets are used in
     turn and a set is not rewritten while the evaluation that reads it is still running."""
-    N, M, F, G = 300_000, 256, 16, 3
+    N, M, G = 300_000, 256, 3
     dev = torch.device("cuda", 0)
     P = synth.head_mesh(N)
     rest = synth.control_points(M, "head")
