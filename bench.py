@@ -315,7 +315,8 @@ def c5_roofline(args, B, n_ctrl, n_mine, eval_ms, flops_frames, tf_frames):
         mfma = {"achieved": fl / secs / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                 "flops_per_launch": fl}
         first = hbm if fl / by < ridge else mfma
-        return {"bound": "hbm" if fl / by < ridge else "mfma", "kernel": "k_deform32_tps_shared_wide" if B > 16 else "k_deform32_tps_shared",
+        from facedeform_amd import capi
+        return {"bound": "hbm" if fl / by < ridge else "mfma", "kernel": capi.load().fd_shared_kernel_name(n_ctrl, B, capi.KERNEL_THIN_PLATE).decode(),
                 "achieved": first["achieved"],
                 "peak": first["peak"], "unit": first["unit"], "frac": first["frac"], "traffic": None, "avg_launch_ms": eval_ms,
                 "frames_per_launch": B, "intensity_flop_per_byte": fl / by, "ridge_flop_per_byte": ridge, "hbm": hbm, "mfma": mfma}
@@ -399,10 +400,41 @@ class RawEvents:
             RawEvents._hip.hipEventDestroy(e)
 
 
-def shared_rows(frames):
-    """Rows of the weight operand the shared-rig launch runs for `frames` frames (16 per output tile; mirrors
-    launch_deform_shared in csrc/fd_eval.hip: 13 frames and more in blocks of 16, one tile per component;
-    fewer as 4 frames x (x, y, z, pad) per tile)."""
+def host_cook_ms(capi, synth, P_host, rest_host, device):
+    """the cook end to end INCLUDING the host link, as the Houdini node lives it -- fdsop_cook (the cookMySop
+    mirror: parm read, control table, build, evaluation, write-back) on page-locked mesh arrays as hdk/SOP_FaceDeformHip.cpp keeps
+    them, thin-plate kernel, the node's other parms at their defaults.  Two figures: everything new every cook (mesh upload 12 MB,
+    model rebuilt, 16 MB back), and the animated-shot case (mesh and rest rig unchanged: deltas only, results back).  Not `value`."""
+    from facedeform_amd.sop import FaceDeformSOP
+    n = P_host.shape[0]
+    pin_in = capi.host_array((n, 3)); pin_in[:] = P_host
+    pin_out = capi.host_array((n, 3)); pin_fall = capi.host_array(n)
+    node = FaceDeformSOP(device=device)
+    node.set("kernel", 1)                       # thin-plate (the wrapper's added ordinal; BASELINE's kernel)
+    out = {}
+    for key, kw in (("rebuild", {}), ("mesh_and_rest_rig_unchanged", {"rig_rest_unchanged": True, "mesh_unchanged": True})):
+        ts = []
+        for f in range(12):
+            deform = synth.deformed_rig(rest_host, f)
+            t0 = time.perf_counter()
+            res = node.cook(pin_in, rest_host, deform, out_P=pin_out, out_falloff=pin_fall, want_Cd=False, **kw)
+            ts.append(time.perf_counter() - t0)
+            if res.severity >= 3:              # FDSOP_ERROR
+                raise SystemExit(f"fdsop_cook failed: {res.errors}")
+        ts = sorted(ts[2:])
+        out[key] = ts[len(ts) // 2] * 1e3
+    node.close()
+    return out
+
+
+def shared_rows(frames, kernel):
+    """Rows of the weight operand the shared-rig launch runs for `frames` frames (mirrors launch_deform_shared in
+    csrc/fd_eval_shared.hip).  17..32 frames (both 32-row kernels): row 3 f + c of a stack of 32-row tiles for nslot = 4 ceil(F / 4)
+    frame slots, i.e. 32 ceil(3 nslot / 32) rows -- 64 at 20 frames, 96 from 21 on.  Up to 16 frames (16-row tiles): 13..16 frames
+    one tile per component, fewer as 4 frames x (x, y, z, pad) per tile."""
+    if kernel in ("k_deform32_shared_w1", "k_deform32_tps_shared_wide"):
+        nslot = 4 * ((frames + 3) // 4)
+        return 32 * ((3 * nslot + 31) // 32)
     return 16 * (3 * ((frames + 15) // 16) if frames > 12 else (frames + 3) // 4)
 
 
@@ -661,12 +693,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    solver_seen = []
+
     def check_builds():
         for ln in lanes:
             for eng in ln["engines"][: ln.get("used", 0)]:
                 rep = eng.build_result()
                 if rep.terminationtype != 1:
                     raise SystemExit(f"build failed: terminationtype {rep.terminationtype}")
+                solver_seen.append(rep.solver_used)
 
     g_next = run_steps(args.warmup)
     if args.warmup < B * n_lanes:                      # touch every lane and capture its graph once
@@ -776,6 +811,8 @@ def main():
             print(f"[timeline ms] group {i // B}: build {base.elapsed_time(events[i][0]):8.3f} -> "
                   f"{base.elapsed_time(events[i][1]):8.3f}   evaluation {base.elapsed_time(events[i][2]):8.3f} -> "
                   f"{base.elapsed_time(events[i][3]):8.3f}", file=sys.stderr, flush=True)
+    lane_solver_used = max(set(solver_seen), key=solver_seen.count) if solver_seen else lane_solver
+    host_cook = host_cook_ms(capi, synth, P_host, rest_host, local_rank) if (rank == 0 and world == 1 and not rehearse) else None
     if rank == 0:
         total_verts = world * args.steps * n_verts
         flops = (FLOPS_PER_PAIR * n_ctrl + FLOPS_PER_VERTEX_AFFINE) * n_verts
@@ -827,10 +864,12 @@ def main():
             Fl = frames_per_launch
             flops_launch = ((8 + 6 * Fl) * n_ctrl + FLOPS_PER_VERTEX_AFFINE * Fl) * n_verts
             bytes_launch = (12 + 16 * Fl) * n_verts
-            # 17..32 thin-plate frames take the 32-row tiles (csrc/fd_eval_shared.hip: k_deform32_tps_shared_wide)
-            kern = "k_deform32_tps_shared_wide" if Fl > 16 else "k_deform32_tps_shared"
-            # executed on the matrix pipe: 3 split products over the rows of the output tiles + the d2 tiles
-            mfma_exec = (3 * 2 * shared_rows(Fl) * n_ctrl + 2 * 16 * n_ctrl) * n_verts        # flop, fp16 MFMA
+            # the kernel the library launches for this (M, frames): 17..32 frames take 32-row tiles -- k_deform32_shared_w1 where the
+            # model is resident in LDS (C2), k_deform32_tps_shared_wide where it is staged in chunks (C3, C5)
+            kern = capi.load().fd_shared_kernel_name(n_ctrl, Fl, capi.KERNEL_THIN_PLATE).decode()
+            # executed on the matrix pipe: 3 split products over the rows of the output tiles + the d2 tiles + the polynomial tile
+            rows = shared_rows(Fl, kern)
+            mfma_exec = (3 * 2 * rows * n_ctrl + 2 * 16 * n_ctrl + 2 * 16 * rows) * n_verts        # flop, fp16 MFMA
             secs = launch_ms * 1e-3
             mfma_alg = {"achieved": flops_launch / secs / 1e12, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops_launch / secs / 1e12 / PEAK_FP16_MFMA_TFLOPS, "flops_per_launch": flops_launch,
@@ -899,9 +938,12 @@ def main():
                 "evaluation_stream": "the group's build stream (a single group: nothing to overlap)" if args.steps <= B else args.eval_stream,
                 "timed_groups": f"HIP event pairs around the build and the evaluation launch of every {stride}-th group" if c_groups else "every group",
                 "cu_split": cu_split,
-                "pipeline_build": ("one workgroup per model, matrix in L2 (FD_SOLVER_ONE_WORKGROUP)" if lane_solver == capi.SOLVER_ONE_WORKGROUP
-                                   else "launch chain (FD_SOLVER_CHAIN)" if lane_solver == capi.SOLVER_CHAIN
-                                   else "one launch, one workgroup per model, matrix in registers (FD_SOLVER_AUTO: fd_build_reg.hip)"),
+                # what the lanes' builds actually ran (fd_report.solver_used of a lane's last build), not what was asked for
+                "pipeline_build": {capi.SOLVER_REGISTER: "one launch, one workgroup per model, matrix in registers (fd_build_reg.hip)",
+                                   capi.SOLVER_ONE_WORKGROUP: "one workgroup per model, matrix in L2 (FD_SOLVER_ONE_WORKGROUP)",
+                                   capi.SOLVER_CHAIN: "launch chain: null-space Cholesky, one launch per 32 columns (fd_nullspace.hip)",
+                                   capi.SOLVER_LU: "launch chain: pivoted LU (fd_build.hip)",
+                                   capi.SOLVER_LU_NOPIVOT: "launch chain: LU without pivot search (fd_build.hip)"}.get(lane_solver_used, f"solver {lane_solver_used}"),
                 "lanes_per_gpu": n_lanes,
                 "parallelism": f"independent frames: {world} GPU(s) x {n_lanes} lanes x {B} frames per batched "
                                "build and per evaluation launch (one build stream per lane, one evaluation "
@@ -923,7 +965,11 @@ def main():
             "host": {"group_call": args.group_call if shared_eval else "python", "us_per_group": host_s[0] / max(1, host_s[1]) * 1e6,
                      "groups_timed": host_s[1]},
             "phases_ms": {"build_per_frame_batched": build_ms, "build_batch": build_group_ms,
-                          "evaluate": eval_ms, "single_cook_latency": latency_ms, "single_build": single_build_ms},
+                          "evaluate": eval_ms, "single_cook_latency": latency_ms, "single_build": single_build_ms,
+                          # PCIe-inclusive, through the cook mirror on page-locked arrays; never `value`
+                          "end_to_end_host_cook": host_cook["rebuild"] if host_cook else None,
+                          "end_to_end_host_cook_static_mesh_and_rig": host_cook["mesh_and_rest_rig_unchanged"] if host_cook else None},
+            "end_to_end_host_cook_mverts_s": (n_verts / (host_cook["rebuild"] * 1e-3) / 1e6) if host_cook else None,
             "eval_only_mverts_s": n_verts / (eval_ms * 1e-3) / 1e6,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -64,7 +64,7 @@ EXPORTS = [
     "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
     "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
     "fd_morph_get_qr",
-    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error", "fd_batch_wait_consumed", "fd_batch_prepare_shared", "fd_batch_set_eval_cus", "fd_batch_cook_group",
+    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error", "fd_batch_wait_consumed", "fd_batch_prepare_shared", "fd_batch_set_eval_cus", "fd_batch_cook_group", "fd_shared_kernel_name",
     "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result", "fd_batch_deform_dev",
     "fd_batch_deform_shared_dev",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
@@ -150,6 +150,7 @@ def load() -> C.CDLL:
     L.fd_batch_wait_consumed.argtypes = [vp, vp]; L.fd_batch_wait_consumed.restype = i32
     L.fd_batch_prepare_shared.argtypes = [vp, vp, vp, vp]; L.fd_batch_prepare_shared.restype = i32
     L.fd_batch_set_eval_cus.argtypes = [vp, i32]; L.fd_batch_set_eval_cus.restype = i32
+    L.fd_shared_kernel_name.argtypes = [i32, i32, i32]; L.fd_shared_kernel_name.restype = C.c_char_p
     L.fd_batch_cook_group.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp]; L.fd_batch_cook_group.restype = i32
     L.fd_batch_last_error.argtypes = [vp]; L.fd_batch_last_error.restype = C.c_char_p
     L.fd_batch_set_points_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32]

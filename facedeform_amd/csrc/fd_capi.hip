@@ -1960,4 +1960,11 @@ int fd_batch_set_eval_cus(fd_batch *b, int n_cus)
 
 int fd_batch_size(const fd_batch *b) { return b ? b->n : 0; }
 
+const char *fd_shared_kernel_name(int M, int frames, int kind)
+{
+    const bool takes = (kind == FD_KERNEL_THIN_PLATE || kind == FD_KERNEL_GAUSSIAN || kind == FD_KERNEL_GAUSSIAN_QNN) && M > 0 && round_up(M, kRecPad) >= 32 &&
+                       frames >= 1 && frames <= kMaxBatch;
+    return takes ? shared_kernel_name(round_up(M, kRecPad), frames, kind) : "";
+}
+
 }  // extern "C"

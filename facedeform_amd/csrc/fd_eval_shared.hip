@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_pack_shared(const SharedSlots slots, co
 // many).  The Gaussian kinds take this form: there the inputs come straight from v_exp_f32, and a vector
 // instruction hidden in an asm string that reads a transcendental's result gets none of the wait states the
 // compiler pads that pair with (hipcc pads nothing inside or around asm strings).
-template <bool PLAIN = false>
+template <bool PLAIN = false, bool NOP = true>
 __device__ __forceinline__ void split_pair_f16(float v0, float v1, unsigned &hi, unsigned &lo)
 {
     if constexpr (PLAIN) {
@@ -267,7 +267,9 @@ __device__ __forceinline__ void split_pair_f16(float v0, float v1, unsigned &hi,
     // (s_nop 1 inside the string: a register written by a vector instruction needs two wait states before a matrix
     // instruction reads it as an operand, and the compiler pads only producers it can see; no measurable cost:
     // 218-229 us per C2 x 32 launch with it, 210-237 without, same box)
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(hi), "v"(v1));
+    // (NOP = false: the caller fences a whole block of pairs with ONE s_nop behind the last of them, fence_operands below)
+    if constexpr (NOP) asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(hi), "v"(v1));
+    else asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(v1));
     lo = l;
 }
 
@@ -807,8 +809,12 @@ constexpr int wide_w16(int nt) { return nt * 2 * 2 * 64; }                      
 // grid (nkb, NT row tiles), 256 threads.  Output regions: weight tiles [kb][tile][K step][hi, lo][lane], NT x 64 words of
 // polynomial tiles, then the d2 operands of the centres ([kb][2 instructions][64 lanes] x 8 B) and the normalisation.
 // nslot frame slots (a multiple of 4); slots.rec32 / model / out of the slots beyond nF point at frame nF - 1 (the host sets them).
+// layout 1 (k_deform32_shared_w1, one vertex tile per wave): the d2 operand of a K block is ONE K = 16 instruction -- lane (h, r)
+// holds coordinate groups 2 h, 2 h + 1 of centre r, 16 bytes -- and the rows are dealt out per lane half: row rho of tile T is
+// register r = 4 (rho / 8) + rho % 4 of half hh = (rho / 4) % 2, flat index k = 16 T + r of that half = component k % 3 of the
+// half's local frame k / 3, which is frame slot 2 (k / 3) + hh.
 __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slots, const SharedOut out, int nF, int nslot, int Mpad,
-                                                           uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles, int gauss)
+                                                           uint4 *wtiles, SharedFrame *frames, const MfmaTileH *ctiles, int gauss, int layout)
 {
     const int kb = blockIdx.x, T = blockIdx.y, nkb = gridDim.x, NT = gridDim.y;
     const int w16 = wide_w16(NT);
@@ -823,6 +829,17 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
                 const int centre = 32 * kb + (int)threadIdx.x;
                 wtiles[copy_at + (size_t)kb * 64 + threadIdx.x] =
                     centre < Mpad ? *reinterpret_cast<const uint4 *>(&slots.rec32[0][centre]) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else if (layout == 1) {
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x, h = lane >> 5, r = lane & 31;
+                const int tile = 2 * kb + (r >> 4);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (tile < Mpad / 16) {
+                    const unsigned *a0 = ctiles[tile].a[16 * (2 * h) + (r & 15)], *a1 = ctiles[tile].a[16 * (2 * h + 1) + (r & 15)];
+                    v = make_uint4(a0[0], a0[1], a1[0], a1[1]);
+                }
+                wtiles[copy_at + (size_t)kb * 64 + lane] = v;
             }
         } else if (threadIdx.x < 128) {
             const int i = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
@@ -867,7 +884,14 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
     __syncthreads();
     if (threadIdx.x >= 128) return;
     const int s = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5;
-    const int row = 32 * T + (lane & 31), f = row / 3, c = row % 3;               // row 3 f + c = component c of frame slot f
+    int f, c;
+    if (layout == 1) {
+        const int rho = lane & 31, k = 16 * T + 4 * (rho >> 3) + (rho & 3);
+        f = 2 * (k / 3) + ((rho >> 2) & 1); c = k % 3;
+    } else {
+        const int row = 32 * T + (lane & 31);                                      // row 3 f + c = component c of frame slot f
+        f = row / 3; c = row % 3;
+    }
     const bool live = f < nslot;
     const float sc = live ? s_scale[f] : 0.f;
     f16x8 hi, lo;
@@ -906,6 +930,9 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 
 #ifndef FD_WIDE_VPM
 #define FD_WIDE_VPM 3            // vector instructions placed after each matrix instruction of the K loop
+#endif
+#ifndef FD_W1_VPM
+#define FD_W1_VPM 3              // the same for the one-tile kernel (k_deform32_shared_w1)
 #endif
 
 // VAR (build variants kept for A/B runs inside one process: FD_SHARED_WIDE_VAR, tests/tools/wide_variants_timing.py):
@@ -1576,6 +1603,435 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 #undef FD_SSTAMP
 }
 
+// ---- 17 to 32 frames, round 4: ONE 32-vertex tile per wave, three waves per SIMD ------------------------------------------------
+// Round 3's 32-row kernel keeps two waves per SIMD (64 vertices = two vertex tiles each, 96 accumulator registers) and loses a
+// third of the launch where a wave is outside its K loop -- loads, epilogue, stores -- because the partner alone cannot keep the
+// matrix pipe busy (matrix pipe busy 0.48 by PMC).  Here a wave owns ONE vertex tile of 32: 48 accumulator registers, ~130
+// registers in all, so THREE waves share a SIMD (twelve per workgroup) and the hardware has two others to issue from while one
+// stores.  What changes beside the tile count:
+//   * d2 of a K block is ONE v_mfma_f32_32x32x16_f16 (K = 16 holds the four coordinate groups x | y | z | norms that round 3
+//     split over two K = 8 instructions): both lane halves carry the same vertex, half 0 supplies groups 0, 1, half 1 groups 2, 3;
+//   * no lane-half swap in the epilogue.  Both halves of a lane pair (h, j) hold rows of the SAME vertex j -- register r of
+//     row tile c is row 8 (r / 4) + 4 h + r % 4 -- so the rows are dealt out per half: frame slot fs lives in half fs & 1 as local
+//     frame lf = fs >> 1, and its component comp is the half's flat accumulator index 3 lf + comp (tile (3 lf + comp) / 16,
+//     register (3 lf + comp) % 16).  One position store instruction writes TWO frames: lanes of half 0 frame 2 lf, of half 1
+//     frame 2 lf + 1, 384 contiguous bytes each (per-lane 64-bit addresses from a 16-byte table entry per (lf, h) in LDS);
+//   * fd_falloff rows of a unit are 128 bytes per frame: one 16-byte store per lane covers EIGHT frames.
+// The weight tiles are packed to that row order (k_pack_shared_wide, layout 1); their [K block][tile][K step][hi, lo][lane] order,
+// the K-slot <-> centre map and the polynomial tile are round 3's.  The K loop is plain double buffering, unrolled by two so
+// that no operand is copied: phi of block k + 1 (16 logarithms, 16 multiplies, the fp16 split) goes under the 18 matrix
+// instructions of block k.
+constexpr int kW1Waves = 12;                      // three per SIMD (tuning builds also instantiate 8: two per SIMD)
+constexpr int kW1Unit = 32;                       // vertices per wave and unit
+constexpr size_t w1_fixed_lds(int nt) { return sizeof(SharedFrame) * (size_t)kWideSlots + 32 * 16 + (size_t)nt * 64 * 16 + 256 * sizeof(uint64_t) + 16; }
+
+// The whole model must be resident in LDS (p.nkb <= p.kchunk: M = 256 at 32 frames): no staging and no barrier inside the unit
+// loop.  Models that are staged in chunks keep the two-tile kernel: its 512-vertex groups re-stage the model a quarter less often
+// (C3, M = 2048: 1.04 against 1.15 ms per 32 frames; C5's ranges, M = 512: 0.40 against 0.44 ms, same process).
+template <bool GAUSS, int NT, int NSLOT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4)))
+void k_deform32_shared_w1(const SharedParams p, int ngroups)
+{
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int NLF = NSLOT / 2;                 // local frames per lane half
+    constexpr int NFQ = (NSLOT + 7) / 8;           // fd_falloff stores per unit (eight frames each)
+    static_assert(NSLOT % 4 == 0 && NSLOT <= kWideSlots && 3 * NLF <= 16 * NT, "frame slots in fours, three rows each, half of them per lane half");
+    constexpr int kW16 = wide_w16(NT);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [frame records 32][(lf, h) table 32 x 16 B][polynomial tiles NT x 1 KiB][fd_falloff pointers 4 x 64 x 8 B][ticket]
+    //      [d2 operands kchunk x 1 KiB][weight tiles kchunk x NT x 4 KiB]
+    SharedFrame *s_frames = reinterpret_cast<SharedFrame *>(smem);
+    uint4 *s_ptab = reinterpret_cast<uint4 *>(smem + sizeof(SharedFrame) * (size_t)kWideSlots);
+    uint4 *s_poly = s_ptab + 32;
+    uint64_t *s_ftab = reinterpret_cast<uint64_t *>(s_poly + NT * 64);
+    unsigned *s_ticket = reinterpret_cast<unsigned *>(s_ftab + 256);
+    uint4 *s_ct = reinterpret_cast<uint4 *>(s_ticket + 4);
+    uint4 *s_w = s_ct + (size_t)64 * p.kchunk;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const float n0 = p.norm[0], n1 = p.norm[1], n2 = p.norm[2];
+    const float inv_s = p.norm[3];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    auto stage_model = [&]() {
+        const int nk = p.nkb;
+        for (int q = tid; q < nk * 64; q += THREADS) s_ct[q] = reinterpret_cast<const uint4 *>(p.ctiles)[q];
+        // eight loads in flight per thread (native vectors: an array of HIP's uint4 structs goes through scratch memory)
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.wtiles);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(s_w);
+        const int n16 = nk * kW16;
+        int q = tid;
+        for (; q + 7 * THREADS < n16; q += 8 * THREADS) {
+            const u32x4 v0 = src[q], v1 = src[q + THREADS], v2 = src[q + 2 * THREADS], v3 = src[q + 3 * THREADS];
+            const u32x4 v4 = src[q + 4 * THREADS], v5 = src[q + 5 * THREADS], v6 = src[q + 6 * THREADS], v7 = src[q + 7 * THREADS];
+            dst[q] = v0; dst[q + THREADS] = v1; dst[q + 2 * THREADS] = v2; dst[q + 3 * THREADS] = v3;
+            dst[q + 4 * THREADS] = v4; dst[q + 5 * THREADS] = v5; dst[q + 6 * THREADS] = v6; dst[q + 7 * THREADS] = v7;
+        }
+        for (; q < n16; q += THREADS) dst[q] = src[q];
+        __syncthreads();
+    };
+
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.frames);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_frames);
+        for (int q = tid; q < kWideSlots * (int)(sizeof(SharedFrame) / 16); q += THREADS) dst[q] = src[q];
+        const uint4 *psrc = p.wtiles + (size_t)p.nkb * kW16;
+        for (int q = tid; q < NT * 64; q += THREADS) s_poly[q] = psrc[q];
+        if (tid == 0) *s_ticket = 0u;
+        if (tid < 32) {
+            // entry 2 lf + h: frame slot 2 lf + h = tid itself -- {P_out, 2^-k, built}
+            const SharedFrame fr = p.frames[tid < NSLOT ? tid : NSLOT - 1];
+            const uint64_t po = (uint64_t)fr.P_out;
+            s_ptab[tid] = make_uint4((unsigned)po, (unsigned)(po >> 32), __float_as_uint(fr.inv_scale), (unsigned)fr.built);
+        }
+        if (p.fast && tid < NFQ * 64) {
+            const int f = 8 * (tid >> 6) + ((tid & 63) >> 3);
+            s_ftab[tid] = (uint64_t)p.frames[f < NSLOT ? f : NSLOT - 1].falloff_out + 16u * (unsigned)(tid & 7);
+        }
+    }
+    stage_model();
+
+    struct UnitRaw { float p[3]; float d2; };
+    // Units: the workgroup's groups (blockIdx + k gridDim) are twelve 32-vertex units each; a wave takes its NEXT unit from a
+    // counter in LDS (no barrier in the loop), and the groups that do not fill a last round are dealt out as single units,
+    // workgroup by workgroup (as in the two-tile kernel above).
+    // (32-bit unit numbers: the host keeps N below 2^31, so there are fewer than 2^26 units; a ticket beyond the last unit maps to
+    // total_units or more, never wraps: at most WAVES tickets are taken after the first empty one)
+    const int whole_rounds = ngroups / (int)gridDim.x;
+    const int pool0 = whole_rounds * (int)gridDim.x * WAVES, total_units = ngroups * WAVES;
+    auto unit_global = [&](int u) -> int {          // the 32-vertex unit behind local ticket u (>= total_units: none)
+        if (u < WAVES * whole_rounds) return ((int)blockIdx.x + (u / WAVES) * (int)gridDim.x) * WAVES + (u % WAVES);
+        const int q = u - WAVES * whole_rounds;
+        return q < 2 * WAVES ? pool0 + (int)blockIdx.x + q * (int)gridDim.x : total_units;
+    };
+    auto unit_group = [&](int u) -> int { const int g = unit_global(u); return g < total_units ? (g / WAVES) : ngroups; };
+    auto next_unit = [&](int u) {
+        (void)u;
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto load_raw = [&](int gu, auto fastTag) {
+        constexpr bool FAST = decltype(fastTag)::value;
+        UnitRaw r;
+        const int64_t vi = (int64_t)gu * kW1Unit + j;
+        const int64_t vc = vi < p.N ? vi : p.N - 1;
+        if constexpr (FAST) {
+            // (the straight-line path runs with 12 N < 2^32: the frame's pointer as scalar base, one 32-bit lane offset)
+            const char *pb = reinterpret_cast<const char *>(p.P_in) + (size_t)(12u * (unsigned)vc);
+            r.p[0] = __builtin_nontemporal_load(reinterpret_cast<const float *>(pb)); r.p[1] = __builtin_nontemporal_load(reinterpret_cast<const float *>(pb + 4));
+            r.p[2] = __builtin_nontemporal_load(reinterpret_cast<const float *>(pb + 8));
+            r.d2 = 0.f;
+        } else {
+            r.p[0] = __builtin_nontemporal_load(&p.P_in[3 * vc]); r.p[1] = __builtin_nontemporal_load(&p.P_in[3 * vc + 1]);
+            r.p[2] = __builtin_nontemporal_load(&p.P_in[3 * vc + 2]);
+            r.d2 = p.dist2 ? p.dist2[vc] : 0.f;
+        }
+        return r;
+    };
+    auto settle = [&](const UnitRaw &r) { asm volatile("" :: "v"(r.p[0]), "v"(r.p[1]), "v"(r.p[2])); };
+    UnitRaw nxt;
+    int uc = 0;                                   // units this wave has done
+#ifdef FD_TUNING
+    // diagnostics of tuning builds (-DFD_TUNING): shader-clock shares of a unit's phases per wave of workgroup 0, p.dbg bit 0 = no
+    // stores, bit 1 = no K loop
+    const bool stamp = p.stamps != nullptr && blockIdx.x == 0;
+    const unsigned long long st_t0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    unsigned long long st_prev = st_t0, st_acc[4] = {0, 0, 0, 0};
+#define FD_W1STAMP(K) if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[K] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define FD_W1STAMP(K)
+#endif
+    auto do_unit = [&](int u, int un, auto fastTag) {
+        constexpr bool FAST = decltype(fastTag)::value;
+        const int64_t vbase = (int64_t)unit_global(u) * kW1Unit;
+        const int gu_next = unit_group(un) < ngroups ? unit_global(un) : unit_global(u);       // whose positions to request
+        const UnitRaw cur = nxt;
+        const float pos[3] = {cur.p[0], cur.p[1], cur.p[2]};
+        const float own_d2 = cur.d2;
+        f32x16 acc[NT];
+        const float x = (cur.p[0] - n0) * inv_s, y = (cur.p[1] - n1) * inv_s, z = (cur.p[2] - n2) * inv_s;
+        const bool lane_live = FAST ? true : ((vbase + j < p.N) && !(own_d2 > p.radius2));
+        const float xx = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        f16x8 bop;
+        {
+            // d2 operand, K = 16: lane half 0 carries the coordinate groups (x | y), half 1 (z | norms)
+            const float va = h == 0 ? -2.f * x : -2.f * z, vb2 = h == 0 ? -2.f * y : xx;
+            const _Float16 ha = (_Float16)va, la = (_Float16)(va - (float)ha);
+            const _Float16 hb = (_Float16)vb2, lb = (_Float16)(vb2 - (float)hb);
+            const _Float16 one = (_Float16)1.0f;
+            bop = h == 0 ? (f16x8){ha, la, ha, la, hb, lb, hb, lb} : (f16x8){ha, la, ha, la, one, one, hb, lb};
+        }
+        {
+            // polynomial operand, K = 16 (k_pack_shared_wide): half 0 {1, xh, yh, zh, xxh, xl, yl, zl}, half 1 {xxl, 1, xh, yh, zh, xxh, 0, 0}
+            // (GAUSS: everything times 2^10, the factor phi carries; undone with the frame's scale)
+            constexpr float ps = GAUSS ? (float)(1 << kGaussShift) : 1.f;
+            constexpr unsigned one16 = GAUSS ? 0x6400u : 0x3c00u;         // fp16 1024 / 1
+            unsigned xyh, xyl, zxh, zxl;
+            split_pair_f16(x * ps, y * ps, xyh, xyl);
+            split_pair_f16(z * ps, xx * ps, zxh, zxl);
+            u32x4 pb;
+            if (h == 0) pb = (u32x4){one16 | (xyh << 16), (xyh >> 16) | (zxh << 16), (zxh >> 16) | (xyl << 16), (xyl >> 16) | (zxl << 16)};
+            else pb = (u32x4){(zxl >> 16) | (one16 << 16), xyh, zxh, 0u};
+            const f16x8 pbv = __builtin_bit_cast(f16x8, pb);
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, s_poly[c * 64 + lane]), pbv, zero16, 0, 0, 0);
+        }
+        const bool wave_work = FAST ? true : __any(lane_live);
+        if constexpr (FAST) nxt = load_raw(gu_next, fastTag);      // a whole K loop ahead of this unit's stores
+        FD_W1STAMP(0)
+
+        // One K block of the software pipeline.  Entering step kb: (ch, cl) = the fp16 pieces of phi(kb), 16 values per lane
+        // (K step s in registers 4 s .. 4 s + 3); dd = the raw d2 of block kb + 1 (thin-plate); (w0h, w0l) = the weight
+        // operands of block kb's first (K step, row tile) pair.  The step forms phi(kb + 1) from dd into (nh, nl) under the 6 NT
+        // matrix instructions that contract phi(kb) with the weights, fetches every pair's weights one pair ahead (the first
+        // pair of block kb + 1 included), and issues the d2 instruction of block kb + 2 as soon as dd's last value is read.
+        // LAST: block kb is the chunk's last -- contraction only.
+        f32x16 dd;
+        f16x8 w0h, w0l;
+        auto d2_block = [&](int kb) {
+            if constexpr (!GAUSS) dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, s_ct[(size_t)kb * 64 + lane]), bop, zero16, 0, 0, 0);
+        };
+        auto phi_from = [&](int kb, u32x8 &xh, u32x8 &xl) {
+            if constexpr (GAUSS) {
+                // exp(-d2 / R_j^2) from direct coordinate differences, one value per instruction; this lane's
+                // centres of K step s -- 16 s + 8 (m / 4) + 4 h + m % 4 -- are records 8 (2 s + m / 4) + 4 h + m % 4 of the block
+                const float4 *cr = reinterpret_cast<const float4 *>(s_ct + (size_t)kb * 64) + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float ph[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float4 c = cr[8 * (q >> 1) + 2 * (q & 1) + e];
+                        const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
+                        float d2 = dx * dx;
+                        d2 = __builtin_fmaf(dy, dy, d2);
+                        d2 = __builtin_fmaf(dz, dz, d2);
+                        ph[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(d2, c.w, (float)kGaussShift));
+                    }
+                    unsigned hh, ll;
+                    split_pair_f16<true>(ph[0], ph[1], hh, ll);
+                    xh[q] = hh; xl[q] = ll;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    unsigned hh, ll;
+                    split_pair_f16<false, false>(d2_log_d2(dd[2 * q]), d2_log_d2(dd[2 * q + 1]), hh, ll);
+                    xh[q] = hh; xl[q] = ll;
+                }
+                // the two wait states a vector write needs before a matrix instruction reads it as an operand, ONCE for the
+                // block: the lo pieces come out of asm strings the compiler pads nothing behind, and every later use of them
+                // depends on this statement
+                asm volatile("s_nop 1" : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xl[4]), "+v"(xl[5]), "+v"(xl[6]), "+v"(xl[7]));
+            }
+        };
+        auto step = [&](int kb, int nk, const u32x8 &ch, const u32x8 &cl, u32x8 &nh, u32x8 &nl, auto lastTag) {
+            constexpr bool LAST = decltype(lastTag)::value;
+            constexpr int NP = 2 * NT;                         // (K step, row tile) pairs of a block, pair = s * NT + c
+            const uint4 *wk = s_w + (size_t)kb * kW16 + lane;
+            const int kbn = kb + 1 < nk ? kb + 1 : kb, kbd = kb + 2 < nk ? kb + 2 : nk - 1;
+            const uint4 *wkn = s_w + (size_t)kbn * kW16 + lane;
+            if constexpr (!LAST) phi_from(kb + 1, nh, nl);
+            f16x8 ph_ = w0h, pl_ = w0l;
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                const int s_ = pr / NT, c = pr % NT;
+                // the next pair's weights (the last pair fetches the first pair of the next block)
+                f16x8 qh, ql;
+                if (pr + 1 < NP) {
+                    const int s2 = (pr + 1) / NT, c2 = (pr + 1) % NT;
+                    qh = __builtin_bit_cast(f16x8, wk[((c2 * 2 + s2) * 2) * 64]); ql = __builtin_bit_cast(f16x8, wk[((c2 * 2 + s2) * 2 + 1) * 64]);
+                } else {
+                    qh = __builtin_bit_cast(f16x8, wkn[0]); ql = __builtin_bit_cast(f16x8, wkn[64]);
+                }
+                const f16x8 vh = __builtin_bit_cast(f16x8, (u32x4){ch[4 * s_], ch[4 * s_ + 1], ch[4 * s_ + 2], ch[4 * s_ + 3]});
+                const f16x8 vl = __builtin_bit_cast(f16x8, (u32x4){cl[4 * s_], cl[4 * s_ + 1], cl[4 * s_ + 2], cl[4 * s_ + 3]});
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph_, vh, acc[c], 0, 0, 0);
+                // (the d2 instruction of block kb + 2 in source order where the schedule below wants it: behind the first
+                // instruction of the last pair -- every logarithm of this step has read dd by then)
+                if constexpr (!LAST) if (pr == NP - 1) d2_block(kbd);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl_, vh, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph_, vl, acc[c], 0, 0, 0);
+                ph_ = qh; pl_ = ql;
+            }
+            w0h = ph_; w0l = pl_;
+            if constexpr (GAUSS || LAST) return;             // (the Gaussian block is left to the scheduler's own order)
+            // issue order: under each matrix instruction one logarithm (two at first where a block has only 12) issued BEFORE it
+            // -- the matrix instruction is the wait state between the logarithm and the multiply that reads it --, then the
+            // other vector work; LDS reads one pair ahead, behind the first instruction of a pair; the d2 instruction of block
+            // kb + 2 right behind the matrix instruction that follows the last logarithm
+            constexpr int NM = 6 * NT, TR2 = NT == 3 ? 0 : 8;        // slots with two logarithms
+            constexpr int QD = 3 * (NP - 1);                         // the d2 instruction goes behind this slot's
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                if (q < TR2) __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                else if (q < TR2 + (16 - 2 * TR2)) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (q == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (q == QD) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NT == 3 ? FD_W1_VPM : FD_W1_VPM + 1, 0);
+            }
+        };
+#ifdef FD_TUNING
+        const bool k_loop = (FAST || wave_work) && !(p.dbg & 2);
+#else
+        const bool k_loop = FAST || wave_work;
+#endif
+        if (k_loop) {
+            const int nk = p.nkb;
+            u32x8 ah_, al_, bh_, bl_;
+            d2_block(0);
+            phi_from(0, ah_, al_);
+            d2_block(nk > 1 ? 1 : 0);
+            w0h = __builtin_bit_cast(f16x8, s_w[lane]); w0l = __builtin_bit_cast(f16x8, s_w[64 + lane]);
+            int kb = 0;
+            while (kb + 2 < nk) {
+                step(kb, nk, ah_, al_, bh_, bl_, std::false_type{});
+                step(kb + 1, nk, bh_, bl_, ah_, al_, std::false_type{});
+                kb += 2;
+            }
+            if (kb + 2 == nk) {
+                step(kb, nk, ah_, al_, bh_, bl_, std::false_type{});
+                step(kb + 1, nk, bh_, bl_, ah_, al_, std::true_type{});
+            } else {
+                step(kb, nk, ah_, al_, bh_, bl_, std::true_type{});
+            }
+        }
+
+        // ---- epilogue.  Lane (h, j): vertex vbase + j, the frames of its half.  The reference's order: gate -> tangent
+        // projection -> fall-off -> add (src/SOP_FaceDeform.cpp:405-438)
+        auto accf = [&](int k) -> float { return acc[k / 16][k % 16]; };      // indices are compile-time after unrolling
+        const int64_t i = vbase + j;
+        FD_W1STAMP(1)
+        if constexpr (!FAST) nxt = load_raw(gu_next, fastTag);
+        if constexpr (FAST) {
+            // straight-line stores: NLF position stores of two frames each + NFQ fall-off stores of eight frames each.  Every table
+            // entry is requested before the first store (one LDS round trip, not one per store)
+            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+            uint64_t voff = 12ull * (uint64_t)i, fbase = 4ull * (uint64_t)vbase;
+            asm volatile("" : "+v"(voff));                 // (kept as a value: folded into the address it becomes a 64-bit multiply-add per store)
+            uint4 ent[NLF];
+            uint64_t fptr[NFQ];
+#pragma unroll
+            for (int lf = 0; lf < NLF; ++lf) ent[lf] = s_ptab[2 * lf + h];
+#pragma unroll
+            for (int q = 0; q < NFQ; ++q) fptr[q] = s_ftab[q * 64 + lane];
+            __builtin_amdgcn_sched_group_barrier(0x100, NLF + NFQ, 0);
+#pragma unroll
+            for (int lf = 0; lf < NLF; ++lf) {
+                const uint4 e = ent[lf];
+                const uint64_t dst = (((uint64_t)e.y << 32) | (uint64_t)e.x) + voff;
+                const float inv = __uint_as_float(e.z);
+#ifdef FD_TUNING
+                if (p.dbg & 1) { asm volatile("" :: "v"(accf(3 * lf)), "v"(accf(3 * lf + 1)), "v"(accf(3 * lf + 2)), "v"(dst), "v"(inv)); continue; }
+#endif
+                if (lf % 4 == 0) __builtin_nontemporal_store(ones, (f32x4_a16 FD_GLOBAL *)(fptr[lf / 4] + fbase));
+                store_pos3_nt((Pos3 FD_GLOBAL *)dst, __builtin_fmaf(accf(3 * lf), inv, pos[0]), __builtin_fmaf(accf(3 * lf + 1), inv, pos[1]),
+                              __builtin_fmaf(accf(3 * lf + 2), inv, pos[2]));
+            }
+            settle(nxt);
+            ++uc;
+            FD_W1STAMP(2)
+            return;
+        }
+        const bool inb = i < p.N;
+        const int64_t ic = inb ? i : p.N - 1;
+        const bool gated = own_d2 > p.radius2;
+        if (inb && gated) {
+            // B2: a gated vertex keeps its position (and no fd_falloff entry is written)
+            for (int f = h; f < p.nF; f += 2) {
+                float *dstp = s_frames[f].P_out;
+                if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
+            }
+        }
+        float fall = 1.f;
+        float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+        const bool doit = inb && !gated;
+        if (doit) {
+            if (p.dist2 != nullptr || !(p.radius2 != 0.f)) {
+                const float q = fminf(own_d2 / p.radius2, 1.f);
+                fall = powf(1.f - q, p.falloffrate);
+            }
+            if (p.tu) {
+                // project_to_tangents (src/SOP_FaceDeform.hpp:28-41): the two axes depend on the vertex only
+                float u3[3] = {p.tu[3 * ic], p.tu[3 * ic + 1], p.tu[3 * ic + 2]};
+                float v3[3] = {p.tv[3 * ic], p.tv[3 * ic + 1], p.tv[3 * ic + 2]};
+                float n3[3] = {p.nrm[3 * ic], p.nrm[3 * ic + 1], p.nrm[3 * ic + 2]};
+                normalize3(u3[0], u3[1], u3[2]);
+                normalize3(v3[0], v3[1], v3[2]);
+                normalize3(n3[0], n3[1], n3[2]);
+                float gm[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gm[r][c] = u3[r] * u3[c] + v3[r] * v3[c] + n3[r] * n3[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    a1[c] = u3[0] * gm[0][c] + u3[1] * gm[1][c] + u3[2] * gm[2][c];
+                    a2[c] = v3[0] * gm[0][c] + v3[1] * gm[1][c] + v3[2] * gm[2][c];
+                }
+                normalize3(a1[0], a1[1], a1[2]);
+                normalize3(a2[0], a2[1], a2[2]);
+            }
+        }
+#pragma unroll
+        for (int lf = 0; lf < NLF; ++lf) {
+            const int f = 2 * lf + h;                      // this lane's frame of the pair
+            if (f >= p.nF || !doit) continue;
+            const SharedFrame fr = s_frames[f];
+            Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)as_global(fr.P_out) + i;
+            if (!fr.built) {
+                if (fr.P_out != p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
+                continue;
+            }
+            float disp[3] = {accf(3 * lf) * fr.inv_scale, accf(3 * lf + 1) * fr.inv_scale, accf(3 * lf + 2) * fr.inv_scale};       // 2^-k is exact
+            if (p.tu) {
+                const float da1 = disp[0] * a1[0] + disp[1] * a1[1] + disp[2] * a1[2];
+                const float da2 = disp[0] * a2[0] + disp[1] * a2[1] + disp[2] * a2[2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
+            }
+            if (fr.falloff_out) __builtin_nontemporal_store(fall, (float FD_GLOBAL *)as_global(fr.falloff_out) + i);
+            store_pos3_nt(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+        }
+    };
+    bool built_here = true;
+    if (lane < NSLOT) built_here = p.frames[lane].built != 0;
+    const bool fast_ok = p.fast && __all(built_here);
+    const int nfull = (int)(p.N / (kW1Unit * WAVES));       // groups in which every wave's 32 vertices exist
+    int u = next_unit(0);
+    nxt = load_raw(unit_group(u) < ngroups ? unit_global(u) : 0, std::false_type{});
+    settle(nxt);
+    // two loops, not one with a branch (see the two-tile kernel)
+    if (fast_ok) {
+        while (unit_group(u) < nfull) {
+            const int un = next_unit(u);     // taken now: its positions are requested a K loop ahead
+            do_unit(u, un, std::true_type{});
+            u = un;
+        }
+    }
+    while (unit_group(u) < ngroups) {
+        const int un = next_unit(u);
+        do_unit(u, un, std::false_type{});
+        u = un;
+    }
+#ifdef FD_TUNING
+    if (stamp && lane == 0 && wave < 16) {
+        for (int q = 0; q < 3; ++q) p.stamps[wave * 8 + q] = st_acc[q];
+        p.stamps[wave * 8 + 3] = (unsigned long long)uc;
+        p.stamps[wave * 8 + 4] = __builtin_amdgcn_s_memtime() - st_t0;          // shader clock against the 100 MHz reference
+        p.stamps[wave * 8 + 5] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
+#undef FD_W1STAMP
+}
 }  // namespace
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one process may hold contexts on
@@ -1618,10 +2074,24 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         out.P_out[f] = a.P_out[q]; out.falloff_out[f] = a.falloff_out ? a.falloff_out[q] : nullptr;
     }
     slots.M = a.M; slots.nreal = a.nF; slots.mismatch = a.mismatch;
+    // 17..32 frames: one vertex tile per wave, three waves per SIMD (k_deform32_shared_w1); FD_SHARED_W1=0: round 3's two-tile kernel
+#ifdef FD_TUNING
+    // (tuning builds read the switch on every launch: tests/tools/shared_ab_timing.py alternates the two kernels inside one process)
+    const bool w1sel = [] { const char *e = getenv("FD_SHARED_W1"); return e ? atoi(e) != 0 : true; }();
+#else
+    constexpr bool w1sel = true;
+#endif
+    // ... where the whole model is resident in LDS (M = 256 at 32 frames, 384 at 20); models staged in chunks keep the two-tile kernel
+    const bool w1 = wide && w1sel && (kSharedLdsBudget - w1_fixed_lds(wNT)) / ((size_t)1024 + (size_t)wide_w16(wNT) * 16) >= (size_t)nkb;
+#ifdef FD_TUNING
+    const int w1waves = [] { const char *e = getenv("FD_W1_WAVES"); return e && atoi(e) == 8 ? 8 : kW1Waves; }();
+#else
+    constexpr int w1waves = kW1Waves;
+#endif
     if (a.mode != 2) {
         if (wide)
             hipLaunchKernelGGL(k_pack_shared_wide, dim3(nkb, wNT), dim3(256), 0, stream, slots, out, a.nF, wslot, a.Mpad, (uint4 *)a.wtiles,
-                               (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
+                               (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0, w1 ? 1 : 0);
         else
             hipLaunchKernelGGL(k_pack_shared, dim3(nkb, nT), dim3(256), 0, stream, slots, out, nslot, a.Mpad, dense ? 1 : 0, (uint4 *)a.wtiles,
                                (SharedFrame *)a.frames, a.ctiles, gauss ? 1 : 0);
@@ -1652,7 +2122,11 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     // ring); the cause was not found in the time given.  FD_SHARED_DRAW=1 selects it.
     { static const bool draw = [] { const char *e = getenv("FD_SHARED_DRAW"); return e && atoi(e) != 0; }();
       p.ctr = (wide && draw) ? a.ctr : nullptr; }
+#ifdef FD_TUNING
+    { const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
+#else
     { static const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
+#endif
     {
         static const bool no_fast = getenv("FD_SHARED_NO_FAST") != nullptr;       // A/B: general epilogue everywhere
         // no gate, no fall-off input, no tangent frames, fd_falloff wanted for every frame: the straight-line epilogue.
@@ -1664,9 +2138,13 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         for (int f = 0; fast && f < a.nF; ++f) fast = a.falloff_out[f] != nullptr && a.P_out[f] != nullptr && ((uintptr_t)a.falloff_out[f] & 15) == 0;
         p.fast = fast ? 1 : 0;
     }
+#ifdef FD_TUNING
+    { const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+#else
     { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
-#ifdef FD_SHARED_STAMPS_BUILD
-    // diagnostics, compiled in only for profiling builds (-DFD_SHARED_STAMPS_BUILD): in-kernel clock stamps, printed per launch
+#endif
+#if defined(FD_SHARED_STAMPS_BUILD) || defined(FD_TUNING)
+    // diagnostics, compiled in only for profiling builds (-DFD_SHARED_STAMPS_BUILD / -DFD_TUNING): in-kernel clock stamps, printed per launch
     static unsigned long long *d_stamps = nullptr;
     static const bool want_stamps = getenv("FD_SHARED_STAMPS") != nullptr;
     constexpr size_t kStampWords = 64 + (size_t)kNumCU * 8 * 2;
@@ -1677,7 +2155,8 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
 #else
     p.stamps = nullptr;
 #endif
-    const size_t fixed = wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)wNT * 64 * 16 + 512 * sizeof(uint64_t) + 16 + 32 * sizeof(int)
+    const size_t fixed = w1 ? w1_fixed_lds(wNT) :
+                         wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)wNT * 64 * 16 + 512 * sizeof(uint64_t) + 16 + 32 * sizeof(int)
                               : sizeof(SharedFrame) * (size_t)shared_slots(nT, dense) + (size_t)nT * 64 * 16;
     const size_t per_kb = wide ? (size_t)1024 + (size_t)wide_w16(wNT) * 16 : 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
     int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);
@@ -1685,7 +2164,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     if (kchunk > nkb) kchunk = nkb;
     p.kchunk = kchunk;
     const size_t lds = fixed + per_kb * (size_t)kchunk;
-    const int64_t per = wide ? 64 * kWideWaves : kSharedThreads / 64 * 64;          // vertices per workgroup and group
+    const int64_t per = w1 ? kW1Unit * w1waves : wide ? 64 * kWideWaves : kSharedThreads / 64 * 64;          // vertices per workgroup and group
     const int64_t ngroups = (a.N + per - 1) / per;
     // One persistent workgroup per CU (150 KiB of LDS, two 240-register waves per SIMD: nothing else fits beside it).
     // a.max_wgs < 256 (fd_batch_set_eval_cus) leaves the other CUs to whatever runs on other streams -- the builds of the
@@ -1710,7 +2189,26 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL, kWideWaves>), dim3(grid), dim3(64 * kWideWaves), lds, stream, p, (int)ngroups); \
     }
 #define FD_WIDE_KIND(NTW, NSL) { if (gauss) FD_WIDE_CASE(true, NTW, NSL) else FD_WIDE_CASE(false, NTW, NSL) }
-    if (wide) {
+#define FD_W1_CASE(GSS, NTW, NSL, WVS)                                                                               \
+    {                                                                                                                \
+        static LdsAttrOnce once;                                                                                     \
+        hipError_t e = once.ensure((const void *)k_deform32_shared_w1<GSS, NTW, NSL, WVS>, 160 * 1024);              \
+        if (e != hipSuccess) return e;                                                                               \
+        hipLaunchKernelGGL((k_deform32_shared_w1<GSS, NTW, NSL, WVS>), dim3(grid), dim3(64 * WVS), lds, stream, p, (int)ngroups); \
+    }
+#ifdef FD_TUNING
+#define FD_W1_WV(GSS, NTW, NSL) { if (w1waves == 8) FD_W1_CASE(GSS, NTW, NSL, 8) else FD_W1_CASE(GSS, NTW, NSL, kW1Waves) }
+#else
+#define FD_W1_WV(GSS, NTW, NSL) FD_W1_CASE(GSS, NTW, NSL, kW1Waves)
+#endif
+#define FD_W1_KIND(NTW, NSL) { if (gauss) FD_W1_WV(true, NTW, NSL) else FD_W1_WV(false, NTW, NSL) }
+    if (w1) {
+        if (wslot == 20) FD_W1_KIND(2, 20)
+        else if (wslot == 24) FD_W1_KIND(3, 24)
+        else if (wslot == 28) FD_W1_KIND(3, 28)
+        else if (wslot == 32) FD_W1_KIND(3, 32)
+        else return hipErrorInvalidValue;
+    } else if (wide) {
         if (wslot == 20) FD_WIDE_KIND(2, 20)
         else if (wslot == 24) FD_WIDE_KIND(3, 24)
         else if (wslot == 28) FD_WIDE_KIND(3, 28)
@@ -1729,11 +2227,20 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
 #undef FD_SHARED_CASE
 #undef FD_WIDE_CASE
 #undef FD_WIDE_KIND
-#ifdef FD_SHARED_STAMPS_BUILD
+#undef FD_W1_CASE
+#undef FD_W1_WV
+#undef FD_W1_KIND
+#if defined(FD_SHARED_STAMPS_BUILD) || defined(FD_TUNING)
     if (want_stamps && d_stamps) {
         static unsigned long long h[kStampWords];
+        (void)hipStreamSynchronize(stream);         // (a non-blocking stream: the copy below does not wait for it by itself)
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (wide) {
+            if (w1) {
+                fprintf(stderr, "[w1 stamps, shader cycles per wave of workgroup 0: load+poly | K loop | epilogue | units | whole (counts, 100 MHz ticks)]\n");
+                for (int w = 0; w < kW1Waves; ++w)
+                    fprintf(stderr, "   wave %2d: %8llu %8llu %8llu  units %llu  whole %llu counts in %llu ticks = %.3f GHz\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3],
+                            h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 5] ? (double)h[w * 8 + 4] / (double)h[w * 8 + 5] * 0.1 : 0.0);
+            } else if (wide) {
                 // first tick anywhere to every workgroup's first and last tick: who starts late, who finishes late (10 ns units)
                 unsigned long long t0 = ~0ull, t1 = 0;
                 for (unsigned b = 0; b < grid * 8; ++b) if (h[64 + 2 * b]) { t0 = h[64 + 2 * b] < t0 ? h[64 + 2 * b] : t0; t1 = h[65 + 2 * b] > t1 ? h[65 + 2 * b] : t1; }
@@ -1745,8 +2252,8 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
                 }
                 fprintf(stderr, "\n");
             }
-            fprintf(stderr, "[shared stamps, shader cycles per wave of workgroup 0: load+poly | K loop | transposes | per-vertex + frames]\n");
-            for (int w = 0; w < 8; ++w)
+            if (!w1) fprintf(stderr, "[shared stamps, shader cycles per wave of workgroup 0: load+poly | K loop | transposes | per-vertex + frames]\n");
+            for (int w = 0; w < 8 && !w1; ++w)
                 fprintf(stderr, "   wave %d: %8llu %8llu %8llu %8llu   (whole: %llu counts in %llu reference ticks)\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3],
                         h[w * 8 + 4], h[w * 8 + 5]);
         }
@@ -1760,6 +2267,14 @@ size_t shared_wtile_bytes(int Mpad, int nF)
     const int nkb = (Mpad / 16 + 1) / 2, nT = shared_tiles(nF);
     // weight tiles + polynomial tiles + the rest rig's centre tiles (2 nkb) and normalisation (16 B)
     return (size_t)nkb * nT * 128 * 16 + (size_t)nT * 64 * 16 + (size_t)2 * nkb * sizeof(MfmaTileH) + 16;
+}
+// the kernel launch_deform_shared picks (same decisions as above)
+const char *shared_kernel_name(int Mpad, int nF, int kind)
+{
+    if (!shared_wide(nF, kind)) return "k_deform32_tps_shared";
+    const int nkb = (Mpad / 16 + 1) / 2, wNT = wide_tiles(wide_slots(nF));
+    const bool w1 = (kSharedLdsBudget - w1_fixed_lds(wNT)) / ((size_t)1024 + (size_t)wide_w16(wNT) * 16) >= (size_t)nkb;
+    return w1 ? "k_deform32_shared_w1" : "k_deform32_tps_shared_wide";
 }
 size_t shared_frame_bytes(int nF)
 {

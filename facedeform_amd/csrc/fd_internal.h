@@ -252,6 +252,7 @@ struct SharedDeformArgs {
 hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream);
 size_t shared_wtile_bytes(int Mpad, int nF);
 size_t shared_frame_bytes(int nF);
+const char *shared_kernel_name(int Mpad, int nF, int kind);
 // island mask (fd_capture.hip): nearest mesh point per rig point + max_edges breadth-first rings
 hipError_t launch_capture_islands(const float *d_P, int64_t N, const int64_t *d_offsets, const int *d_neighbours,
                                   const float *d_rig, int M, int max_edges, unsigned char *d_mask, hipStream_t stream);

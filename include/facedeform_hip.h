@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 8   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds, fd_report.reserved becomes solver_used */
+#define FD_ABI_VERSION 9   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds, fd_report.reserved becomes solver_used; 9: fd_shared_kernel_name */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -390,6 +390,12 @@ int fd_batch_prepare_shared(fd_batch *batch, void *hip_stream, float *const *d_P
  * 224 of 256 beside three batches of builds).  Per batch, not
  * per process: two nodes cooking side by side choose independently (round 2 read an environment variable once). */
 int fd_batch_set_eval_cus(fd_batch *batch, int n_cus);
+/* Which kernel fd_batch_deform_shared_dev launches for `frames` frames of an M-centre model of `kind` (a name for profiles and
+ * benchmark lines -- the one rocprofv3 prints): "k_deform32_shared_w1" (17..32 frames, the model resident in LDS),
+ * "k_deform32_tps_shared_wide" (17..32 frames, staged in chunks), "k_deform32_tps_shared" (up to 16 frames), or "" where the
+ * shared-rig launch does not apply (other kernels, fewer than 32 centres: the per-frame launch runs).  No reference counterpart:
+ * the reference has one loop (src/SOP_FaceDeform.cpp:404-439). */
+const char *fd_shared_kernel_name(int M, int frames, int kind);
 /* One GROUP of frames of a shot in one call -- what a frame pipeline enqueues per group, in the order it must be enqueued:
  *   fd_batch_wait_consumed(batch, build_stream)            the batch's previous evaluation has its own copy of the models
  *   fd_batch_set_points_dev(batch, d_rest, d_delta, M)      (the SAME rest array for every context: frames of one rig)

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(hip_lib):
 
 
 def test_abi_version(hip_lib):
-    assert hip_lib.fd_abi_version() == 8   # 8: fd_report carries the fp32 estimate, fd_set_eval_precision, fd_fp32_holds; 7: fd_batch_cook_group + the solver names; 6: fd_batch_set_eval_cus; 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres; 4: fd_mesh_capture + the capture inputs of fdsop_geo; 5: fd_batch_wait_consumed
+    assert hip_lib.fd_abi_version() == 9   # 9: fd_shared_kernel_name; 8: fd_report carries the fp32 estimate, fd_set_eval_precision, fd_fp32_holds; 7: fd_batch_cook_group + the solver names; 6: fd_batch_set_eval_cus; 2: fdsop_geo grew the morph-space inputs; 3: solver choice, multilayer kind, fd_model_centres; 4: fd_mesh_capture + the capture inputs of fdsop_geo; 5: fd_batch_wait_consumed
 
 
 def test_struct_layouts_match_header():
