@@ -18,7 +18,7 @@ EXTRA_FLAGS = {"fd_eval.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # v_pk_* again): packed arithmetic under its matrix instructions is what gave launch-to-launch differences
                # (DESIGN.md 4.1c); same speed, and the Gaussian instantiation loses its four spills
                "fd_eval_shared.hip": ["-fno-slp-vectorize"]}
-HEADERS = [os.path.join(CSRC, "fd_internal.h"), os.path.join(CSRC, "fd_pack.h"), os.path.join(CSRC, "fd_eval_common.h"), os.path.join(_ROOT, "include", "facedeform_hip.h")]
+HEADERS = [os.path.join(CSRC, "fd_internal.h"), os.path.join(CSRC, "fd_tuning.h"), os.path.join(CSRC, "fd_pack.h"), os.path.join(CSRC, "fd_eval_common.h"), os.path.join(_ROOT, "include", "facedeform_hip.h")]
 
 
 def hipcc_path() -> str:

@@ -21,6 +21,7 @@ TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
 EVAL_FP32, EVAL_FP64 = 0, 1
 SOLVER_AUTO, SOLVER_LU, SOLVER_ONE_WORKGROUP, SOLVER_REGISTER, SOLVER_CHAIN = 0, 1, 2, 3, 4
 SOLVER_LU_NOPIVOT = 5          # a value of fd_report.solver_used only
+OUTPUT_POSITION, OUTPUT_DISPLACEMENT = 0, 1
 FDSOP_OK, FDSOP_MESSAGE, FDSOP_WARNING, FDSOP_ERROR = range(4)
 
 _f32p = C.POINTER(C.c_float)
@@ -54,7 +55,7 @@ class FdsopGeo(C.Structure):
 
 # every symbol include/facedeform_hip.h declares
 EXPORTS = [
-    "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_eval_precision", "fd_fp32_holds", "fd_set_points",
+    "fd_create", "fd_destroy", "fd_last_error", "fd_abi_version", "fd_set_stream", "fd_set_eval_precision", "fd_set_output", "fd_fp32_holds", "fd_set_points",
     "fd_set_points_dev", "fd_set_deltas", "fd_set_deltas_dev", "fd_set_kernel", "fd_set_term", "fd_build", "fd_build_async",
     "fd_build_result", "fd_deform", "fd_deform_dev", "fd_deform_dev_stream", "fd_get_weights", "fd_model_centres", "fd_model_bytes",
     "fd_export_model", "fd_import_model", "fd_synchronize", "fd_host_alloc", "fd_host_free",
@@ -97,6 +98,7 @@ def load() -> C.CDLL:
     L.fd_abi_version.argtypes = []; L.fd_abi_version.restype = i32
     L.fd_set_stream.argtypes = [vp, vp]; L.fd_set_stream.restype = i32
     L.fd_set_eval_precision.argtypes = [vp, i32]; L.fd_set_eval_precision.restype = i32
+    L.fd_set_output.argtypes = [vp, i32]; L.fd_set_output.restype = i32
     L.fd_fp32_holds.argtypes = [C.POINTER(FdReport), C.c_double]; L.fd_fp32_holds.restype = i32
     L.fd_set_points.argtypes = [vp, vp, vp, i32]; L.fd_set_points.restype = i32
     L.fd_set_points_dev.argtypes = [vp, vp, vp, i32]; L.fd_set_points_dev.restype = i32
@@ -229,6 +231,10 @@ class Engine:
     def set_eval_precision(self, precision: int):
         """EVAL_FP32 / EVAL_FP64 for the evaluations from here on (a built model carries both records)."""
         self._check(self.L.fd_set_eval_precision(self.ctx, precision))
+
+    def set_output(self, what: int):
+        """fd_set_output: OUTPUT_POSITION (P + d f, the reference's write-back) or OUTPUT_DISPLACEMENT (d f alone)."""
+        self._check(self.L.fd_set_output(self.ctx, int(what)))
 
     def fp32_holds(self, report: "FdReport", tol: float = 1e-5) -> bool:
         """fd_fp32_holds: is the fp32 evaluation of the reported model expected to hold tol of every vertex's displacement?"""

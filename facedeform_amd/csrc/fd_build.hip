@@ -1076,7 +1076,7 @@ hipError_t launch_assemble_block(const BuildBuffers &b, hipStream_t stream, int 
 {
     const unsigned nb = (unsigned)b.nbatch;
     // kernels without per-column radii give a block that is symmetric bit for bit: half of it is computed
-    static const bool no_sym = getenv("FD_ASSEMBLE_FULL") != nullptr;
+    static const bool no_sym = tuning_env("FD_ASSEMBLE_FULL") != nullptr;
     const int sym = (!no_sym && b.kind != FD_KERNEL_GAUSSIAN && b.kind != FD_KERNEL_GAUSSIAN_QNN && b.kind != FD_KERNEL_GAUSSIAN_ML) ? 1 : 0;
     if (npad_a <= 512) {
         const unsigned g = (unsigned)(npad_a + 31) / 32;

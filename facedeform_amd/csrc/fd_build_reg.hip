@@ -1074,8 +1074,8 @@ hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const Poi
     // (diagnostics: phase stamps, only outside stream capture -- FD_REG_STAMPS=1)
     static unsigned long long *d_stamps = nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    static const bool stamps_env = getenv("FD_REG_STAMPS") != nullptr;
-    static const bool stamps_late = stamps_env && atoi(getenv("FD_REG_STAMPS")) == 2;      // 2: no read-back per launch (the pipeline stays a pipeline); the last launch's stamps at exit
+    static const bool stamps_env = tuning_env("FD_REG_STAMPS") != nullptr;
+    static const bool stamps_late = stamps_env && atoi(tuning_env("FD_REG_STAMPS")) == 2;      // 2: no read-back per launch (the pipeline stays a pipeline); the last launch's stamps at exit
     const bool want_stamps = stamps_env && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
     if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 96 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 96 * sizeof(unsigned long long)); }
     hipLaunchKernelGGL(k_build_reg, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,

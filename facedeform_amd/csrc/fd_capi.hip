@@ -17,6 +17,7 @@ struct fd_ctx {
     hipStream_t stream_ = nullptr;          // fd_set_stream; nullptr: own_stream
     int eval_precision = FD_EVAL_FP32;
     int eval_variant = 0;
+    int output = FD_OUTPUT_POSITION;    // fd_set_output
     int solver = FD_SOLVER_AUTO;
     int imported_layers = 0;         // a multilayer model that came in through fd_import_model
     const float *rest_src = nullptr; // caller's device array the rest points were last read from in place (fd_batch_set_points_dev), else null
@@ -132,7 +133,6 @@ struct fd_batch {
     // has finished -- with fd_batch_prepare_shared the next pack runs on the build stream, under the previous evaluation.
     struct SharedSet {
         void *d_wtiles = nullptr, *d_frames = nullptr;
-        unsigned *d_ctr = nullptr;       // {next group, finished waves} of the evaluation's device-wide draw (zero between launches)
         size_t cap_wtiles = 0, cap_frames = 0;
         hipEvent_t packed_ev = nullptr;  // behind the pack kernel that filled the set
         hipEvent_t eval_ev = nullptr;    // behind the last evaluation that read it
@@ -273,7 +273,7 @@ static int ensure_solver_capacity(fd_ctx *ctx, int npad)
 // the overlap of a ~25 us panel with a ~30 us update buys.
 static bool make_lookahead(hipStream_t *stream, hipEvent_t events[4])
 {
-    static const bool on = getenv("FD_LOOKAHEAD") != nullptr;
+    static const bool on = tuning_env("FD_LOOKAHEAD") != nullptr;
     if (!on) return false;
     if (*stream) return true;
     if (hipStreamCreateWithFlags(stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); *stream = nullptr; return false; }
@@ -407,7 +407,7 @@ fd_ctx *fd_create(const fd_config *cfg)
         return nullptr;
     }
     ctx->tev0 = ctx->ev0; ctx->tev_mid = ctx->ev_mid; ctx->tev1 = ctx->ev1;
-    ctx->use_graph = getenv("FD_NO_GRAPH") == nullptr;
+    ctx->use_graph = tuning_env("FD_NO_GRAPH") == nullptr;
     return ctx;
 }
 
@@ -584,7 +584,7 @@ static double ctx_lambda(const fd_ctx *ctx)
 // FD_SOLVER=lu keeps every system on the pivoted LU (A/B measurements, tests of that path)
 static bool use_spd(const fd_ctx *ctx)
 {
-    static const char *env = getenv("FD_SOLVER");
+    static const char *env = tuning_env("FD_SOLVER");
     if ((env && strcmp(env, "lu") == 0) || ctx->solver == FD_SOLVER_LU || ctx->prefer_lu) return false;
     if (ctx->kind == FD_KERNEL_GAUSSIAN_ML) return false;          // its own pipeline (launch_build_ml)
     return spd_applicable(ctx->kind, ctx->term, ctx_lambda(ctx), ctx->M);
@@ -594,7 +594,7 @@ static bool use_spd(const fd_ctx *ctx)
 // a build of this rig has asked for the pivoted LU (prefer_lu), nor under FD_SOLVER_LU.
 static bool use_nopivot(const fd_ctx *ctx)
 {
-    static const char *env = getenv("FD_SOLVER");
+    static const char *env = tuning_env("FD_SOLVER");
     if ((env && strcmp(env, "lu") == 0) || ctx->solver == FD_SOLVER_LU || ctx->prefer_lu) return false;
     return ctx->kind == FD_KERNEL_GAUSSIAN_QNN && round_up(ctx->M, 32) <= 1024;
 }
@@ -604,7 +604,7 @@ static bool use_nopivot(const fd_ctx *ctx)
 // (FD_REG_BUILD=0 in the environment: never, for A/B measurements).
 static bool use_reg(const fd_ctx *ctx)
 {
-    static const bool off = [] { const char *e = getenv("FD_REG_BUILD"); return e && atoi(e) == 0; }();
+    static const bool off = [] { const char *e = tuning_env("FD_REG_BUILD"); return e && atoi(e) == 0; }();
     if (off || !(ctx->solver == FD_SOLVER_AUTO || ctx->solver == FD_SOLVER_REGISTER)) return false;
     return reg_applicable(ctx->kind, ctx->term, ctx_lambda(ctx), ctx->M);
 }
@@ -848,6 +848,14 @@ int fd_set_eval_precision(fd_ctx *ctx, int eval_precision)
     return FD_OK;
 }
 
+int fd_set_output(fd_ctx *ctx, int what)
+{
+    if (!ctx) return FD_E_INVALID;
+    if (what != FD_OUTPUT_POSITION && what != FD_OUTPUT_DISPLACEMENT) { set_err(ctx, "fd_set_output: unknown output %d", what); return FD_E_INVALID; }
+    ctx->output = what;
+    return FD_OK;
+}
+
 int fd_build(fd_ctx *ctx, fd_report *report)
 {
     int rc = fd_build_async(ctx);
@@ -928,6 +936,7 @@ int fd_deform_dev_stream(fd_ctx *ctx, void *hip_stream, int64_t N, const float *
     a.model = ctx->d_model;
     a.precision = ctx->eval_precision;
     a.variant = ctx->eval_variant;
+    a.delta_out = ctx->output == FD_OUTPUT_DISPLACEMENT;
     if ((rc = order_after_batch(ctx, launch_stream))) return rc;
     FD_HIP(ctx, launch_deform(a, launch_stream));
     return FD_OK;
@@ -949,7 +958,7 @@ int fd_deform(fd_ctx *ctx, int64_t N, const float *P_in, float *P_out, const flo
     // and writes them in place over the host link -- reads and writes travel in both directions
     // at once and nothing is staged.  Measured at C2: 0.44 ms against 0.62 ms for upload +
     // evaluate + download (chunking those copies over two streams did not overlap them at all).
-    static const bool no_zero_copy = getenv("FD_NO_ZEROCOPY") != nullptr;
+    static const bool no_zero_copy = tuning_env("FD_NO_ZEROCOPY") != nullptr;
     const bool all_pinned = host_is_pinned(P_in) && host_is_pinned(P_out) && (!dist2 || host_is_pinned(dist2)) &&
                             (!falloff_out || host_is_pinned(falloff_out)) &&
                             (!tu || (host_is_pinned(tu) && host_is_pinned(tv) && host_is_pinned(nrm)));
@@ -1184,7 +1193,7 @@ int fd_deform_mesh(fd_ctx *ctx, float *P_out, float *falloff_out, float radius2,
                 *nr = ctx->mesh_has_frames ? ctx->m_nrm : nullptr;
     // page-locked outputs: the kernel reads the mesh from HBM and writes the results straight
     // into the caller's arrays -- the only traffic on the host link is the result itself
-    static const bool no_zero_copy = getenv("FD_NO_ZEROCOPY") != nullptr;
+    static const bool no_zero_copy = tuning_env("FD_NO_ZEROCOPY") != nullptr;
     if (!no_zero_copy && host_is_pinned(P_out) && (!falloff_out || host_is_pinned(falloff_out))) {
         void *zo = nullptr, *zf = nullptr;
         bool ok = hipHostGetDevicePointer(&zo, P_out, 0) == hipSuccess;
@@ -1422,7 +1431,7 @@ fd_batch *fd_batch_create(fd_ctx *const *ctxs, int n)
         fd_batch_destroy(b);
         return nullptr;
     }
-    b->use_graph = getenv("FD_NO_GRAPH") == nullptr;
+    b->use_graph = tuning_env("FD_NO_GRAPH") == nullptr;
     return b;
 }
 
@@ -1447,7 +1456,6 @@ void fd_batch_destroy(fd_batch *b)
     for (auto &st : b->sets) {
         if (st.d_wtiles) (void)hipFree(st.d_wtiles);
         if (st.d_frames) (void)hipFree(st.d_frames);
-        if (st.d_ctr) (void)hipFree(st.d_ctr);
         if (st.packed_ev) (void)hipEventDestroy(st.packed_ev);
         if (st.eval_ev) (void)hipEventDestroy(st.eval_ev);
     }
@@ -1544,8 +1552,8 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     for (int i = 0; i < b->n; ++i)
         if (!use_nopivot(b->ctxs[i])) bb.nopivot = 0;
     if (bb.reg && reg_build_init() != hipSuccess) { (void)hipGetLastError(); bb.reg = 0; }
-    static const bool no_groups = getenv("FD_NO_PANEL_PAIRS") != nullptr;
-    bb.group_panels = (b->n >= 4 && !no_groups && !getenv("FD_LOOKAHEAD")) ? 1 : 0;
+    static const bool no_groups = tuning_env("FD_NO_PANEL_PAIRS") != nullptr;
+    bb.group_panels = (b->n >= 4 && !no_groups && !tuning_env("FD_LOOKAHEAD")) ? 1 : 0;
     if (make_lookahead(&b->lu_stream, b->lu_events)) {
         bb.aux_stream = b->lu_stream;
         for (int q = 0; q < 4; ++q) bb.aux_events[q] = b->lu_events[q];
@@ -1712,6 +1720,8 @@ int fd_batch_deform_dev(fd_batch *b, void *hip_stream, int64_t N, const float *c
         a.model = c->d_model;
         a.precision = c->eval_precision;
         a.variant = c->eval_variant;
+        a.delta_out = c0->output == FD_OUTPUT_DISPLACEMENT;
+        if (c->output != c0->output) { batch_err(b, "fd_batch_deform_dev: context %d has another fd_set_output setting than context 0", i); return FD_E_INVALID; }
     }
     // statuses first: a model the poll had to rebuild (on its context's stream) is then ordered like any other build
     if ((rc = batch_poll(b))) return rc;
@@ -1743,6 +1753,7 @@ static int shared_applies(fd_batch *b, const char *who, float *const *d_P_out, i
                          "same rest array for all), kernel and term; context %d does not", who, i);
             return FD_E_INVALID;
         }
+        if (c->output != c0->output) { batch_err(b, "%s: context %d has another fd_set_output setting than context 0", who, i); return FD_E_INVALID; }
         if (c->eval_precision != FD_EVAL_FP32 || c->eval_variant > 0 || record_layers(c) != 0) fast = false;
     }
     return fast ? 1 : 0;
@@ -1783,12 +1794,6 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
             return FD_E_NOMEM;
         }
         st.cap_wtiles = wb; st.cap_frames = fb;
-    }
-    if (!st.d_ctr) {
-        if (hipMalloc((void **)&st.d_ctr, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(st.d_ctr, 0, 2 * sizeof(unsigned)) != hipSuccess) {
-            (void)hipGetLastError();
-            if (st.d_ctr) { (void)hipFree(st.d_ctr); st.d_ctr = nullptr; }      // (the launch then deals the groups out in fixed shares)
-        }
     }
     // the evaluation that last read this set must be through with it
     if (st.eval_pending && st.eval_ev && hipStreamWaitEvent(stream, st.eval_ev, 0) != hipSuccess) {
@@ -1889,8 +1894,8 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     a.wtiles = st.d_wtiles; a.frames = st.d_frames;
     a.packed_ev = nullptr;
     a.mode = 2;
+    a.delta_out = c0->output == FD_OUTPUT_DISPLACEMENT;
     a.max_wgs = b->eval_cus;
-    a.ctr = st.d_ctr;
     hipError_t e = launch_deform_shared(a, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_shared failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
     if (make_event(&st.eval_ev)) {

@@ -49,6 +49,7 @@ struct EvalParams {
     const float *tu, *tv, *nrm;
     float radius2, falloffrate;
     int Mpad;
+    int delta;             // write the displacement, not P + displacement (fd_set_output); shares Mpad's 8 bytes
     const Rec32 *rec32;
     const Rec64 *rec64;
     const MfmaTile *tiles;
@@ -181,14 +182,17 @@ __device__ __forceinline__ void epilogue_store(const EvalParams &p, int64_t i, c
     // (measured on the shared-rig launch: +6 % on the whole pipeline)
 #ifdef FD_EVAL_TEMPORAL_STORES
     if (p.falloff_out) p.falloff_out[i] = falloff;
-    p.P_out[3 * i] = pos[0] + disp[0] * falloff;
-    p.P_out[3 * i + 1] = pos[1] + disp[1] * falloff;
-    p.P_out[3 * i + 2] = pos[2] + disp[2] * falloff;
+    const float b0 = p.delta ? 0.f : pos[0], b1 = p.delta ? 0.f : pos[1], b2 = p.delta ? 0.f : pos[2];
+    p.P_out[3 * i] = b0 + disp[0] * falloff;
+    p.P_out[3 * i + 1] = b1 + disp[1] * falloff;
+    p.P_out[3 * i + 2] = b2 + disp[2] * falloff;
 #else
     if (p.falloff_out) __builtin_nontemporal_store(falloff, &p.falloff_out[i]);
-    __builtin_nontemporal_store(pos[0] + disp[0] * falloff, &p.P_out[3 * i]);
-    __builtin_nontemporal_store(pos[1] + disp[1] * falloff, &p.P_out[3 * i + 1]);
-    __builtin_nontemporal_store(pos[2] + disp[2] * falloff, &p.P_out[3 * i + 2]);
+    // (FD_OUTPUT_DISPLACEMENT: the addend of :438 alone -- 0 + d f is d f exactly)
+    const float b0 = p.delta ? 0.f : pos[0], b1 = p.delta ? 0.f : pos[1], b2 = p.delta ? 0.f : pos[2];
+    __builtin_nontemporal_store(b0 + disp[0] * falloff, &p.P_out[3 * i]);
+    __builtin_nontemporal_store(b1 + disp[1] * falloff, &p.P_out[3 * i + 1]);
+    __builtin_nontemporal_store(b2 + disp[2] * falloff, &p.P_out[3 * i + 2]);
 #endif
 }
 
@@ -430,7 +434,9 @@ __device__ __forceinline__ void deform32_body(const EvalParams &p)
         if (i >= p.N) continue;
         const float pos[3] = {p.P_in[3 * i], p.P_in[3 * i + 1], p.P_in[3 * i + 2]};
         if (!live[v] || !built) {
-            if (p.P_out != p.P_in) {
+            if (p.delta) {
+                p.P_out[3 * i] = 0.f; p.P_out[3 * i + 1] = 0.f; p.P_out[3 * i + 2] = 0.f;      // a gated or unbuilt vertex does not move
+            } else if (p.P_out != p.P_in) {
                 p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
             }
             continue;
@@ -674,7 +680,9 @@ __device__ __forceinline__ void deform32_tps_mfma_body(const EvalParams &p, int 
             const float pos[3] = {in.pos[q][0], in.pos[q][1], in.pos[q][2]};
             const float d2v = in.d2v[q];
             if (d2v > p.radius2 || !built) {
-                if (p.P_out != p.P_in) {
+                if (p.delta) {
+                    p.P_out[3 * i] = 0.f; p.P_out[3 * i + 1] = 0.f; p.P_out[3 * i + 2] = 0.f;      // a gated or unbuilt vertex does not move
+                } else if (p.P_out != p.P_in) {
                     p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
                 }
                 continue;
@@ -767,7 +775,9 @@ __global__ __launch_bounds__(kBlock) void k_deform64(const EvalParams p)
         if (i >= p.N) continue;
         const float pos[3] = {pxf[v], pyf[v], pzf[v]};
         if (!live[v] || !built) {
-            if (p.P_out != p.P_in) {
+            if (p.delta) {
+                p.P_out[3 * i] = 0.f; p.P_out[3 * i + 1] = 0.f; p.P_out[3 * i + 2] = 0.f;      // a gated or unbuilt vertex does not move
+            } else if (p.P_out != p.P_in) {
                 p.P_out[3 * i] = pos[0]; p.P_out[3 * i + 1] = pos[1]; p.P_out[3 * i + 2] = pos[2];
             }
             continue;
@@ -794,7 +804,7 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
     // thin-plate with at least four centre tiles: d2 on the matrix pipe (variant 200) is the
     // faster kernel (C2 68 vs 80 us, C3 429 vs 540 us); below that its per-group set-up shows
     if (a.variant <= 0 && KIND == FD_KERNEL_THIN_PLATE && a.tiles != nullptr && a.Mpad >= 64) {
-        static const bool bf16_tiles = getenv("FD_MFMA_BF16") != nullptr;
+        static const bool bf16_tiles = tuning_env("FD_MFMA_BF16") != nullptr;
         variant = (a.tiles16 != nullptr && !bf16_tiles) ? 202 : 200;
     }
     if (variant == 202 && a.tiles16 == nullptr) variant = 200;
@@ -806,7 +816,7 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
             // at most ~8 workgroups per CU in the grid; beyond that a workgroup walks several
             // vertex groups and stages a resident model only once
             static const int64_t max_grid = [] {
-                const char *e = getenv("FD_MFMA_GRID");
+                const char *e = tuning_env("FD_MFMA_GRID");
                 const long v = e ? atol(e) : 0;
                 return (int64_t)(v > 0 ? v : 2048);
             }();
@@ -831,8 +841,8 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
         if (a.variant <= 0 && a.layers >= 2 && a.layers % 2 == 0) {
             const int64_t per = (int64_t)kBlock * 4;
             const unsigned grid = (unsigned)((a.N + per - 1) / per);
-            const unsigned share = (grid + kNumCU - 1) / kNumCU;
-            const bool bal = getenv("FD_NO_BALANCE") == nullptr;
+            const unsigned ncu = device_cus(), share = (grid + ncu - 1) / ncu;
+            const bool bal = tuning_env("FD_NO_BALANCE") == nullptr;
             const size_t dyn = (bal && share >= 3 && share <= 8) ? (((160u * 1024u) / share) & ~1023u) : 0;
             if (a.layers % 8 == 0)
                 hipLaunchKernelGGL((k_deform32<KIND, 4, false, f32x2, 8>), dim3(grid), dim3(kBlock), dyn, stream, p);
@@ -848,13 +858,14 @@ hipError_t launch_kind(const DeformArgs &a, const EvalParams &p, hipStream_t str
     // Even placement: with every workgroup resident at once the dispatcher may stack 5 on one
     // CU and 3 on another, and the kernel then lasts as long as the fullest CU.  Reserving
     // 160 KiB / ceil(grid / 256) of LDS per workgroup caps every CU at the even share.
-    const bool balance = getenv("FD_NO_BALANCE") == nullptr;
+    const bool balance = tuning_env("FD_NO_BALANCE") == nullptr;
+    const unsigned ncu = device_cus();
 #define FD_LAUNCH(VV, LDS, LT)                                                                      \
     do {                                                                                             \
         const int64_t per = (int64_t)kBlock * (VV);                                                  \
         const unsigned grid = (unsigned)((a.N + per - 1) / per);                                     \
         size_t dyn = (LDS) ? lds_bytes : 0;                                                          \
-        const unsigned share = (grid + kNumCU - 1) / kNumCU;                                         \
+        const unsigned share = (grid + ncu - 1) / ncu;                                               \
         if (!(LDS) && balance && share >= 3 && share <= 8) dyn = ((160u * 1024u) / share) & ~1023u;  \
         hipLaunchKernelGGL((k_deform32<KIND, VV, LDS, LT>), dim3(grid), dim3(kBlock), dyn, stream, p); \
         return hipGetLastError();                                                                    \
@@ -890,6 +901,7 @@ hipError_t launch_deform(const DeformArgs &a, hipStream_t stream)
     p.Mpad = a.Mpad;
     p.rec32 = a.rec32; p.rec64 = a.rec64; p.tiles = a.tiles; p.tiles16 = a.tiles16;
     p.model = a.model;
+    p.delta = a.delta_out;
     switch (a.kind) {
     case FD_KERNEL_GAUSSIAN:
     case FD_KERNEL_GAUSSIAN_QNN: return launch_kind<FD_KERNEL_GAUSSIAN>(a, p, stream);
@@ -911,6 +923,7 @@ static EvalParams make_params(const DeformArgs &a)
     p.Mpad = a.Mpad;
     p.rec32 = a.rec32; p.rec64 = a.rec64; p.tiles = a.tiles; p.tiles16 = a.tiles16;
     p.model = a.model;
+    p.delta = a.delta_out;
     return p;
 }
 
@@ -926,7 +939,7 @@ hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream)
         same = a[i].precision == FD_EVAL_FP32 && a[i].variant <= 0 && a[i].N == a[0].N && a[i].N > 0 &&
                a[i].Mpad == a[0].Mpad && a[i].kind == a[0].kind &&
                !(a[i].layers >= 2 && a[i].layers % 2 == 0);     // shared-distance multilayer kernel: single launches (same bits as fd_deform)
-    static const bool bf16_tiles = getenv("FD_MFMA_BF16") != nullptr;
+    static const bool bf16_tiles = tuning_env("FD_MFMA_BF16") != nullptr;
     bool mfma = same && a[0].kind == FD_KERNEL_THIN_PLATE && a[0].Mpad >= 64 && !bf16_tiles;
     for (int i = 0; i < n && mfma; ++i) mfma = a[i].tiles16 != nullptr;
     const bool valu = same && !mfma && !(a[0].kind == FD_KERNEL_THIN_PLATE && a[0].Mpad >= 64);

@@ -45,9 +45,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kSharedThreads = 512;
-// waves per workgroup of the 32-row kernel: 8 (two per SIMD, up to 256 registers each) or 12 (three per SIMD, 168 registers:
-// 87 spilled, none inside the K loop -- measured r3: the 32-frame launch alone 189 -> 206 us, bench.py 155-161 k -> 142 k Mverts/s)
-constexpr int kWideWaves = 8;
+constexpr int kWideWaves = 8;      // waves per workgroup of the two-tile 32-row kernel: two per SIMD, up to 256 registers each
 constexpr size_t kSharedLdsBudget = 158 * 1024;   // of 160 KiB (one workgroup per CU)
 
 // Two row layouts of the output tiles (16 rows x 16 vertices each):
@@ -94,9 +92,9 @@ struct SharedParams {
     int dbg;                      // FD_SHARED_DBG (diagnostics, tests/tools/shared_eval_timing.py): 1 = no stores, 2 = no K loop
     int fast;                     // no dist2, no tangent frames, every frame slot in use and built, fd_falloff wanted everywhere:
                                   // full vertex groups take the branch-free epilogue (below)
+    int delta;                    // FD_OUTPUT_DISPLACEMENT: write d f instead of P + d f (general epilogue only: the host clears `fast`)
     int stagger;                  // waves 4..7 start this many x 8192 cycles late (resident model only)
     unsigned long long *stamps;   // diagnostics (FD_SHARED_STAMPS): shader-clock shares of the phases, per wave of workgroup 0
-    unsigned *ctr;                // 32-row kernel: {next 512-vertex group, waves that have finished} -- device-wide, self-resetting (or null)
 };
 
 struct SharedSlots {              // the models of the frames (kernel argument of the pack kernel)
@@ -685,15 +683,17 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
             return;
         }
         if (inb && gated) {
-            // B2: a gated vertex keeps its position (and no fd_falloff entry is written)
+            // B2: a gated vertex keeps its position (and no fd_falloff entry is written); as a displacement: zero
             for (int f = 0; f < p.nF; ++f) {
                 float *dstp = s_frames[f].P_out;
-                if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
+                if (p.delta) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, 0.f, 0.f, 0.f);
+                else if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
             }
         }
         float fall = 1.f;
         float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
         const bool doit = inb && !gated;
+        const float base[3] = {p.delta ? 0.f : pos[0], p.delta ? 0.f : pos[1], p.delta ? 0.f : pos[2]};     // (0 + d f = d f exactly)
         if (doit) {
             if (p.dist2 != nullptr || !(p.radius2 != 0.f)) {
                 const float q = fminf(own_d2 / p.radius2, 1.f);
@@ -737,7 +737,8 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
                 // scalar base (the wave's window of the frame's arrays) + a 32-bit lane offset
                 Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)((char FD_GLOBAL *)(pout + 12ull * (uint64_t)vbase) + off12);
                 if (!built) {
-                    if (pout != (uint64_t)p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
+                    if (p.delta) store_pos3(dstP, 0.f, 0.f, 0.f);
+                else if (pout != (uint64_t)p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
                     continue;
                 }
                 // 2^-k is exact: disp is the sum the matrix pipe accumulated, polynomial included
@@ -757,7 +758,7 @@ void k_deform32_tps_shared(const SharedParams p, int ngroups)
                     for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
                 }
                 if (fout) __builtin_nontemporal_store(fall, (float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4));
-                store_pos3_nt(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+                store_pos3_nt(dstP, base[0] + disp[0] * fall, base[1] + disp[1] * fall, base[2] + disp[2] * fall);
             }
         }
         FD_SSTAMP(3)
@@ -945,12 +946,13 @@ __global__ __launch_bounds__(256) void k_pack_shared_wide(const SharedSlots slot
 //   bit 5  the positions read with the non-temporal hint
 // Instantiated: 49 only (r2 kept eight for A/B runs; the others lost and are gone from the library).
 // NT row tiles of 32 (2 or 3), NSLOT frame slots (20: NT = 2; 24, 28, 32: NT = 3) -- see wide_slots / wide_tiles.
-template <int VAR, bool GAUSS, int NT, int NSLOT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4)))
+template <int VAR, bool GAUSS, int NT, int NSLOT>
+__global__ __launch_bounds__(64 * kWideWaves) __attribute__((amdgpu_waves_per_eu(kWideWaves / 4, kWideWaves / 4)))
 void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
 {
-    // WAVES per workgroup (8 or 12: two or three per SIMD), 64 vertices each per group
-    constexpr int THREADS = 64 * WAVES;
+    // eight waves per workgroup (two per SIMD), 64 vertices each per group.  (Three per SIMD -- 12 waves, 168 registers, 87 spilled --
+    // was measured slower in round 3: 189 -> 206 us; round 4's one-tile kernel below is the three-wave form that pays.)
+    constexpr int WAVES = kWideWaves, THREADS = 64 * WAVES;
     static_assert(NSLOT % 4 == 0 && NSLOT <= kWideSlots && 3 * NSLOT <= 32 * NT, "frame slots in fours, three rows each");
     constexpr int kWideW16 = wide_w16(NT);
     constexpr bool SKEWED = (VAR & 1) != 0;
@@ -968,7 +970,6 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     // fd_falloff pointers of the straight-line epilogue: store q of a group covers frames 4 q .. 4 q + 3, 16 lanes x 16 B each
     uint64_t *s_ftab = reinterpret_cast<uint64_t *>(s_w + (size_t)kWideW16 * p.kchunk);
     unsigned *s_ticket = reinterpret_cast<unsigned *>(s_ftab + 512);      // next 64-vertex unit of this workgroup
-    int *s_ring = reinterpret_cast<int *>(s_ticket + 4);                  // [16] group of round r at r & 15, [16] its tag r + 1 (0: not fetched yet)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1019,13 +1020,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         const uint4 *psrc = p.wtiles + (size_t)p.nkb * kWideW16;
         for (int q = tid; q < NT * 64; q += THREADS) s_poly[q] = psrc[q];
         if (tid == 0) *s_ticket = 0u;
-        if (tid < 32) s_ring[tid] = 0;
         __syncthreads();
-        if (tid < 3 && p.ctr != nullptr) {                 // the groups of rounds 0, 1 and 2 (the waves' first tickets come after a barrier)
-            const unsigned gq = (p.dbg & 8) ? blockIdx.x + (unsigned)tid * gridDim.x : __hip_atomic_fetch_add(p.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_ring[tid] = (int)(gq < (unsigned)ngroups ? gq : (unsigned)ngroups);
-            s_ring[16 + tid] = tid + 1;
-        }
         if (p.fast && tid < NSLOT * 16) s_ftab[tid] = (uint64_t)p.frames[4 * (tid >> 6) + ((tid & 63) >> 4)].falloff_out + 16u * (unsigned)(tid & 15);
     }
     if (resident) {
@@ -1056,84 +1051,25 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
     // workgroup (VAR bit 3 clear): every workgroup then ends with one or two lone units at a lone wave's pace (0.6 of a
     // round) instead of a few workgroups running a whole extra round beside idle CUs (at 192 CUs: 34 of them).
     constexpr bool POOL = (VAR & 8) == 0;
-    // Groups from a DEVICE-WIDE counter (p.ctr, r3): a workgroup draws its next 512-vertex group when the first unit of the
-    // current one is handed out -- a round ahead of need, one atomic per workgroup and round, published to its eight waves
-    // through a small ring in LDS -- so a launch on all 256 CUs takes whatever the builds of a pipeline leave free: a
-    // workgroup that finds its CU held by a build starts late and simply draws fewer groups.  (r2 dealt the groups out in
-    // fixed shares; the best CU budget for the evaluation was then a cliff: 140 k Mverts/s at 192 CUs, 118 k at 200.  Drawing
-    // every 64-vertex UNIT from a device-wide counter had failed earlier: one atomic per unit from 2 048 waves, and the
-    // eight waves of a workgroup no longer write adjacent pieces of a frame at about the same time.)  The last round is
-    // balanced by the draw itself.  In this mode a "unit" below is its global index.
-    const bool gdyn = dynamic && p.ctr != nullptr;
-    const int whole_rounds = gdyn ? 0 : ((dynamic && POOL) ? ngroups / (int)gridDim.x : (ngroups + (int)gridDim.x - 1) / (int)gridDim.x);
+    // (A device-wide draw of the groups -- a workgroup fetching its next group from a global counter three rounds ahead, published to
+    // its waves through a ring in LDS -- was built in round 3 and measured slower, 245 against 170 us per launch: the ring's LDS
+    // word sits between the epilogue's stores and any small wait there waits for the stores in flight.  Removed in round 4;
+    // DESIGN.md 4.1c keeps the account.)
+    const int whole_rounds = (dynamic && POOL) ? ngroups / (int)gridDim.x : (ngroups + (int)gridDim.x - 1) / (int)gridDim.x;
     const int64_t pool0 = (int64_t)whole_rounds * (int64_t)gridDim.x * WAVES, total_units = (int64_t)ngroups * WAVES;
     auto unit_global = [&](int u) -> int64_t {          // the 64-vertex unit behind local ticket u (>= total_units: none)
-        if (gdyn) return (int64_t)u;
         if (u < WAVES * whole_rounds) return ((int64_t)blockIdx.x + (int64_t)(u / WAVES) * (int64_t)gridDim.x) * WAVES + (u % WAVES);
         return pool0 + (int64_t)blockIdx.x + (int64_t)(u - WAVES * whole_rounds) * (int64_t)gridDim.x;
     };
     auto unit_group = [&](int u) -> int64_t { const int64_t g = unit_global(u); return g < total_units ? (g / WAVES) : (int64_t)ngroups; };
-    // The draw is ISSUED when the first unit of round r is handed out, for round r + 3, and its result is PUBLISHED only at the
-    // end of that wave's current group, behind the epilogue's stores, in straight-line code: a wave's vector-memory operations
-    // retire in order, so waiting for the atomic's return where it is issued would wait for every store before it (the
-    // launch lost a third of its speed that way), while behind ~46 younger operations the wait is vmcnt(46) on a value that
-    // came back a K loop ago.  (Three rounds ahead, not one: tickets are taken a unit ahead of the work, the two waves of a SIMD take the issue priority
-    // in turn, and when the drawer was the slow one the fast waves reached the round before its number was out: 170 -> 245 us
-    // per launch with r + 2.  Rounds 0 to 2 are drawn at the kernel's start.  When the groups run out nobody draws any
-    // more: at most eight tickets are handed out after the first empty one, which reach into the next round at the furthest.)
-    // The atomic is an asm string: written with the builtin the compiler waits for its return value where it is ISSUED
-    // (vmcnt(0): every store in flight), whatever distance the first use is at; the string's result is, to the compiler,
-    // ready at once, so the wait is placed by hand in front of the use: none in the straight-line epilogue (see publish_draw),
-    // vmcnt(0) on the rare other paths.  Likewise the ring is read and written
-    // with ds_ instructions in asm strings: volatile accesses and workgroup-scope fences both came out with vmcnt(0).
-    int pend_round = -1;
-    unsigned pend_val = 0u;
     int round_taken = 0;                                 // workgroup-local round of the ticket taken last
-    const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int *)s_ring;
-    auto publish_draw = [&](auto strictTag) {
-        if (pend_round >= 0 && lane == 0) {
-            // (value, then tag: a wave's LDS operations execute in order, and the reader takes them in the opposite order)
-            const int r = pend_round;
-            // (strict: wait for everything.  Otherwise NO wait: the caller has just waited for the next group's positions
-            // (`settle`), loads issued AFTER the atomic -- returns come in order, so its value is there.  A wait of its own
-            // with a small count waits for this group's STORES to be acknowledged: 170 -> 249 us per launch when tried.)
-            if constexpr (decltype(strictTag)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned val = pend_val < (unsigned)ngroups ? pend_val : (unsigned)ngroups;
-            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %2, %3" :: "v"(ring_lds + 4u * (unsigned)(r & 15)), "v"(val),
-                         "v"(ring_lds + 4u * (unsigned)(16 + (r & 15))), "v"((unsigned)(r + 1)) : "memory");
-        }
-        pend_round = -1;
-    };
     auto next_unit = [&](int u) {
         if (!dynamic) return u + WAVES;
         unsigned v = 0;
         if (lane == 0) v = __hip_atomic_fetch_add(s_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int t = (int)__builtin_amdgcn_readfirstlane(v);
         round_taken = t / WAVES;
-        if (!gdyn) return t;
-        const int r = t / WAVES;
-        int grp = 0;
-        if (lane == 0) {
-            unsigned tag, val;
-            for (;;) {
-                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(tag), "=&v"(val)
-                             : "v"(ring_lds + 4u * (unsigned)(16 + (r & 15))), "v"(ring_lds + 4u * (unsigned)(r & 15)) : "memory");
-                if (tag == (unsigned)(r + 1)) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            grp = (int)val;                                 // (read behind its tag: published in the opposite order)
-        }
-        grp = __builtin_amdgcn_readfirstlane(grp);
-        if ((t % WAVES) == 0 && grp < ngroups) {
-            if (pend_round >= 0) publish_draw(std::true_type{});      // (a wave that drew twice before finishing a group: never leave a round unpublished)
-            if (lane == 0) {
-                unsigned one = 1u;
-                if (p.dbg & 8) pend_val = blockIdx.x + (unsigned)(r + 3) * gridDim.x;          // diagnostics: the fixed shares through the ring
-                else asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pend_val) : "v"(p.ctr), "v"(one) : "memory");
-            }
-            pend_round = r + 3;
-        }
-        return grp < ngroups ? grp * WAVES + (t % WAVES) : (int)total_units;
+        return t;
     };
     auto load_raw = [&](int64_t gu, auto fastTag) {
         constexpr bool FAST = decltype(fastTag)::value;
@@ -1163,16 +1099,8 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         const int64_t gu_next = unit_group(un) < ngroups ? unit_global(un) : unit_global(u);       // whose positions to request
         // (the workgroup's OWN round counter decides: the global group numbers a workgroup draws all have the parity of its
         // index -- 256 workgroups draw in step -- and one wave of each SIMD would keep the priority for the whole launch)
-        if constexpr (WAVES == 8) {
-            if (((lround ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        } else {
-            // three waves per SIMD: the priority goes round
-            const int turn = (lround + (wave >> 2)) % 3;
-            if (turn == 0) __builtin_amdgcn_s_setprio(2);
-            else if (turn == 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
+        if (((lround ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
         const GroupRaw cur = nxt;
         // this lane's own vertex in the epilogue is (vt = h, j)
         const float pos[3] = {h ? cur.p[1][0] : cur.p[0][0], h ? cur.p[1][1] : cur.p[0][1], h ? cur.p[1][2] : cur.p[0][2]};
@@ -1482,20 +1410,21 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 }
             }
             settle(nxt);
-            publish_draw(std::false_type{});
             FD_SSTAMP(3)
             return;
         }
         if (inb && gated) {
-            // B2: a gated vertex keeps its position (and no fd_falloff entry is written)
+            // B2: a gated vertex keeps its position (and no fd_falloff entry is written); as a displacement: zero
             for (int f = 0; f < p.nF; ++f) {
                 float *dstp = s_frames[f].P_out;
-                if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
+                if (p.delta) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, 0.f, 0.f, 0.f);
+                else if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
             }
         }
         float fall = 1.f;
         float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
         const bool doit = inb && !gated;
+        const float base[3] = {p.delta ? 0.f : pos[0], p.delta ? 0.f : pos[1], p.delta ? 0.f : pos[2]};     // (0 + d f = d f exactly)
         if (doit) {
             if (p.dist2 != nullptr || !(p.radius2 != 0.f)) {
                 const float q = fminf(own_d2 / p.radius2, 1.f);
@@ -1523,7 +1452,6 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 normalize3(a2[0], a2[1], a2[2]);
             }
         }
-        publish_draw(std::true_type{});
 #pragma unroll
         for (int fs = 0; fs < NSLOT; ++fs) {
             const int f = fs;
@@ -1537,7 +1465,8 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
             if (!doit) continue;
             Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)((char FD_GLOBAL *)(pout + 12ull * (uint64_t)vbase) + off12);
             if (!built) {
-                if (pout != (uint64_t)p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
+                if (p.delta) store_pos3(dstP, 0.f, 0.f, 0.f);
+                else if (pout != (uint64_t)p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
                 continue;
             }
             float disp[3] = {row_of(fs, 0) * inv, row_of(fs, 1) * inv, row_of(fs, 2) * inv};       // 2^-k is exact
@@ -1549,7 +1478,7 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
                 for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
             }
             if (fout) __builtin_nontemporal_store(fall, (float FD_GLOBAL *)((char FD_GLOBAL *)(fout + 4ull * (uint64_t)vbase) + off4));
-            store_pos3_nt(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+            store_pos3_nt(dstP, base[0] + disp[0] * fall, base[1] + disp[1] * fall, base[2] + disp[2] * fall);
         }
         FD_SSTAMP(3)
     };
@@ -1581,22 +1510,12 @@ void k_deform32_tps_shared_wide(const SharedParams p, int ngroups)
         do_group(u, un, ru, std::false_type{});
         u = un; ru = run;
     }
-    publish_draw(std::true_type{});
-    if (gdyn && lane == 0) {
-        // the last wave of the launch to finish puts both counters back to zero for the next launch on this scratch set
-        // (every draw of every workgroup has returned by then: a wave stores its draw in the ring before it goes on)
-        const unsigned done = __hip_atomic_fetch_add(p.ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x * (THREADS / 64) - 1) {
-            __hip_atomic_store(p.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.ctr + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     if (stamp && lane == 0 && wave < 8) {
         for (int q = 0; q < 4; ++q) p.stamps[wave * 8 + q] = st_acc[q];
         p.stamps[wave * 8 + 4] = __builtin_amdgcn_s_memtime() - st_t0;          // shader clock against the 100 MHz reference
         p.stamps[wave * 8 + 5] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
-    if (p.stamps != nullptr && lane == 0 && wave < 8) {      // every wave's first and last tick of the 100 MHz clock: the spread over the workgroups
+    if (p.stamps != nullptr && lane == 0 && wave < 8 && blockIdx.x < kMaxCUs) {      // every wave's first and last tick of the 100 MHz clock: the spread over the workgroups
         p.stamps[64 + ((size_t)blockIdx.x * 8 + wave) * 2] = st_r0;
         p.stamps[64 + ((size_t)blockIdx.x * 8 + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
     }
@@ -1945,15 +1864,17 @@ void k_deform32_shared_w1(const SharedParams p, int ngroups)
         const int64_t ic = inb ? i : p.N - 1;
         const bool gated = own_d2 > p.radius2;
         if (inb && gated) {
-            // B2: a gated vertex keeps its position (and no fd_falloff entry is written)
+            // B2: a gated vertex keeps its position (and no fd_falloff entry is written); as a displacement: zero
             for (int f = h; f < p.nF; f += 2) {
                 float *dstp = s_frames[f].P_out;
-                if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
+                if (p.delta) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, 0.f, 0.f, 0.f);
+                else if (dstp != p.P_in) store_pos3((Pos3 FD_GLOBAL *)as_global(dstp) + i, pos[0], pos[1], pos[2]);
             }
         }
         float fall = 1.f;
         float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
         const bool doit = inb && !gated;
+        const float base[3] = {p.delta ? 0.f : pos[0], p.delta ? 0.f : pos[1], p.delta ? 0.f : pos[2]};     // (0 + d f = d f exactly)
         if (doit) {
             if (p.dist2 != nullptr || !(p.radius2 != 0.f)) {
                 const float q = fminf(own_d2 / p.radius2, 1.f);
@@ -1988,7 +1909,8 @@ void k_deform32_shared_w1(const SharedParams p, int ngroups)
             const SharedFrame fr = s_frames[f];
             Pos3 FD_GLOBAL *dstP = (Pos3 FD_GLOBAL *)as_global(fr.P_out) + i;
             if (!fr.built) {
-                if (fr.P_out != p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
+                if (p.delta) store_pos3(dstP, 0.f, 0.f, 0.f);
+                else if (fr.P_out != p.P_in) store_pos3(dstP, pos[0], pos[1], pos[2]);
                 continue;
             }
             float disp[3] = {accf(3 * lf) * fr.inv_scale, accf(3 * lf + 1) * fr.inv_scale, accf(3 * lf + 2) * fr.inv_scale};       // 2^-k is exact
@@ -1999,7 +1921,7 @@ void k_deform32_shared_w1(const SharedParams p, int ngroups)
                 for (int c = 0; c < 3; ++c) disp[c] = a1[c] * da1 + a2[c] * da2;
             }
             if (fr.falloff_out) __builtin_nontemporal_store(fall, (float FD_GLOBAL *)as_global(fr.falloff_out) + i);
-            store_pos3_nt(dstP, pos[0] + disp[0] * fall, pos[1] + disp[1] * fall, pos[2] + disp[2] * fall);
+            store_pos3_nt(dstP, base[0] + disp[0] * fall, base[1] + disp[1] * fall, base[2] + disp[2] * fall);
         }
     };
     bool built_here = true;
@@ -2077,14 +1999,14 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     // 17..32 frames: one vertex tile per wave, three waves per SIMD (k_deform32_shared_w1); FD_SHARED_W1=0: round 3's two-tile kernel
 #ifdef FD_TUNING
     // (tuning builds read the switch on every launch: tests/tools/shared_ab_timing.py alternates the two kernels inside one process)
-    const bool w1sel = [] { const char *e = getenv("FD_SHARED_W1"); return e ? atoi(e) != 0 : true; }();
+    const bool w1sel = [] { const char *e = tuning_env("FD_SHARED_W1"); return e ? atoi(e) != 0 : true; }();
 #else
     constexpr bool w1sel = true;
 #endif
     // ... where the whole model is resident in LDS (M = 256 at 32 frames, 384 at 20); models staged in chunks keep the two-tile kernel
     const bool w1 = wide && w1sel && (kSharedLdsBudget - w1_fixed_lds(wNT)) / ((size_t)1024 + (size_t)wide_w16(wNT) * 16) >= (size_t)nkb;
 #ifdef FD_TUNING
-    const int w1waves = [] { const char *e = getenv("FD_W1_WAVES"); return e && atoi(e) == 8 ? 8 : kW1Waves; }();
+    const int w1waves = [] { const char *e = tuning_env("FD_W1_WAVES"); return e && atoi(e) == 8 ? 8 : kW1Waves; }();
 #else
     constexpr int w1waves = kW1Waves;
 #endif
@@ -2103,7 +2025,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     }
     SharedParams p{};
     p.N = a.N; p.P_in = a.P_in; p.dist2 = a.dist2; p.tu = a.tu; p.tv = a.tv; p.nrm = a.nrm;
-    p.radius2 = a.radius2; p.falloffrate = a.falloffrate;
+    p.radius2 = a.radius2; p.falloffrate = a.falloffrate; p.delta = a.delta_out;
     p.ntiles = ntiles; p.nkb = nkb; p.nF = a.nF; p.nT = nT;
     if (wide) {
         const uint4 *copy = (const uint4 *)a.wtiles + (size_t)nkb * wide_w16(wNT) + (size_t)wNT * 64;
@@ -2115,48 +2037,41 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
         p.norm = reinterpret_cast<const float *>(copy + (size_t)2 * nkb * (sizeof(MfmaTileH) / 16));
     }
     p.wtiles = (const uint4 *)a.wtiles; p.frames = (const SharedFrame *)a.frames;
-    // The device-wide draw of the groups (k_deform32_tps_shared_wide, `gdyn`) is built and tested but NOT the default: it
-    // flattens the CU-budget cliff of a pipeline (117-123 k Mverts/s for any budget from 192 to 256 CUs) at a lower level than
-    // the fixed shares reach at their best budget (150 k at 224), because the launch itself is slower with it -- 245 against
-    // 170 us alone at C2 x 32 frames, with or without the atomic (FD_SHARED_DBG=8 deals the fixed shares out through the same
-    // ring); the cause was not found in the time given.  FD_SHARED_DRAW=1 selects it.
-    { static const bool draw = [] { const char *e = getenv("FD_SHARED_DRAW"); return e && atoi(e) != 0; }();
-      p.ctr = (wide && draw) ? a.ctr : nullptr; }
 #ifdef FD_TUNING
-    { const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
+    { const char *e = tuning_env("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
 #else
-    { static const char *e = getenv("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
+    { static const char *e = tuning_env("FD_SHARED_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
     {
-        static const bool no_fast = getenv("FD_SHARED_NO_FAST") != nullptr;       // A/B: general epilogue everywhere
+        static const bool no_fast = tuning_env("FD_SHARED_NO_FAST") != nullptr;       // A/B: general epilogue everywhere
         // no gate, no fall-off input, no tangent frames, fd_falloff wanted for every frame: the straight-line epilogue.
         // Any frame count: the slots a launch runs beyond nF repeat the last frame (above).
         // (repeated slots cost stores: worth it up to a quarter of the frames -- 17..32 frames always qualify)
-        bool fast = !no_fast && (p.dbg & 1) == 0 && a.dist2 == nullptr && a.tu == nullptr && a.radius2 > 0.f && a.falloff_out != nullptr &&
+        bool fast = !no_fast && !a.delta_out && (p.dbg & 1) == 0 && a.dist2 == nullptr && a.tu == nullptr && a.radius2 > 0.f && a.falloff_out != nullptr &&
                     a.N < ((int64_t)1 << 28) && 4 * (nslot - a.nF) <= a.nF;
         // (the straight-line epilogues store fd_falloff 8 and 16 bytes at a time: 16-byte aligned arrays, or the general path)
         for (int f = 0; fast && f < a.nF; ++f) fast = a.falloff_out[f] != nullptr && a.P_out[f] != nullptr && ((uintptr_t)a.falloff_out[f] & 15) == 0;
         p.fast = fast ? 1 : 0;
     }
 #ifdef FD_TUNING
-    { const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+    { const char *e = tuning_env("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
 #else
-    { static const char *e = getenv("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+    { static const char *e = tuning_env("FD_SHARED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
 #endif
 #if defined(FD_SHARED_STAMPS_BUILD) || defined(FD_TUNING)
     // diagnostics, compiled in only for profiling builds (-DFD_SHARED_STAMPS_BUILD / -DFD_TUNING): in-kernel clock stamps, printed per launch
     static unsigned long long *d_stamps = nullptr;
-    static const bool want_stamps = getenv("FD_SHARED_STAMPS") != nullptr;
-    constexpr size_t kStampWords = 64 + (size_t)kNumCU * 8 * 2;
+    static const bool want_stamps = tuning_env("FD_SHARED_STAMPS") != nullptr;
+    constexpr size_t kStampWords = 64 + (size_t)kMaxCUs * 8 * 2;
     if (want_stamps && !d_stamps) (void)hipMalloc((void **)&d_stamps, kStampWords * sizeof(unsigned long long));
     if (want_stamps && d_stamps) (void)hipMemsetAsync(d_stamps, 0, kStampWords * sizeof(unsigned long long), stream);
     p.stamps = want_stamps ? d_stamps : nullptr;
-    { static const bool e = getenv("FD_SHARED_STAMPS_GENERAL") != nullptr; if (want_stamps && e) p.fast = 0; }
+    { static const bool e = tuning_env("FD_SHARED_STAMPS_GENERAL") != nullptr; if (want_stamps && e) p.fast = 0; }
 #else
     p.stamps = nullptr;
 #endif
     const size_t fixed = w1 ? w1_fixed_lds(wNT) :
-                         wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)wNT * 64 * 16 + 512 * sizeof(uint64_t) + 16 + 32 * sizeof(int)
+                         wide ? sizeof(SharedFrame) * (size_t)kWideSlots + (size_t)wNT * 64 * 16 + 512 * sizeof(uint64_t) + 16
                               : sizeof(SharedFrame) * (size_t)shared_slots(nT, dense) + (size_t)nT * 64 * 16;
     const size_t per_kb = wide ? (size_t)1024 + (size_t)wide_w16(wNT) * 16 : 2 * sizeof(MfmaTileH) + (size_t)nT * 128 * 16;
     int kchunk = (int)((kSharedLdsBudget - fixed) / per_kb);
@@ -2171,7 +2086,7 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
     // next frames in a pipeline (bench.py).
     // More than 256: the workgroups beyond the resident ones go out as CUs come free -- shorter shares, so a workgroup that had to
     // wait for a CU a build holds delays the launch by less.
-    const int64_t max_wgs = a.max_wgs > 0 ? (a.max_wgs < 4096 ? a.max_wgs : 4096) : kNumCU;
+    const int64_t max_wgs = a.max_wgs > 0 ? (a.max_wgs < 4096 ? a.max_wgs : 4096) : (int64_t)device_cus();
     const unsigned grid = (unsigned)(ngroups < max_wgs ? ngroups : max_wgs);
 #define FD_SHARED_CASE(NTV, DNS, GSS)                                                                                \
     {                                                                                                                \
@@ -2184,9 +2099,9 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
 #define FD_WIDE_CASE(GSS, NTW, NSL)                                                                                  \
     {                                                                                                                \
         static LdsAttrOnce once;                                                                                     \
-        hipError_t e = once.ensure((const void *)k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL, kWideWaves>, 160 * 1024); \
+        hipError_t e = once.ensure((const void *)k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL>, 160 * 1024); \
         if (e != hipSuccess) return e;                                                                               \
-        hipLaunchKernelGGL((k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL, kWideWaves>), dim3(grid), dim3(64 * kWideWaves), lds, stream, p, (int)ngroups); \
+        hipLaunchKernelGGL((k_deform32_tps_shared_wide<kWideDefaultVar, GSS, NTW, NSL>), dim3(grid), dim3(64 * kWideWaves), lds, stream, p, (int)ngroups); \
     }
 #define FD_WIDE_KIND(NTW, NSL) { if (gauss) FD_WIDE_CASE(true, NTW, NSL) else FD_WIDE_CASE(false, NTW, NSL) }
 #define FD_W1_CASE(GSS, NTW, NSL, WVS)                                                                               \
@@ -2243,9 +2158,10 @@ hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream)
             } else if (wide) {
                 // first tick anywhere to every workgroup's first and last tick: who starts late, who finishes late (10 ns units)
                 unsigned long long t0 = ~0ull, t1 = 0;
-                for (unsigned b = 0; b < grid * 8; ++b) if (h[64 + 2 * b]) { t0 = h[64 + 2 * b] < t0 ? h[64 + 2 * b] : t0; t1 = h[65 + 2 * b] > t1 ? h[65 + 2 * b] : t1; }
+                const unsigned sgrid = grid < kMaxCUs ? grid : kMaxCUs;
+                for (unsigned b = 0; b < sgrid * 8; ++b) if (h[64 + 2 * b]) { t0 = h[64 + 2 * b] < t0 ? h[64 + 2 * b] : t0; t1 = h[65 + 2 * b] > t1 ? h[65 + 2 * b] : t1; }
                 fprintf(stderr, "[shared stamps: %u workgroups, first entry to last exit %.1f us; per workgroup (entry, exit) in us after the first entry:]\n", grid, (t1 - t0) * 0.01);
-                for (unsigned b = 0; b < grid; ++b) {
+                for (unsigned b = 0; b < sgrid; ++b) {
                     unsigned long long a = ~0ull, z = 0;
                     for (int w = 0; w < 8; ++w) if (h[64 + 2 * (b * 8 + w)]) { a = h[64 + 2 * (b * 8 + w)] < a ? h[64 + 2 * (b * 8 + w)] : a; z = h[65 + 2 * (b * 8 + w)] > z ? h[65 + 2 * (b * 8 + w)] : z; }
                     fprintf(stderr, "%s%5.1f-%5.1f", b % 8 ? "  " : "\n   ", (a - t0) * 0.01, (z - t0) * 0.01);

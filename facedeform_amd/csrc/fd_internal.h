@@ -7,6 +7,8 @@
 
 #include "../../include/facedeform_hip.h"
 
+#include "fd_tuning.h"
+
 namespace fd {
 
 // A pointer fetched from a table in memory is a generic pointer to the compiler: every access
@@ -217,6 +219,7 @@ struct DeformArgs {
     const DevModel *model;
     int precision, variant;
     int layers;            // multilayer Gaussian model: records are centre-major, `layers` per centre; 0 otherwise
+    int delta_out;         // FD_OUTPUT_DISPLACEMENT: P_out receives the displacement (the addend of :438), not P + displacement
 };
 hipError_t launch_deform(const DeformArgs &a, hipStream_t stream);
 hipError_t launch_deform_batch(const DeformArgs *a, int n, hipStream_t stream);
@@ -240,14 +243,13 @@ struct SharedDeformArgs {
                                           // launch reads nothing of the contexts -- their next build may start
     int mode;                             // 0: pack kernel + evaluation; 1: pack kernel only (fd_batch_prepare_shared);
                                           // 2: evaluation only, on a scratch set packed earlier
+    int delta_out;                        // FD_OUTPUT_DISPLACEMENT (see DeformArgs)
     int max_wgs;                          // CUs the launch may occupy (one persistent workgroup each); 0 or >= 256: all of them
     // pack kernel only: every model's centres (fp64, M x 3) are compared with model 0's -- "one rest rig" checked by content --
     // and 1 + the index of a model that differs is posted to *mismatch (device address of a page-locked word; may be null)
     const double *centres[kMaxBatch];
     int M;
     int *mismatch;
-    unsigned *ctr;                        // two zeroed device words per scratch set: the 32-row kernel draws its groups from a
-                                          // device-wide counter and puts them back to zero itself (null: fixed shares)
 };
 hipError_t launch_deform_shared(const SharedDeformArgs &a, hipStream_t stream);
 size_t shared_wtile_bytes(int Mpad, int nF);

@@ -23,6 +23,7 @@
 #include <new>
 
 #include "facedeform_hip.h"
+#include "fd_tuning.h"
 
 namespace {
 
@@ -745,7 +746,7 @@ static int morph_factor(fd_morph *m)
 {
     // FD_MORPH_UNBLOCKED: the column-by-column form (A/B measurements; also what very wide shape sets take,
     // whose per-workgroup sums would not fit the LDS of the block-reflector pass)
-    static const bool unblocked = getenv("FD_MORPH_UNBLOCKED") != nullptr;
+    static const bool unblocked = tuning_env("FD_MORPH_UNBLOCKED") != nullptr;
     if (!unblocked && m->S <= 256) return morph_factor_blocked(m);
     const int64_t rows = 3 * m->N;
     const int S = m->S;

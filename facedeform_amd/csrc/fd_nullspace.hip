@@ -1486,7 +1486,7 @@ __global__ void k_qnn_finish(const BatchSlot *tab, int M, int T, int npad, int f
 void launch_factor(const BuildBuffers &b, hipStream_t stream, int npc, int n1, int rhs_only)
 {
     const unsigned nb = (unsigned)b.nbatch;
-    static const bool unfused = getenv("FD_CHOL_UNFUSED") != nullptr;      // A/B: two launches per step
+    static const bool unfused = tuning_env("FD_CHOL_UNFUSED") != nullptr;      // A/B: two launches per step
     if (!rhs_only && unfused) hipLaunchKernelGGL(k_chol_first, dim3(1, 1, nb), dim3(256), 0, stream, b.d_slots, b.M, b.lda, n1);
     if (!rhs_only && !unfused) {
         // block 0: the step kernel with no panel before it (factorise, solve the rows below, nothing else)
@@ -1585,7 +1585,7 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
     // 32 frames on most of the device while the next 32 models are solved it is the other way round: 32 workgroups
     // on 32 CUs for 0.65 ms disturb the evaluation less than 18 launches with grids all over the device (bench.py:
     // 120-122k against 112k Mverts/s).
-    static const bool use_small = [] { const char *e = getenv("FD_SMALL_BUILD"); return e && atoi(e) == 1; }();
+    static const bool use_small = [] { const char *e = tuning_env("FD_SMALL_BUILD"); return e && atoi(e) == 1; }();
     if (npc <= kSmallMaxNpc && (use_small || b.small)) {
         // one workgroup per model does everything after the assembly
         hipError_t e0 = launch_assemble_block(b, stream, npa);
@@ -1593,7 +1593,7 @@ hipError_t launch_build_spd(const BuildBuffers &b, hipStream_t stream, hipEvent_
         if (ev_mid) (void)hipEventRecord(ev_mid, stream);
         const size_t lds = kStepPanelLds > sizeof(double) * 3 * (size_t)npc ? kStepPanelLds : sizeof(double) * 3 * (size_t)npc;
         static unsigned long long *d_stamps = nullptr;
-        static const bool want_stamps = getenv("FD_SMALL_STAMPS") != nullptr;
+        static const bool want_stamps = tuning_env("FD_SMALL_STAMPS") != nullptr;
         if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 32 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 32 * sizeof(unsigned long long)); }
         hipLaunchKernelGGL(k_build_small, dim3(1, 1, nb), dim3(256), lds, stream, b.d_slots, M, T, b.npad, b.lda, b.kind, b.Mpad,
                            want_stamps ? d_stamps : nullptr);

@@ -65,6 +65,14 @@ def deformed_rig(rest: np.ndarray, frame: int = 0) -> np.ndarray:
     return (rest + smooth_deltas(rest, frame)).astype(np.float32)
 
 
+def rig_deltas(rest: np.ndarray, frame: int = 0) -> np.ndarray:
+    """The control table's delta as the reference forms it from its two rig inputs (src/SOP_FaceDeform.cpp:278): the fp32
+    difference deformed_rig - rest.  NOT smooth_deltas(rest, frame) bit for bit -- the deformed rig's positions are rounded to
+    fp32 first -- so a test that hands the engine deltas and the oracle the two rigs uses this on both sides."""
+    rest = np.asarray(rest, np.float32)
+    return (deformed_rig(rest, frame) - rest).astype(np.float32)
+
+
 def tangent_frames(mesh: np.ndarray, seed: int = 7):
     """Non-unit, non-orthogonal (tangentu, tangentv, N) per vertex, fp32 -- exercises
     the in-place normalisation and the non-orthogonal axes of project_to_tangents."""

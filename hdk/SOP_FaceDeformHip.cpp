@@ -1,9 +1,11 @@
 // SOP_FaceDeformHip.cpp -- Houdini-side wrapper: the `facedeform` SOP with its RBF hot path
 // running in libfacedeform_hip.so (MI355X) instead of ALGLIB.
 //
-// NOT compiled by this repository's build: it needs the Houdini HDK ($HT), which is not
-// available in the build container.  It is the reference-side binding INTEGRATION.md refers
-// to.  It keeps the outer plugin contract of the reference (operator name/label/inputs:
+// Not part of libfacedeform_hip.so: a plugin needs the Houdini HDK ($HT), which the build container does not have.  What the
+// repository does with it: tests/test_hdk_wrapper_compiles.py compiles it (g++ -fsyntax-only -Wall -Wextra) and
+// tests/test_gpu_hdk_wrapper.py cooks a paged detail through it on the GPU, both against tests/hdk_mock/ -- a mock of exactly the
+// HDK types this file touches; against the real HDK it has never been built.  It is the reference-side binding INTEGRATION.md
+// refers to.  It keeps the outer plugin contract of the reference (operator name/label/inputs:
 // reference src/SOP_FaceDeform.cpp:35-46; parm tokens and defaults: :99-137) and hands the cook
 // to fdsop_cook(), the HDK-free mirror of cookMySop in facedeform_amd/csrc/fd_sop_host.cpp.
 //
@@ -41,19 +43,38 @@ namespace fdhip {
 
 // ---- parm surface: driven by the engine's own table so the two cannot drift -------------
 // (token, label, kind) -- kinds: s string, o ordinal, f float, l log-float, i int, t toggle, 2 float2
-struct ParmRow { const char *token, *label; char kind; float def0, def1; };
+struct ParmRow { const char *token, *label; char kind; float def0, def1; const char *help; };
+// The help texts of the reference's templates (src/SOP_FaceDeform.cpp:67-94, attached at :121-137), as the user of the node reads
+// them in the parameter pane: part of the parm surface like the tokens and labels.  (Two of them name ALGLIB, whose models the
+// engine restates densely: DESIGN.md 1.)
+static const char *const kModelHelp = "QNN and Multilayer are different algorithms to perform RBF interpolation in ALGLIB. "
+                                      "Multilayer is more robust and thus more expensive.";
+static const char *const kTermHelp = "By appending small linear or constant term to RBF system one can stabalize it and help to solve smooth solution.";
+static const char *const kRadiusHelp = "Radius controls not only RBF solution (how far to reach for a scattered data), "
+                                       "but also radius of deformation applied to geometry.";
+static const char *const kMaxEdgesHelp = "Number of edges deformation affects geometry. This is applied before radius.";
+static const char *const kTangentHelp = "Project deformation into tangential space of a rest geometry. This helps to remove extreme deformations. ";
+static const char *const kMorphHelp = "Projects deformation into subspace defined by blendshapes of a base mesh. They should be connected after second "
+                                      "and third input and match rest mesh topology (unlike 2d and 3rd input which are typically sparser than first "
+                                      "input (rest pose geo)).";
+static const char *const kWeightRangeHelp = "Clamps total blendshape weights, so that deformation will be constrained strictly to blends' poses.";
+static const char *const kFalloffHelp = "This is exponent of distance ratio (distance / radius) with which displacement falls off.";
 static const ParmRow kRows[] = {
-    {"model", "Model", 'o', 0, 0},          {"term", "RBF Term", 'o', 0, 0},
-    {"qcoef", "Q (Smoothness)", 'f', 1, 0}, {"zcoef", "Z (Deviation)", 'f', 5, 0},
-    {"radius", "Radius", 'l', 1, 0},        {"maxedges", "Max edges", 'i', 4, 0},
-    {"layers", "Layers", 'i', 4, 0},        {"lambda", "Lambda", 'f', 0.1f, 0},
-    {"tangent", "Tangent space", 't', 0, 0}, {"morphspace", "Blendshapes subspace", 't', 0, 0},
-    {"doclampweight", "Clamp weights", 't', 0, 0}, {"weightrange", "Range", '2', 0, 1},
-    {"dofalloff", "Falloff", 't', 0, 0},    {"falloffradius", "Falloff radius", 'l', 1, 0},
-    {"falloffrate", "Falloff rate (exponent)", 'f', 1, 0},
+    {"model", "Model", 'o', 0, 0, kModelHelp},          {"term", "RBF Term", 'o', 0, 0, kTermHelp},
+    {"qcoef", "Q (Smoothness)", 'f', 1, 0, nullptr},    {"zcoef", "Z (Deviation)", 'f', 5, 0, nullptr},
+    {"radius", "Radius", 'l', 1, 0, kRadiusHelp},       {"maxedges", "Max edges", 'i', 4, 0, kMaxEdgesHelp},
+    {"layers", "Layers", 'i', 4, 0, nullptr},           {"lambda", "Lambda", 'f', 0.1f, 0, nullptr},
+    {"tangent", "Tangent space", 't', 0, 0, kTangentHelp}, {"morphspace", "Blendshapes subspace", 't', 0, 0, kMorphHelp},
+    {"doclampweight", "Clamp weights", 't', 0, 0, kWeightRangeHelp}, {"weightrange", "Range", '2', 0, 1, kWeightRangeHelp},
+    {"dofalloff", "Falloff", 't', 0, 0, nullptr},       {"falloffradius", "Falloff radius", 'l', 1, 0, kRadiusHelp},
+    {"falloffrate", "Falloff rate (exponent)", 'f', 1, 0, kFalloffHelp},
     // additions (SURVEY.md 8b allows new parms; nothing above is renamed or removed)
-    {"kernel", "Kernel", 'o', 0, 0},        {"smoothing", "Smoothing", 'f', 0, 0},
-    {"precision", "Evaluation precision", 'o', 0, 0}, {"device", "GPU device", 'i', -1, 0},
+    {"kernel", "Kernel", 'o', 0, 0, "Radial kernel of the dense system. Gaussian follows the Model parameter (QNN radii or multilayer); thin plate, "
+                                    "biharmonic and cubic are solved with the RBF Term's polynomial."},
+    {"smoothing", "Smoothing", 'f', 0, 0, "Added to the diagonal of the kernel matrix (0 interpolates the control points exactly)."},
+    {"precision", "Evaluation precision", 'o', 0, 0, "fp32 evaluation is ~80x faster; the default falls back to fp64 for a rig whose displacements fp32 cannot "
+                                                     "hold to 1e-5 (a warning names the two numbers)."},
+    {"device", "GPU device", 'i', -1, 0, "HIP device ordinal (-1: the process's current device)."},
 };
 static constexpr int kNumRows = sizeof(kRows) / sizeof(kRows[0]);
 
@@ -89,14 +110,15 @@ static PRM_Template *buildTemplates()
         case 'o': {
             PRM_ChoiceList *menu = tok == "model" ? &sModelMenu : tok == "term" ? &sTermMenu
                                    : tok == "kernel" ? &sKernelMenu : &sPrecisionMenu;
-            sTemplates.emplace_back(PRM_ORD, 1, name, def, menu);
+            sTemplates.emplace_back(PRM_ORD, 1, name, def, menu, nullptr, nullptr, nullptr, 0, r.help);
             break;
         }
-        case 'f': sTemplates.emplace_back(PRM_FLT_J, 1, name, def, nullptr, tok == "falloffrate" ? &sFalloffRange : nullptr); break;
-        case 'l': sTemplates.emplace_back(PRM_FLT_LOG, 1, name, def, nullptr, &sRadiusRange); break;
-        case 'i': sTemplates.emplace_back(PRM_INT_J, 1, name, def); break;
-        case 't': sTemplates.emplace_back(PRM_TOGGLE, 1, name, def); break;
-        case '2': sTemplates.emplace_back(PRM_FLT_J, 2, name, def); break;
+        // (type, size, name, defaults, menu, range, callback, spare data, parm group, help text -- the reference's argument order, :121-137)
+        case 'f': sTemplates.emplace_back(PRM_FLT_J, 1, name, def, nullptr, tok == "falloffrate" ? &sFalloffRange : nullptr, nullptr, nullptr, 0, r.help); break;
+        case 'l': sTemplates.emplace_back(PRM_FLT_LOG, 1, name, def, nullptr, &sRadiusRange, nullptr, nullptr, 0, r.help); break;
+        case 'i': sTemplates.emplace_back(PRM_INT_J, 1, name, def, nullptr, nullptr, nullptr, nullptr, 0, r.help); break;
+        case 't': sTemplates.emplace_back(PRM_TOGGLE, 1, name, def, nullptr, nullptr, nullptr, nullptr, 0, r.help); break;
+        case '2': sTemplates.emplace_back(PRM_FLT_J, 2, name, def, nullptr, nullptr, nullptr, nullptr, 0, r.help); break;
         }
     }
     sTemplates.emplace_back();

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 9   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds, fd_report.reserved becomes solver_used; 9: fd_shared_kernel_name */
+#define FD_ABI_VERSION 9   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds, fd_report.reserved becomes solver_used; 9: fd_shared_kernel_name, fd_set_output */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -178,6 +178,14 @@ int fd_set_stream(fd_ctx *ctx, void *hip_stream);
 /* FD_EVAL_FP32 / FD_EVAL_FP64 for the evaluations from here on (fd_config.eval_precision is the initial value).  A built
  * model carries the records of both: no rebuild.  fdsop_cook switches per cook on fd_fp32_holds(). */
 int fd_set_eval_precision(fd_ctx *ctx, int eval_precision);
+/* What the evaluation calls write into P_out.  FD_OUTPUT_POSITION (default): P + d f, the reference's write-back
+ * (src/SOP_FaceDeform.cpp:438).  FD_OUTPUT_DISPLACEMENT: the addend alone, d f -- the fp32 displacement after the tangent projection
+ * and the fall-off (:415-437), BEFORE it is added to the position; gated vertices and frames without a built model, which the
+ * reference leaves where they are, get 0.  P_in is still the evaluation point.  For callers that keep a delta attribute, and for
+ * parity tests that hold the displacement itself to 1e-5 without the rounding of P + d in the way.  Takes effect with the next
+ * fd_deform* call; a batch takes the setting of its first context (all of them must agree). */
+enum { FD_OUTPUT_POSITION = 0, FD_OUTPUT_DISPLACEMENT = 1 };
+int fd_set_output(fd_ctx *ctx, int what);
 
 /* ---- model set-up -----------------------------------------------------------
  * fd_set_points replaces alglib::rbfsetpoints(model, xy) with the M x 6 table
@@ -194,6 +202,10 @@ int fd_set_points_dev(fd_ctx *ctx, const float *d_rest_xyz, const float *d_delta
  * the rest points, kernel and term only, so after fd_set_deltas the next fd_build* carries just
  * the new right-hand sides through the stored factorisation (same kernels and operand order as
  * a full build: the weights are bit-identical to fd_set_points + fd_build with the same data).
+ * Exception: where FD_SOLVER_AUTO takes the register-resident one-launch build (thin-plate, cubic, biharmonic, fixed-radius
+ * Gaussian with a term that makes them definite, up to 256 control points) no factorisation is stored -- the matrix never leaves
+ * the registers -- and the next fd_build* simply builds again, in one launch (0.19 ms at M = 256, less than the stored-factor
+ * path's launch chain); the weights are the same bits either way.  FD_SOLVER_CHAIN keeps and reuses the factorisation.
  * FD_E_NOT_BUILT when there is no factorisation to reuse (no build yet, or fd_set_points /
  * fd_set_kernel / fd_set_term / fd_import_model since); M must match; order <= 2048. */
 int fd_set_deltas(fd_ctx *ctx, const float *delta_xyz, int M);

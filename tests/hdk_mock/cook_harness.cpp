@@ -6,6 +6,7 @@
 // in:  int64 N, M, hole_every; float P[3N], rest[3M], deform_a[3M], deform_b[3M]
 // out: float P_a[3N], P_b[3N], falloff_b[N]        (two cooks: everything new; then only the animated rig changed)
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -55,9 +56,19 @@ int main(int argc, char **argv)
     newSopOperator(&table);
     if (table.ops.size() != 1 || table.ops[0]->name != "facedeform" || table.ops[0]->label != "Face Deform" || table.ops[0]->minIn != 3 ||
         table.ops[0]->maxIn != 1000) { fprintf(stderr, "operator registration differs from the reference's (:38-45)\n"); return 3; }
-    int nparms = 0;
-    for (PRM_Template *t = table.ops[0]->templates; t->type != PRM_LIST_TERMINATOR; ++t) ++nparms;
-    printf("parms: %d\n", nparms);
+    int nparms = 0, nhelp = 0;
+    // the reference attaches a help text to these tokens (src/SOP_FaceDeform.cpp:121-137)
+    const char *documented[] = {"model", "term", "radius", "maxedges", "tangent", "morphspace", "doclampweight", "weightrange", "falloffradius", "falloffrate"};
+    for (PRM_Template *t = table.ops[0]->templates; t->type != PRM_LIST_TERMINATOR; ++t) {
+        ++nparms;
+        for (const char *d : documented)
+            if (t->name && t->name->token && std::strcmp(t->name->token, d) == 0) {
+                if (!t->help || !*t->help) { fprintf(stderr, "parm %s carries no help text\n", d); return 3; }
+                ++nhelp;
+            }
+    }
+    printf("parms: %d (%d with the reference's help texts)\n", nparms, nhelp);
+    if (nhelp != (int)(sizeof(documented) / sizeof(documented[0]))) return 3;
     OP_Network net;
     std::unique_ptr<OP_Node> holder(table.ops[0]->ctor(&net, "facedeform1", table.ops[0].get()));
     SOP_Node *node = dynamic_cast<SOP_Node *>(holder.get());

@@ -229,11 +229,11 @@ struct PRM_SpareData {};
 typedef int (*PRM_Callback)(void *, int, fpreal, const void *);
 struct PRM_Template {
     PRM_Type type = PRM_LIST_TERMINATOR; int size = 0; PRM_Name *name = nullptr; PRM_Default *def = nullptr;
-    PRM_ChoiceList *menu = nullptr; PRM_Range *range = nullptr;
+    PRM_ChoiceList *menu = nullptr; PRM_Range *range = nullptr; const char *help = nullptr;
     PRM_Template() {}
     PRM_Template(PRM_Type t, int n, PRM_Name *nm, PRM_Default *d = nullptr, PRM_ChoiceList *m = nullptr, PRM_Range *r = nullptr,
-                 PRM_Callback = nullptr, PRM_SpareData * = nullptr)
-        : type(t), size(n), name(nm), def(d), menu(m), range(r) {}
+                 PRM_Callback = nullptr, PRM_SpareData * = nullptr, int /*parm group*/ = 0, const char *h = nullptr)
+        : type(t), size(n), name(nm), def(d), menu(m), range(r), help(h) {}
 };
 extern PRM_Name PRMgroupName;
 

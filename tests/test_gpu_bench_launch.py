@@ -57,7 +57,7 @@ def c2():
     P = synth.head_mesh(N)
     rest = synth.control_points(M, "head")
     P[:8] = rest[:8]                                         # vertices on centres: d2 == 0
-    deltas = np.stack([synth.smooth_deltas(rest, f) for f in range(64)]).astype(np.float32)     # bench.py's N_FRAMES phases
+    deltas = np.stack([synth.rig_deltas(rest, f) for f in range(64)])     # bench.py's N_FRAMES phases, as the fp32 difference of the two rigs (the numbers the oracle's table holds)
     return {"dev": dev, "P": P, "rest": rest, "deltas": deltas, "d_P": torch.from_numpy(P).to(dev),
             "d_rest": torch.from_numpy(rest).to(dev), "d_deltas": torch.from_numpy(deltas).to(dev)}
 

@@ -338,41 +338,30 @@ def test_a_repaired_build_is_ordered_before_evaluations_on_other_streams(hip_lib
 
 
 def test_one_workgroup_build_matches_the_chain(hip_lib):
-    """k_build_small (FD_SMALL_BUILD=1: everything after the assembly in one launch of one workgroup).
-    Slower than the launch chain on this hardware and therefore off by default; kept selectable, so it
-    is kept correct: weights against the chain's to rounding, fd_set_deltas bit-identical to a rebuild,
-    batch == single.  The switch is read once per process, hence the child process."""
-    import os, subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import sys, numpy as np
-        sys.path.insert(0, %r)
-        from facedeform_amd import capi, synth
+    """k_build_small (fd_config.solver = FD_SOLVER_ONE_WORKGROUP: everything after the assembly in one launch of one workgroup).
+    Slower than the launch chain for a lone build and therefore not what FD_SOLVER_AUTO takes; kept selectable, so it is kept
+    correct: weights against the chain's (FD_SOLVER_CHAIN) to rounding at M = 40, 256, 500, fd_set_deltas bit-identical to a
+    rebuild.  (Round 2 selected it with an environment variable in a child process; the product library reads none.)"""
+    res = {}
+    for solver in (capi.SOLVER_CHAIN, capi.SOLVER_ONE_WORKGROUP):
         out = {}
         for M in (40, 256, 500):
             rest = synth.control_points(M, "head")
             d0 = synth.smooth_deltas(rest, 0).astype(np.float32); d1 = synth.smooth_deltas(rest, 1).astype(np.float32)
-            e = capi.Engine(); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
-            e.set_points(rest, d0); assert e.build().terminationtype == 1
-            out["w%%d" %% M] = e.get_weights()[0]
+            e = capi.Engine(solver=solver); e.set_kernel(capi.KERNEL_THIN_PLATE); e.set_term(capi.TERM_LINEAR)
+            e.set_points(rest, d0)
+            rep = e.build()
+            assert rep.terminationtype == 1 and rep.solver_used == solver, (M, rep.solver_used)
+            out[f"w{M}"] = e.get_weights()[0]
             e.set_deltas(d1); assert e.build().terminationtype == 1
             wd = e.get_weights()[0]
             e.set_points(rest, d1); e.build()
             assert np.array_equal(wd, e.get_weights()[0]), M          # new deltas through the stored factor == rebuild
-            out["d%%d" %% M] = wd
+            out[f"d{M}"] = wd
             e.close()
-        np.savez(sys.argv[1], **out)
-    """ % root)
-    import tempfile
-    res = {}
-    for mode in ("0", "1"):
-        path = os.path.join(tempfile.mkdtemp(prefix="fdsmall_"), "w.npz")
-        env = dict(os.environ, FD_SMALL_BUILD=mode)
-        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[mode] = np.load(path)
-    for k in res["0"].files:
-        a, b = res["0"][k], res["1"][k]
+        res[solver] = out
+    for k in res[capi.SOLVER_CHAIN]:
+        a, b = res[capi.SOLVER_CHAIN][k], res[capi.SOLVER_ONE_WORKGROUP][k]
         assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max(), k
 
 
