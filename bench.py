@@ -101,6 +101,12 @@ def parse_args():
     ap.add_argument("--time-every", type=int, default=4,
                     help="shared evaluation, one call per group: every n-th group carries the four HIP events that time its build and "
                          "its evaluation launch (runs of fewer than 16 groups time every group)")
+    ap.add_argument("--no-shared-factor-alternative", dest="shared_factor_alternative", action="store_false",
+                    help="skip the second timed pass with one factorisation per group (reported under \"alternative\", never as `value`)")
+    ap.add_argument("--alt-eval-cus", type=int, default=224,
+                    help="CUs of the shared-rig evaluation in the shared-factor pass (its builds hold one CU for the factorisation and "
+                         "31 briefly for the other frames; measured 216 / 224 / 228 / 232 / 236: 168 / 166 / 167 / 149 / 150 k Mverts/s -- the "
+                         "pass is bound by the evaluation launch, 0.19 ms per 32 frames on 224 CUs, and the CU-budget cliff is where it was)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=float, default=3.0e8,
                     help="bound on (vertex, centre) pairs in the CPU baseline sample")
@@ -743,6 +749,42 @@ def main():
     elapsed = time.perf_counter() - t0
     check_builds()
 
+    # SURVEY 8e's alternative for frames that share a rest rig: ONE factorisation per group (fd_batch_set_shared_factor), every
+    # frame's right-hand sides through it.  The same steps, the same pipeline, timed again with the switch on and reported
+    # under "alternative" -- `value` stays the rebuild-per-frame figure (the reference rebuilds its model every cook).
+    alternative = None
+    if c_groups and args.shared_factor_alternative and args.build == "register" and n_ctrl <= 256:
+        for ln in lanes:
+            for bt in ln["batches"].values():
+                bt.set_shared_factor(True)
+                bt.set_eval_cus(args.alt_eval_cus if args.steps > B else args.eval_cus)
+        run_steps(min(args.steps, 2 * B * n_lanes), g0=0)          # every lane once or twice with the switch on
+        if args.steps % B:
+            run_steps(args.steps % B, g0=args.steps // B)
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(args.steps, None, g0=0)
+        sync_all()
+        alt_elapsed = time.perf_counter() - t0
+        check_builds()
+        flags = [(len(bt), bt.last_build_shared_factor()) for ln in lanes for bt in ln["batches"].values()]
+        if os.environ.get("FD_BENCH_DEBUG"):
+            print("[shared-factor pass: (batch size, took the shared path)]", flags, file=sys.stderr, flush=True)
+        took = any(t for _, t in flags) and all(t for n, t in flags if n == min(B, args.steps) or n == B)
+        ta = torch.tensor([alt_elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        alt_elapsed = float(ta.item())
+        alternative = {"build": "one factorisation per group of frames that share the rest rig (fd_batch_set_shared_factor: k_build_reg for the "
+                                "group's first frame, k_resolve_reg -- one workgroup per frame -- for the others); weights equal the per-frame "
+                                "builds' to 1e-12 (tests/test_gpu_shared_factor.py)",
+                       "value": world * args.steps * n_verts / alt_elapsed / 1e6, "unit": "Mverts/s", "ms_per_step": alt_elapsed / args.steps * 1e3,
+                       "evaluation_cus": args.alt_eval_cus if args.steps > B else args.eval_cus, "took_the_shared_path": bool(took)}
+        for ln in lanes:
+            for bt in ln["batches"].values():
+                bt.set_shared_factor(False)
+                bt.set_eval_cus(args.eval_cus)
+
     # one cook at a time, host-synchronised: the latency a single interactive cook sees
     # (unbatched fd_set_points_dev + fd_build_async + fd_deform_dev on one context)
     lat = []
@@ -959,6 +1001,7 @@ def main():
                                "achieved_batched": (n_ctrl - 4) ** 3 / 3.0 / (build_ms * 1e-3) / 1e12,
                                "frac_batched": (n_ctrl - 4) ** 3 / 3.0 / (build_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
                                "note": "a chain of dependent launches on a small matrix: latency, not flops, bounds it (DESIGN.md 4.2b/4.2c)"},
+            "alternative": alternative,
             "ranks": ranks,
             # host side of the pipeline: wall time the rank's Python thread spends enqueueing one group (fd_batch_cook_group: one
             # foreign call; --group-call python: five calls with pointer tables built per group)

@@ -65,7 +65,7 @@ EXPORTS = [
     "fd_morph_set_rest", "fd_morph_is_initialised", "fd_morph_is_computed", "fd_morph_shape_count", "fd_morph_last_init_ms",
     "fd_morph_compute_weights_dev", "fd_morph_displace_dev", "fd_morph_apply", "fd_morph_get_weights",
     "fd_morph_get_qr",
-    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error", "fd_batch_wait_consumed", "fd_batch_prepare_shared", "fd_batch_set_eval_cus", "fd_batch_cook_group", "fd_shared_kernel_name",
+    "fd_batch_create", "fd_batch_destroy", "fd_batch_size", "fd_batch_last_error", "fd_batch_wait_consumed", "fd_batch_prepare_shared", "fd_batch_set_eval_cus", "fd_batch_cook_group", "fd_shared_kernel_name", "fd_batch_set_shared_factor", "fd_batch_last_build_shared_factor",
     "fd_batch_set_points_dev", "fd_batch_build_async", "fd_batch_build_result", "fd_batch_deform_dev",
     "fd_batch_deform_shared_dev",
     "fdsop_create", "fdsop_destroy", "fdsop_set_float", "fdsop_set_int", "fdsop_set_string",
@@ -153,6 +153,8 @@ def load() -> C.CDLL:
     L.fd_batch_prepare_shared.argtypes = [vp, vp, vp, vp]; L.fd_batch_prepare_shared.restype = i32
     L.fd_batch_set_eval_cus.argtypes = [vp, i32]; L.fd_batch_set_eval_cus.restype = i32
     L.fd_shared_kernel_name.argtypes = [i32, i32, i32]; L.fd_shared_kernel_name.restype = C.c_char_p
+    L.fd_batch_set_shared_factor.argtypes = [vp, i32]; L.fd_batch_set_shared_factor.restype = i32
+    L.fd_batch_last_build_shared_factor.argtypes = [vp]; L.fd_batch_last_build_shared_factor.restype = i32
     L.fd_batch_cook_group.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp]; L.fd_batch_cook_group.restype = i32
     L.fd_batch_last_error.argtypes = [vp]; L.fd_batch_last_error.restype = C.c_char_p
     L.fd_batch_set_points_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32]
@@ -538,6 +540,13 @@ class Batch:
     def set_eval_cus(self, n_cus: int):
         """fd_batch_set_eval_cus: CUs this batch's shared-rig evaluation launches may occupy (0: all)."""
         self._check(self.L.fd_batch_set_eval_cus(self.h, int(n_cus)))
+
+    def set_shared_factor(self, on: bool = True):
+        """fd_batch_set_shared_factor: one factorisation per batched build where the contexts share the rest array."""
+        self._check(self.L.fd_batch_set_shared_factor(self.h, 1 if on else 0))
+
+    def last_build_shared_factor(self) -> bool:
+        return bool(self.L.fd_batch_last_build_shared_factor(self.h))
 
     def group_tables(self, d_delta_ptrs, d_P_out, d_falloff=None):
         """The pointer tables of fd_batch_cook_group, built once and reused by a pipeline whose arrays do not move."""

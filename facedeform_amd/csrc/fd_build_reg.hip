@@ -296,8 +296,21 @@ __device__ __forceinline__ int tile_owner(int I, int J)
     return (I + (int)((kOffsets >> (3 * J)) & 7ull)) % kWorkers;
 }
 
+// ---- one factorisation for a group of frames that share the rest rig (fd_batch_set_shared_factor; SURVEY 8e: "factor once and
+// treat frames as extra right-hand sides").  The system matrix depends on the rest rig, the kernel and the term only
+// (src/SOP_FaceDeform.cpp:331-363 rebuilds it every cook).  k_build_reg builds frame 0 as ever and, given `fac`, leaves behind what
+// the other frames need: the Cholesky factor's tiles as they sit in the workers' registers ([column-major tile number][register]
+// [lane]: 512 contiguous bytes per store), the inverted diagonal blocks, the reflectors, B21, the small matrices and the
+// model's flags.  k_resolve_reg then runs ONE workgroup per remaining frame: Q^T f, both substitutions against the factor in L2
+// (a column of tiles per step, the next one requested a step ahead), the polynomial, w = Q [y; 0], packing.
+constexpr int kFacTiles = kMaxBlocks * (kMaxBlocks + 1) / 2;                         // 136
+constexpr size_t kFacL = 0, kFacMinv = (size_t)kFacTiles * 256, kFacV = kFacMinv + (size_t)kMaxBlocks * kTileLds, kFacB21 = kFacV + 4 * kRows,
+                 kFacSmall = kFacB21 + 4 * kRows, kFacMeta = kFacSmall + kSmallDoubles, kFacDoubles = kFacMeta + 8;
+// meta: [0] amax, [1] coincident centres, [2] singular (pivot / rank of P / spin time-out), [3] smallest pivot, [4] largest pivot
+
 __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab, const PointSrc src, int use_src, int M, int T, int npad,
-                                                            int kind, int Mpad, double lambda, double gauss_R, unsigned long long *stamps)
+                                                            int kind, int Mpad, double lambda, double gauss_R, unsigned long long *stamps,
+                                                            double *fac)
 {
     const BatchSlot &slot = tab[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
@@ -923,6 +936,27 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     };
     if (!worker && nb > 0) solve_block(nb - 1);
     __syncthreads();
+    if (fac != nullptr && blockIdx.z == 0) {
+        // the factor and its company for the group's other frames (k_resolve_reg); everything here is final: the tiles hold L,
+        // minv the inverted diagonal blocks, stat the pivot statistics
+        gdouble *fg = as_global(fac);
+#pragma unroll
+        for (int t = 0; t < kSlots; ++t) {
+            if (FD_SLOT(m_matrix, t)) {
+                const int q = __builtin_amdgcn_readlane(ijv, t) >> 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fg[kFacL + ((size_t)q * 4 + i) * 64 + lane] = S[t][i];
+            }
+        }
+        for (int e = tid; e < kMaxBlocks * kTileLds; e += kRegThreads) fg[kFacMinv + e] = e < nb * kTileLds ? L.minv[e] : 0.0;
+        for (int e = tid; e < 4 * kRows; e += kRegThreads) { fg[kFacV + e] = L.V[e]; fg[kFacB21 + e] = L.B21[e]; }
+        if (tid < kSmallDoubles) fg[kFacSmall + tid] = L.small[tid];
+        if (tid == 0) {
+            fg[kFacMeta + 0] = amax; fg[kFacMeta + 1] = dup_any ? 1.0 : 0.0;
+            fg[kFacMeta + 2] = (L.stat[2] != 0.0 || L.stat[3] != 0.0) ? 1.0 : 0.0;
+            fg[kFacMeta + 3] = L.stat[0]; fg[kFacMeta + 4] = L.stat[1];
+        }
+    }
     for (int I = nb - 1; I >= 1; --I) {
         const unsigned m_row = slots_where(ivI == I && ivJ < I);
         const bool next_mine = slots_where(ivI == I && ivJ == I - 1) != 0u;
@@ -1042,7 +1076,219 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
 #undef FD_SLOT
 }
 
+// ---- frames 1 .. n - 1 of a shared-factor group: one workgroup of 256 threads per frame.  Thread = row (forward) or column
+// (backward) of the system; the three right-hand sides of the frame ride in LDS.  tab + 1 + blockIdx.z is the frame's slot.
+__global__ __launch_bounds__(256) void k_resolve_reg(const BatchSlot *tab, const PointSrc src, int use_src, int M, int T, int npad, int kind,
+                                                      int Mpad, double gauss_R, const double *fac)
+{
+    const int fi = 1 + (int)blockIdx.z;
+    const BatchSlot &slot = tab[fi];
+    __shared__ double s_minv[kMaxBlocks * kTileLds];          // 34.8 KB
+    __shared__ double s_V[4 * kRows], s_B21[4 * kRows], s_small[kSmallDoubles];
+    __shared__ double s_f[3 * kRows];                         // f, then z, then y: in place
+    __shared__ double s_blk[3 * 16];                          // the block just solved
+    __shared__ double s_red[4 * 12];
+    __shared__ double s_g[12], s_a[12];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n1 = M - T, nb = (n1 + 15) / 16, nbk = (M + 15) / 16;
+    gcdouble *fg = as_global(fac);
+    DevModel FD_GLOBAL *model = as_global(slot.model);
+    // column-major number of tile (I, J) of the lower triangle of an nbk x nbk tile grid (k_build_reg's staging index)
+    auto tile_q = [&](int I, int J) { return J * nbk - J * (J - 1) / 2 + (I - J); };
+    for (int e = tid; e < kMaxBlocks * kTileLds; e += 256) s_minv[e] = fg[kFacMinv + e];
+    for (int e = tid; e < 4 * kRows; e += 256) { s_V[e] = fg[kFacV + e]; s_B21[e] = fg[kFacB21 + e]; }
+    if (tid < kSmallDoubles) s_small[tid] = fg[kFacSmall + tid];
+    {
+        // control table of this frame (reference :268-287, widened to fp64); the centres are frame 0's (one rest rig)
+        const float *rest = use_src ? src.rest[fi] : slot.rest;
+        const float *delta = use_src ? src.delta[fi] : slot.delta;
+        for (int i = tid; i < kRows; i += 256) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                double d = 0.0;
+                if (i < M) {
+                    const float r = rest[3 * i + q], dl = delta[3 * i + q];
+                    d = (double)dl;
+                    slot.centres[3 * i + q] = (double)r;
+                    if (use_src) { slot.rest[3 * i + q] = r; slot.delta[3 * i + q] = dl; }
+                }
+                s_f[q * kRows + i] = d;
+            }
+            if (i < M) slot.radii[i] = gauss_R;
+        }
+    }
+    __syncthreads();
+    // ---- f <- Q^T f = H_{T-1} .. H_0 f; the pivot rows' shares g_k go to the polynomial equations (k_build_reg folds this into
+    // the reflectors' own sweep; v_k is column k of V, 1 at its pivot row M-1-k and 0 below it)
+    const int i0 = tid;                                        // this thread's row (kRows == 256)
+    for (int k = 0; k < T; ++k) {
+        const int piv = M - 1 - k;
+        const double v = s_V[4 * i0 + k];
+        double d[3] = {v * s_f[i0], v * s_f[kRows + i0], v * s_f[2 * kRows + i0]};
+        packing::block_reduce_many<3, false>(d, s_red, tid);
+        const double tau = s_small[kTau + k];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const double fv = fma(-tau * d[e], v, s_f[e * kRows + i0]);
+            if (i0 == piv) { s_g[3 * k + e] = fv; s_f[e * kRows + i0] = 0.0; }
+            else if (i0 < piv) s_f[e * kRows + i0] = fv;
+        }
+        __syncthreads();
+    }
+    // ---- forward: L z = f, right-looking, a column of tiles per step.  Thread = row r: its 16 entries of column block K are 128
+    // contiguous bytes of the tile image (register r % 16 / 4, lanes 16 (r % 4) .. + 15); the next column's are requested before
+    // this column's are used.
+    {
+        const int r = tid, I = r >> 4, rr = r & 15;
+        double cur[16], nxt[16];
+        auto fetch = [&](int K, double (&dst)[16]) {
+            if (I > K && I < nb) {
+                gcdouble *p = fg + kFacL + ((size_t)tile_q(I, K) * 4 + (rr >> 2)) * 64 + 16 * (rr & 3);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dst[k] = p[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dst[k] = 0.0;
+            }
+        };
+        fetch(0, cur);
+        for (int K = 0; K < nb; ++K) {
+            if (K + 1 < nb) fetch(K + 1, nxt);
+            if (tid < 48) {                                    // z_K = inv(L_KK) f_K
+                const int e = tid >> 4, n = tid & 15;
+                const double *mk = s_minv + (size_t)K * kTileLds;
+                double z = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) z = fma(s_f[e * kRows + 16 * K + k], mk[n * kPitch + k], z);
+                s_blk[e * 16 + n] = z;
+            }
+            __syncthreads();
+            if (tid < 48) s_f[(tid >> 4) * kRows + 16 * K + (tid & 15)] = s_blk[tid];
+            if (I > K && I < nb) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    double acc = s_f[e * kRows + r];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc = fma(-cur[k], s_blk[e * 16 + k], acc);
+                    s_f[e * kRows + r] = acc;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+        }
+    }
+    // ---- backward: y^T L = z^T, bottom up.  Thread = column c of block J: for row block I > J it needs column c of tile (I, J).
+    {
+        const int cidx = tid, J = cidx >> 4, cc = cidx & 15;
+        double cur[16], nxt[16];
+        auto fetch = [&](int I, double (&dst)[16]) {
+            if (I > J && I < nb) {
+                gcdouble *p = fg + kFacL + (size_t)tile_q(I, J) * 256 + cc;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) dst[rr] = p[(rr >> 2) * 64 + 16 * (rr & 3)];      // element (rr, cc)
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) dst[rr] = 0.0;
+            }
+        };
+        if (nb > 0) fetch(nb - 1, cur);
+        for (int I = nb - 1; I >= 0; --I) {
+            if (I > 0) fetch(I - 1, nxt);
+            if (tid < 48) {                                    // y_I = inv(L_II)^T z_I
+                const int e = tid >> 4, n = tid & 15;
+                const double *mi = s_minv + (size_t)I * kTileLds;
+                double y = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) y = fma(s_f[e * kRows + 16 * I + k], mi[k * kPitch + n], y);
+                s_blk[e * 16 + n] = y;
+            }
+            __syncthreads();
+            if (tid < 48) s_f[(tid >> 4) * kRows + 16 * I + (tid & 15)] = s_blk[tid];
+            if (J < I) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    double acc = s_f[e * kRows + cidx];
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) acc = fma(-cur[rr], s_blk[e * 16 + rr], acc);
+                    s_f[e * kRows + cidx] = acc;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) cur[rr] = nxt[rr];
+        }
+    }
+    // ---- R a = g - B21 y;  w = Q [y; 0] = H_0 .. H_{T-1} [y; 0]
+    double xr[3];
+    {
+        const bool in = i0 < n1;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) xr[e] = in ? s_f[e * kRows + i0] : 0.0;
+        double q12[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double b = (in && k < T) ? s_B21[4 * i0 + k] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) q12[3 * k + e] = b * xr[e];
+        }
+        if (T > 0) packing::block_reduce_many<12, false>(q12, s_red, tid);
+        if (tid == 0) {
+            double a[4][3] = {};
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                if (k >= T) continue;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    double v = s_g[3 * k + e] - q12[3 * k + e];
+#pragma unroll
+                    for (int c2 = k + 1; c2 < 4; ++c2) if (c2 < T) v = fma(-s_small[kR + 4 * k + c2], a[c2][e], v);
+                    a[k][e] = v / s_small[kR + 4 * k + k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) s_a[3 * k + e] = a[k][e];
+        }
+        for (int k = T - 1; k >= 0; --k) {
+            const int piv = M - 1 - k;
+            const double v = i0 <= piv ? s_V[4 * i0 + k] : 0.0;
+            double d[3] = {v * xr[0], v * xr[1], v * xr[2]};
+            packing::block_reduce_many<3, false>(d, s_red, tid);
+            const double tau = s_small[kTau + k];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) xr[e] = fma(-tau * d[e], v, xr[e]);
+        }
+        __syncthreads();
+        gdouble *X = as_global(slot.X);
+        if (i0 < M) { X[i0] = xr[0]; X[(size_t)npad + i0] = xr[1]; X[2 * (size_t)npad + i0] = xr[2]; }
+        for (int rrow = M + tid; rrow < npad; rrow += 256) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) X[(size_t)e * npad + rrow] = (rrow - M < T) ? s_a[3 * (rrow - M) + e] : 0.0;
+        }
+        if (tid == 0) {
+            model->terminationtype = 0;
+            model->dup_flag = fg[kFacMeta + 1] != 0.0 ? 1 : 0;
+            model->sing_flag = fg[kFacMeta + 2] != 0.0 ? 1 : 0;
+            model->iterations = M + T;
+            model->amax_bits = (unsigned long long)__double_as_longlong(fg[kFacMeta + 0]);
+            model->pivmin_bits = (unsigned long long)__double_as_longlong(fg[kFacMeta + 3]);
+            model->pivmax_bits = (unsigned long long)__double_as_longlong(fg[kFacMeta + 4]);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    packing::pack_body(slot, npad, M, Mpad, T, kind, 0, 0);
+    if (kind == FD_KERNEL_THIN_PLATE) {
+        __syncthreads();
+        for (int tile = tid >> 6; tile < Mpad / 16; tile += 4) packing::pack_tiles_body(slot, Mpad, tile, lane);
+    }
+}
+
 }  // namespace
+
+size_t reg_factor_doubles() { return kFacDoubles; }
 
 bool reg_applicable(int kind, int term, double lambda, int M)
 {
@@ -1065,6 +1311,21 @@ hipError_t reg_build_init()
 }
 
 // The WHOLE build, control table included: one launch.  src == nullptr: the contexts' own copies of the control points.
+// One factorisation for the whole batch (the contexts share rest rig, kernel and term: the caller has checked): frame 0 through
+// k_build_reg, which leaves the factor in `fac` (reg_factor_doubles() doubles of device scratch), the others through k_resolve_reg.
+hipError_t launch_build_reg_shared(const BuildBuffers &b, hipStream_t stream, const PointSrc *src, hipEvent_t ev_mid, double *fac)
+{
+    static const PointSrc none{};
+    if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+    const size_t lds = sizeof(double) * reg_lds_doubles(b.M);
+    hipLaunchKernelGGL(k_build_reg, dim3(1, 1, 1), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,
+                       b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, (unsigned long long *)nullptr, fac);
+    if (b.nbatch > 1)
+        hipLaunchKernelGGL(k_resolve_reg, dim3(1, 1, (unsigned)b.nbatch - 1), dim3(256), 0, stream, b.d_slots, src ? *src : none, src ? 1 : 0,
+                           b.M, b.T, b.npad, b.kind, b.Mpad, b.gauss_R, (const double *)fac);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const PointSrc *src, hipEvent_t ev_mid)
 {
     static const PointSrc none{};
@@ -1079,7 +1340,7 @@ hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const Poi
     const bool want_stamps = stamps_env && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
     if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 96 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 96 * sizeof(unsigned long long)); }
     hipLaunchKernelGGL(k_build_reg, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,
-                       b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, want_stamps ? d_stamps : nullptr);
+                       b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, want_stamps ? d_stamps : nullptr, (double *)nullptr);
     if (want_stamps && d_stamps && stamps_late) {
         static bool registered = false;
         static unsigned long long *d_keep = nullptr;

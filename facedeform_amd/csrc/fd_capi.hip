@@ -144,6 +144,9 @@ struct fd_batch {
     // differs through like a failed build and posts 1 + its index here (page-locked); the next call on the batch reports it.
     int *h_mismatch = nullptr;
     int eval_cus = 0;                    // fd_batch_set_eval_cus: CUs a shared-rig evaluation may occupy (0: all)
+    int shared_factor = 0;               // fd_batch_set_shared_factor: one factorisation per build where the contexts share the rest rig
+    double *d_fac = nullptr;             // ... and its scratch (reg_factor_doubles())
+    int last_shared_factor = 0;          // the last build took that path
     int cur_set = 0;                     // the set packed last
     bool packed_valid = false;           // sets[cur_set].packed_ev is recorded (fd_batch_wait_consumed)
     bool prepared = false;               // sets[cur_set] holds the contexts' CURRENT models and prep_* outputs
@@ -1459,6 +1462,7 @@ void fd_batch_destroy(fd_batch *b)
         if (st.packed_ev) (void)hipEventDestroy(st.packed_ev);
         if (st.eval_ev) (void)hipEventDestroy(st.eval_ev);
     }
+    if (b->d_fac) (void)hipFree(b->d_fac);
     if (b->fallback_ev) (void)hipEventDestroy(b->fallback_ev);
     if (b->group_ev) (void)hipEventDestroy(b->group_ev);
     if (b->h_mismatch) (void)hipHostFree(b->h_mismatch);
@@ -1581,8 +1585,20 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         hipError_t e_ = (call);                                                               \
         if (e_ != hipSuccess) { batch_err(b, "%s failed: %s", #call, hipGetErrorString(e_)); return FD_E_DEVICE; } \
     } while (0)
+    // One factorisation for the group (fd_batch_set_shared_factor): the register-resident build applies and every context reads
+    // its rest rig, in place, from the SAME device array (fd_batch_set_points_dev with one rest pointer); anything else builds
+    // every model on its own as ever.
+    bool shared_fac = b->shared_factor != 0 && bb.reg && b->have_src && b->n > 1;
+    for (int i = 1; i < b->n && shared_fac; ++i) shared_fac = b->src.rest[i] == b->src.rest[0];
+    if (shared_fac && !b->d_fac && hipMalloc((void **)&b->d_fac, sizeof(double) * reg_factor_doubles()) != hipSuccess) {
+        (void)hipGetLastError(); b->d_fac = nullptr; shared_fac = false;
+    }
+    b->last_shared_factor = shared_fac ? 1 : 0;
     FD_BHIP(hipEventRecord(b->ev0, stream));
-    if (bb.reg) {
+    if (shared_fac) {
+        FD_BHIP(launch_build_reg_shared(bb, stream, &b->src, b->ev_mid, b->d_fac));
+        b->have_src = false;
+    } else if (bb.reg) {
         // one launch, one workgroup per model, control table included
         FD_BHIP(launch_build_reg(bb, stream, b->have_src ? &b->src : nullptr, b->ev_mid));
         b->have_src = false;
@@ -1962,6 +1978,15 @@ int fd_batch_set_eval_cus(fd_batch *b, int n_cus)
     b->eval_cus = n_cus > 0 ? n_cus : 0;
     return FD_OK;
 }
+
+int fd_batch_set_shared_factor(fd_batch *b, int on)
+{
+    if (!b) return FD_E_INVALID;
+    b->shared_factor = on ? 1 : 0;
+    return FD_OK;
+}
+
+int fd_batch_last_build_shared_factor(const fd_batch *b) { return b ? b->last_shared_factor : 0; }
 
 int fd_batch_size(const fd_batch *b) { return b ? b->n : 0; }
 

@@ -197,6 +197,8 @@ hipError_t launch_resolve_spd(const BuildBuffers &b, hipStream_t stream, const P
 bool reg_applicable(int kind, int term, double lambda, int M);
 // the WHOLE build in one launch, control table included (src == nullptr: the contexts' own copies of the control points)
 hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const PointSrc *src, hipEvent_t ev_mid);
+hipError_t launch_build_reg_shared(const BuildBuffers &b, hipStream_t stream, const PointSrc *src, hipEvent_t ev_mid, double *fac);
+size_t reg_factor_doubles();
 hipError_t reg_build_init();          // once per device, outside stream capture
 constexpr int kMaxLayers = 8;
 hipError_t launch_build_ml(const BuildBuffers &b, hipStream_t stream, hipEvent_t ev_mid);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 9   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds, fd_report.reserved becomes solver_used; 9: fd_shared_kernel_name, fd_set_output */
+#define FD_ABI_VERSION 9   /* 3: fd_config.solver, FD_KERNEL_GAUSSIAN_ML, fd_model_centres; 4: fd_mesh_capture, capture inputs at the end of fdsop_geo; 5: fd_batch_wait_consumed, fd_batch_prepare_shared; 6: fd_batch_set_eval_cus; 7: fd_batch_cook_group, FD_SOLVER_REGISTER / FD_SOLVER_CHAIN; 8: fd_report grows by the fp32 estimate (callers built against 7 pass a shorter struct: rebuild), fd_set_eval_precision, fd_fp32_holds, fd_report.reserved becomes solver_used; 9: fd_shared_kernel_name, fd_set_output, fd_batch_set_shared_factor */
 
 /* ---- error codes ---------------------------------------------------------- */
 enum {
@@ -402,6 +402,18 @@ int fd_batch_prepare_shared(fd_batch *batch, void *hip_stream, float *const *d_P
  * 224 of 256 beside three batches of builds).  Per batch, not
  * per process: two nodes cooking side by side choose independently (round 2 read an environment variable once). */
 int fd_batch_set_eval_cus(fd_batch *batch, int n_cus);
+/* One factorisation per batched build where the contexts share the rest rig ("factor once and treat frames as extra
+ * right-hand sides").  The reference rebuilds its model on every cook (src/SOP_FaceDeform.cpp:331-363); the system matrix depends
+ * on the rest points, the kernel and the term only, so the frames of a shot -- one rest rig, other deltas -- can share it.
+ * With `on`, fd_batch_build_async (and fd_batch_cook_group) assembles, projects and factorises ONCE, in the register-resident
+ * one-launch build of the batch's first context, and carries every other context's right-hand sides through that factor, one
+ * workgroup per context (Q^T f, both substitutions, the polynomial, packing).  It applies when the register-resident build does
+ * (a definite kernel + term pair, up to 256 control points) AND every context was given the SAME rest array by
+ * fd_batch_set_points_dev; otherwise -- other rigs, other kernels, larger rigs -- the call builds every model on its own, as
+ * without the switch.  Weights equal the per-context builds' to rounding (1e-12 of max |w|), not bit for bit.  Off by default.
+ * fd_batch_last_build_shared_factor: 1 if the batch's last build took the shared path. */
+int fd_batch_set_shared_factor(fd_batch *batch, int on);
+int fd_batch_last_build_shared_factor(const fd_batch *batch);
 /* Which kernel fd_batch_deform_shared_dev launches for `frames` frames of an M-centre model of `kind` (a name for profiles and
  * benchmark lines -- the one rocprofv3 prints): "k_deform32_shared_w1" (17..32 frames, the model resident in LDS),
  * "k_deform32_tps_shared_wide" (17..32 frames, staged in chunks), "k_deform32_tps_shared" (up to 16 frames), or "" where the
