@@ -113,6 +113,21 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
     }
     double ext[4] = {r2, r2o, dmax2, ndmin2};
     block_reduce_many<4, true>(ext, s_red, tid);
+    // The smallest displacement the tolerance is asked of: the least |delta_i| among the control points that MOVE, i.e. by at
+    // least a tenth of the largest one.  A rig with stationary or barely moving control points (most of a face, in most frames;
+    // the fringe of any localised deformation) has min |delta_i| = 0 or next to it, and a floor of zero sends every such cook
+    // to fp64 although the field near a stationary point is zero to within half an ulp of the position in fp32 too.
+    if (dl) {
+        const double moving2 = 1e-2 * ext[2];
+        double nmin[1] = {-INFINITY};
+        for (int j = tid; j < M; j += 256) {
+            const double a = dl[3 * j], b = dl[3 * j + 1], c2 = dl[3 * j + 2];
+            const double dd = a * a + b * b + c2 * c2;
+            if (dd >= moving2 && dd > 0.0 && -dd > nmin[0]) nmin[0] = -dd;
+        }
+        block_reduce_many<1, true>(nmin, s_red, tid);
+        ext[3] = nmin[0] > -INFINITY ? nmin[0] : 0.0;
+    }
     const double rad_c = sqrt(ext[0]);
     const double rad_o = sqrt(ext[1]);
     const double cen = sqrt(cenx * cenx + ceny * ceny + cenz * cenz);

@@ -90,6 +90,7 @@ struct fdsop_node {
     float e_qcoef = 0, e_zcoef = 0, e_radius = 0, e_lambda = 0;
     int e_layers = 0, e_maxedges = 0;
     int engine_precision = -1, engine_device = -2;
+    bool fp64_warned = false;         // the "evaluating in fp64" warning has been given for the current rest rig (once per rig, not per cook)
 
     void add(int sev, const char *text)
     {
@@ -394,12 +395,16 @@ int fdsop_cook(fdsop_node *node, const fdsop_geo *geo)
     // build reports (fd_report.fp32_error).  Where that floor exceeds the reference's 1e-5 of the smallest displacements of
     // the control table, this cook is evaluated in fp64 -- unless the artist asked for fp32 outright (precision = 2).
     int cook_precision = precision;
+    if (!geo->rig_rest_unchanged) node->fp64_warned = false;       // another rest rig: say it again if it applies
     if (precision_parm == 0 && !fd_fp32_holds(&report, 1e-5)) {
         cook_precision = FD_EVAL_FP64;
-        char t[240];
-        snprintf(t, sizeof(t), "fp32 evaluation would not hold 1e-5 of this rig's displacements (error ~%.2g, smallest delta %.2g): "
-                               "evaluating in fp64.", report.fp32_error, report.delta_min);
-        node->add(FDSOP_WARNING, t);
+        if (!node->fp64_warned) {                                  // once per rig: an animated shot cooks the same rig every frame
+            char t[240];
+            snprintf(t, sizeof(t), "fp32 evaluation would not hold 1e-5 of this rig's displacements (error ~%.2g, smallest delta %.2g): "
+                                   "evaluating in fp64.", report.fp32_error, report.delta_min);
+            node->add(FDSOP_WARNING, t);
+            node->fp64_warned = true;
+        }
     }
     fd_set_eval_precision(ctx, cook_precision);
     // :370-373

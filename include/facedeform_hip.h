@@ -150,14 +150,16 @@ typedef struct fd_report {
      * the decision fdsop_cook takes; 0 in all four for imported models (no control table to measure against). */
     double fp32_error;   /* ~ absolute error of an fp32-evaluated displacement, in position units        */
     double cancellation; /* S / max_i |delta_i|: how much larger the summed terms are than what they add up to */
-    double delta_min;    /* smallest |delta_i| of the control table                                       */
+    double delta_min;    /* smallest |delta_i| among the control points that move (|delta_i| >= 0.1 delta_max): a
+                          * stationary or barely moving control point -- most of a face rig in most frames, the fringe of a
+                          * localised deformation -- does not count */
     double delta_max;    /* largest                                                                       */
     double extent;       /* largest |rest_i|: the size of the positions the displacement is added to     */
 } fd_report;
 
 /* 1 when the fp32 evaluation of the reported model is expected to hold `tol` (the reference's 1e-5) of every
- * vertex's own displacement: fp32_error <= tol * delta_min / 2 (vertices between control points move less than the
- * least of those) + one fp32 ulp of the positions (both sides round P + d to
+ * vertex's own displacement: fp32_error <= tol * delta_min / 2 (vertices between the moving control points move less than the
+ * least of those; around a stationary one the field is zero to within the next term in fp32 too) + one fp32 ulp of the positions (both sides round P + d to
  * fp32, :438, which shelters errors below that).  0: evaluate this model with FD_EVAL_FP64 (fd_set_eval_precision).
  * Conservative where the displacement field has zeros between control points -- no estimate from M points sees those. */
 int fd_fp32_holds(const fd_report *report, double tol);
