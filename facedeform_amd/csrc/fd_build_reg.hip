@@ -1358,6 +1358,7 @@ hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const Poi
         }
     } else if (want_stamps && d_stamps) {
         unsigned long long h[80];
+        (void)hipStreamSynchronize(stream);          // (a non-blocking stream: the copy below does not wait for it by itself)
         if (hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[k_build_reg stamps, shader cycles: table | assembly | tile loads | reflectors + Q^T f | Y = K V | W + rotation + B21 | Cholesky | back substitution | recovery | pack]\n  ");
             for (int q = 0; q < 10; ++q) fprintf(stderr, " %llu", h[q]);
