@@ -20,6 +20,8 @@ struct fd_ctx {
     int output = FD_OUTPUT_POSITION;    // fd_set_output
     int solver = FD_SOLVER_AUTO;
     int imported_layers = 0;         // a multilayer model that came in through fd_import_model
+    uint64_t rig_build_id = 0;       // nonzero: the id of the ONE batched build that read this context's rest rig, in place, from the same array as
+                                     // its batch mates (their centres are equal by construction); 0: built on its own / from its own copy
     const float *rest_src = nullptr; // caller's device array the rest points were last read from in place (fd_batch_set_points_dev), else null
     bool prefer_lu = false;          // the Cholesky path lost definiteness on this rig: LU until kernel, term or M change
     unsigned long long model_gen = 0; // counts the models this context has held (every enqueued build, every import): what a
@@ -473,6 +475,7 @@ static int set_points_common(fd_ctx *ctx, const float *rest, const float *delta,
     if (M != ctx->M) ctx->prefer_lu = false;
     ctx->M = M;
     ctx->rest_src = nullptr;
+    ctx->rig_build_id = 0;
     ctx->sticky_rc = FD_OK; ctx->status_inflight = false;
     ctx->points_set = true;
     ctx->built = false;
@@ -1384,6 +1387,7 @@ int fd_import_model(fd_ctx *ctx, const void *buf, size_t bytes, int on_device)
     ctx->points_set = false;   // no rest/delta on this context: it can deform, not rebuild
     // never dereferenced, only compared: bit 0 marks an imported identity (arrays are at least 4-byte aligned), so that it
     // can only ever equal another imported model's
+    ctx->rig_build_id = 0;
     ctx->rest_src = h.rig_token ? (const float *)(uintptr_t)(h.rig_token | 1u) : nullptr;
     ctx->build_pending = false;
     ctx->built = true;
@@ -1494,6 +1498,7 @@ int fd_batch_set_points_dev(fd_batch *b, const float *const *d_rest_xyz, const f
         c->have_factor = false;
         c->deltas_only = false;
         c->rest_src = d_rest_xyz[i];
+        c->rig_build_id = 0;
         b->src.rest[i] = d_rest_xyz[i];
         b->src.delta[i] = d_delta_xyz[i];
     }
@@ -1588,8 +1593,11 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     // One factorisation for the group (fd_batch_set_shared_factor): the register-resident build applies and every context reads
     // its rest rig, in place, from the SAME device array (fd_batch_set_points_dev with one rest pointer); anything else builds
     // every model on its own as ever.
-    bool shared_fac = b->shared_factor != 0 && bb.reg && b->have_src && b->n > 1;
-    for (int i = 1; i < b->n && shared_fac; ++i) shared_fac = b->src.rest[i] == b->src.rest[0];
+    // every context reads its rest rig in place from ONE array, in this one launch sequence: their centres are equal by construction
+    bool same_rest_launch = b->have_src;
+    for (int i = 1; i < b->n && same_rest_launch; ++i) same_rest_launch = b->src.rest[i] == b->src.rest[0];
+    const bool shared_fac_ok = same_rest_launch;
+    bool shared_fac = b->shared_factor != 0 && bb.reg && shared_fac_ok && b->n > 1;
     if (shared_fac && !b->d_fac && hipMalloc((void **)&b->d_fac, sizeof(double) * reg_factor_doubles()) != hipSuccess) {
         (void)hipGetLastError(); b->d_fac = nullptr; shared_fac = false;
     }
@@ -1617,8 +1625,11 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     FD_BHIP(hipEventRecord(b->ev1, stream));
     b->waited_stream = nullptr;
 #undef FD_BHIP
+    static uint64_t build_ids = 0;
+    const uint64_t this_build = same_rest_launch ? ++build_ids : 0;
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];
+        c->rig_build_id = this_build;
         c->wait_event = b->ev1; c->wait_stream = stream; c->wait_batch = b;
         c->tev0 = b->ev0; c->tev_mid = b->ev_mid; c->tev1 = b->ev1;
         c->have_factor = bb.ml_layers == 0;   // a batched build leaves a factorisation fd_set_deltas can reuse (not the multilayer model)
@@ -1797,6 +1808,13 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
         fd_ctx *c = b->ctxs[i];
         a.rec32[i] = c->d_rec32; a.model[i] = c->d_model; a.P_out[i] = d_P_out[i]; a.centres[i] = c->d_centres;
         if ((rc = order_after_batch(c, stream))) { batch_err(b, "context %d: %s", i, c->err); return rc; }
+    }
+    // "one rest rig" by content is what the pack kernel checks (an address does not identify contents); contexts that ONE batched
+    // build read from one array are equal by construction, and the comparison -- the pack kernel's longest chain -- is skipped
+    {
+        bool one_build = c0->rig_build_id != 0;
+        for (int i = 1; i < b->n && one_build; ++i) one_build = b->ctxs[i]->rig_build_id == c0->rig_build_id;
+        if (one_build) for (int i = 1; i < b->n; ++i) a.centres[i] = a.centres[0];
     }
     const size_t wb = shared_wtile_bytes(a.Mpad, a.nF), fb = shared_frame_bytes(a.nF);
     if (wb > st.cap_wtiles || fb > st.cap_frames) {
