@@ -378,7 +378,7 @@ class RawEvents:
     stream, evaluation launch start / end on the evaluation stream), read with hipEventElapsedTime."""
     _hip = None
 
-    def __init__(self, capi):
+    def __init__(self, capi, after_build=True):
         import ctypes
         if RawEvents._hip is None:
             RawEvents._hip = ctypes.CDLL("libamdhip64.so")
@@ -391,7 +391,10 @@ class RawEvents:
             if RawEvents._hip.hipEventCreate(ctypes.byref(e)) != 0:
                 raise RuntimeError("hipEventCreate failed")
             self.h.append(e)
-        self.struct = capi.FdGroupEvents(*[e.value for e in self.h])
+        # after_build=False: no event between the builds and the packing kernel (NULL members are skipped by the library): the
+        # "build" of such a group is then timed to the event in front of the evaluation and includes the packing kernel
+        self.build_end = 1 if after_build else 2
+        self.struct = capi.FdGroupEvents(*[(e.value if (q != 1 or after_build) else None) for q, e in enumerate(self.h)])
 
     def ms(self, a, b):
         import ctypes
@@ -603,7 +606,7 @@ def main():
     def group(g, first, count, ev=None):
         th0 = time.perf_counter()
         _group(g, first, count, ev)
-        if ev is not None:
+        if ev is not None and ev != "tables-only":
             host_s[0] += time.perf_counter() - th0
             host_s[1] += 1
 
@@ -625,8 +628,12 @@ def main():
             key = (count, frames[0])
             tabs = ln.setdefault("tables", {})
             if key not in tabs:
+                # (the pointer tables of a group -- static: the same arrays every time the group comes round -- are built on first use;
+                #  `prime_only` builds those of the timed groups before the timed region starts)
                 tabs[key] = batch.group_tables([d_deltas.data_ptr() + f * delta_stride for f in frames],
                                                [o.data_ptr() for o in ln["out"][:count]], [f.data_ptr() for f in ln["fall"][:count]])
+            if ev == "tables-only":
+                return
             # timed groups: four raw HIP events recorded INSIDE the call, around the builds and around the evaluation launch
             batch.cook_group(stream.cuda_stream, es.cuda_stream, d_rest.data_ptr(), n_ctrl, n_verts, d_P.data_ptr(), tabs[key],
                              events=ev[first].struct if (ev and first in ev) else None)
@@ -724,7 +731,11 @@ def main():
         # when there are few): the event packets are not free on the evaluation stream (see _group)
         n_groups = (args.steps + B - 1) // B
         stride = 1 if n_groups < 16 else max(1, args.time_every)
-        events = {i: RawEvents(capi) for i in range(0, args.steps, B * stride)}
+        # a run of ONE group (the driver's `--steps 20`) cooks on one stream, where every event record between two kernels is a
+        # barrier packet the queue idles ~4 us for: no event between its builds and its packing kernel
+        one_group = args.steps <= B
+        events = {i: RawEvents(capi, after_build=not one_group) for i in range(0, args.steps, B * stride)}
+        run_steps(args.steps, "tables-only", g0=0)         # argument tables of the timed groups: static pointers, built once
     else:
         events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     # One HIP event pair per run of `event_every` consecutive evaluations of a group (the pair's
@@ -825,7 +836,7 @@ def main():
     group_firsts = sorted(events) if c_groups else list(range(0, args.steps, B))
     def ev_ms(i, a, b):
         return events[i].ms(a, b) if c_groups else events[i][a].elapsed_time(events[i][b])
-    build_group_ms = float(np.mean([ev_ms(i, 0, 1) for i in group_firsts]))
+    build_group_ms = float(np.mean([ev_ms(i, 0, events[i].build_end if c_groups else 1) for i in group_firsts]))
     build_ms = build_group_ms / min(B, args.steps)
     if batched_eval:
         # one event pair per evaluation launch; a launch covers the frames of its group
@@ -1008,6 +1019,8 @@ def main():
             "host": {"group_call": args.group_call if shared_eval else "python", "us_per_group": host_s[0] / max(1, host_s[1]) * 1e6,
                      "groups_timed": host_s[1]},
             "phases_ms": {"build_per_frame_batched": build_ms, "build_batch": build_group_ms,
+                          # (a run of one group has no event between its builds and its packing kernel: see RawEvents)
+                          "build_batch_includes_packing_kernel": bool(c_groups and args.steps <= B),
                           "evaluate": eval_ms, "single_cook_latency": latency_ms, "single_build": single_build_ms,
                           # PCIe-inclusive, through the cook mirror on page-locked arrays; never `value`
                           "end_to_end_host_cook": host_cook["rebuild"] if host_cook else None,

@@ -284,6 +284,245 @@ __device__ __forceinline__ double4_t factor_invert_tile(double4_t Tt, int lane, 
     return U;
 }
 
+// ---- one 16 x 16 tile of K in the accumulator layout: e[i] of lane (c, g) = phi(|c_row - c_col|^2) (+ lambda on the diagonal) at
+// row 16 I + g + 4 i, column 16 J + c; zero outside the M x M matrix.  Beside it the largest |element| and whether two different
+// centres coincide (-> -5).
+__device__ __forceinline__ void assemble_tile(const double *cen, int I, int J, int c, int g, int M, int kind, double lambda, double inv_r2,
+                                              double (&e)[4], double &amax_w, bool &dup)
+{
+    const int col = 16 * J + c;
+    const double cx = cen[3 * col], cy = cen[3 * col + 1], cz = cen[3 * col + 2];
+    double d2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 16 * I + g + 4 * i;
+        const double dx = cen[3 * row] - cx, dy = cen[3 * row + 1] - cy, dz = cen[3 * row + 2] - cz;
+        d2[i] = dx * dx + dy * dy + dz * dz;
+    }
+    if (kind == FD_KERNEL_THIN_PLATE) {
+        // (no branch around the logarithm: four independent chains the scheduler can interleave; d2 = 0 -- the
+        // diagonal, padding, coincident centres -- goes through as 1 and is zeroed by the select)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool pos = d2[i] > 0.0;
+            const double lg = log_pos(pos ? d2[i] : 1.0);
+            e[i] = pos ? 0.5 * d2[i] * lg : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = phi_reg(kind, d2[i], inv_r2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 16 * I + g + 4 * i;
+        const bool real = row < M && col < M;
+        if (row == col) e[i] += lambda;
+        else if (d2[i] == 0.0 && real) dup = true;                 // coincident centres -> -5
+        if (!real) e[i] = 0.0;
+        const double ae = fabs(e[i]);
+        amax_w = ae > amax_w ? ae : amax_w;
+    }
+}
+
+// ---- the reflectors of P = [1 x y z] with f <- Q^T f folded in, the compact WY factor: ONE wave, four rows per lane, every sum a
+// DPP reduction, no workgroup barrier.  In: L.cen (centres), L.F (the three right-hand sides), rows M .. 255 zero.  Out: L.V
+// (reflectors), L.F (Q^T f with the pivot rows' shares aside in L.small[kG..]), L.small (tau, R, Tm), L.stat[3] (P rank-deficient).
+__device__ __forceinline__ void reflect_wave(const RegLds &L, int M, int T, int lane)
+{
+    // ---- meanwhile, wave 7: reflectors of P = [1 x y z] (dlarfg upside down: reflector k acts on rows 0 .. M-1-k, beta in
+    // row M-1-k) with f <- Q^T f folded into the same sweep: four rows per lane, every sum a DPP reduction, no barrier.
+    bool singular = false;
+    double cn[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        if (i < M) {
+            const double p[4] = {1.0, L.cen[3 * i], L.cen[3 * i + 1], L.cen[3 * i + 2]};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double v = t < T ? p[t] : 0.0;
+                L.V[4 * i + t] = v;
+                cn[t] = fma(v, v, cn[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cn[t] = wave_sum(cn[t]);
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= T) break;
+        const int piv = M - 1 - k;
+        // sigma, x . column c (c > k), x . f_c over the rows above the pivot
+        double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double x[4], fr[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            x[q] = 0.0; fr[q][0] = fr[q][1] = fr[q][2] = 0.0;
+            if (i < piv) {
+                x[q] = L.V[4 * i + k];
+                acc[0] = fma(x[q], x[q], acc[0]);
+#pragma unroll
+                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) acc[cc - k] = fma(x[q], L.V[4 * i + cc], acc[cc - k]);
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { fr[q][e] = L.F[e * kRows + i]; acc[4 + e] = fma(x[q], fr[q][e], acc[4 + e]); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 7; ++e) acc[e] = wave_sum(acc[e]);
+        const double xp = L.V[4 * piv + k];
+        const double sigma = acc[0];
+        const double norm = sqrt(fma(xp, xp, sigma));
+        double beta = xp, tau = 0.0, scale = 0.0;
+        if (sigma > 0.0) {
+            beta = xp >= 0.0 ? -norm : norm;
+            tau = (beta - xp) / beta;
+            scale = 1.0 / (xp - beta);
+        }
+        if (!(norm > 64.0 * (double)M * kEps * sqrt(cn[k]))) singular = true;   // P has no full column rank (NaN too)
+        double sc[4] = {0.0, 0.0, 0.0, 0.0}, prow[4] = {0.0, 0.0, 0.0, 0.0}, df[3];
+#pragma unroll
+        for (int cc = k + 1; cc < 4; ++cc) if (cc < T) { prow[cc] = L.V[4 * piv + cc]; sc[cc] = fma(scale, acc[cc - k], prow[cc]); }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) df[e] = fma(scale, acc[4 + e], L.F[e * kRows + piv]);       // v . f_e (v_piv = 1)
+        wave_lds_sync();                      // everyone has read the pivot row
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i < piv) {
+                const double v = x[q] * scale;
+                L.V[4 * i + k] = v;
+#pragma unroll
+                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) L.V[4 * i + cc] = fma(-tau * sc[cc], v, L.V[4 * i + cc]);
+#pragma unroll
+                for (int e = 0; e < 3; ++e) L.F[e * kRows + i] = fma(-tau * df[e], v, fr[q][e]);
+            }
+        }
+        if (lane == 0) {
+            L.small[kTau + k] = tau;
+            L.small[kR + 4 * k + k] = beta;
+            L.V[4 * piv + k] = 1.0;
+#pragma unroll
+            for (int cc = k + 1; cc < 4; ++cc) if (cc < T) {
+                L.small[kR + 4 * k + cc] = fma(-tau, sc[cc], prow[cc]);
+                L.V[4 * piv + cc] = 0.0;
+            }
+            // the pivot row's share of Q^T f belongs to the polynomial equations: aside, and zero in the Cholesky's right-hand side
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { L.small[kG + 3 * k + e] = fma(-tau, df[e], L.F[e * kRows + piv]); L.F[e * kRows + piv] = 0.0; }
+        }
+        wave_lds_sync();
+    }
+    // compact WY factor from the Gram matrix of V
+    double gram[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        if (i < M) {
+            const double v0 = L.V[4 * i], v1 = L.V[4 * i + 1], v2 = L.V[4 * i + 2], v3 = L.V[4 * i + 3];
+            gram[0] = fma(v0, v1, gram[0]); gram[1] = fma(v0, v2, gram[1]); gram[2] = fma(v0, v3, gram[2]);
+            gram[3] = fma(v1, v2, gram[3]); gram[4] = fma(v1, v3, gram[4]); gram[5] = fma(v2, v3, gram[5]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) gram[e] = wave_sum(gram[e]);
+    {
+        // (fully unrolled on purpose: a small matrix indexed by run-time loop counters lives in scratch memory)
+        const double G[4][4] = {{0.0, gram[0], gram[1], gram[2]}, {0.0, 0.0, gram[3], gram[4]}, {0.0, 0.0, 0.0, gram[5]}, {0.0, 0.0, 0.0, 0.0}};
+        double Tm[4][4] = {};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double tau = k < T ? L.small[kTau + k] : 0.0;
+            Tm[k][k] = tau;
+#pragma unroll
+            for (int a = 0; a < k; ++a) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = a; b < k; ++b) v = fma(Tm[a][b], G[b][k], v);
+                Tm[a][k] = -tau * v;
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) L.small[kTm + 4 * a + b] = Tm[a][b];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k >= T) L.small[kTau + k] = 0.0;
+            L.stat[3] = singular ? 1.0 : 0.0;
+        }
+    }
+}
+
+// ---- G = Tm^T sym(V^T Y) Tm (4 x 4, symmetric) from L.V, L.W (= Y) and L.small[kTm..] into L.small[kGm..]: one wave
+__device__ __forceinline__ void gram_wave(const RegLds &L, int M, int lane)
+{
+    double Sm[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Sm[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        if (i < M) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) Sm[4 * a + b] = fma(L.V[4 * i + a], L.W[4 * i + b], Sm[4 * a + b]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Sm[q] = wave_sum(Sm[q]);
+    double Tm[16], ST[16], Gm[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Tm[q] = L.small[kTm + q];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double v = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) v = fma(0.5 * (Sm[4 * a + cc] + Sm[4 * cc + a]), Tm[4 * cc + b], v);
+            ST[4 * a + b] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double v = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) v = fma(Tm[4 * cc + a], ST[4 * cc + b], v);
+            Gm[4 * a + b] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) { const double m = 0.5 * (Gm[4 * a + b] + Gm[4 * b + a]); Gm[4 * a + b] = m; Gm[4 * b + a] = m; }
+    if (lane < 16) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v = lane == q ? Gm[q] : v;
+        L.small[kGm + lane] = v;
+    }
+}
+
+// ---- row i of W = Y Tm - (1/2) V G, in place over Y
+__device__ __forceinline__ void w_row(const RegLds &L, int i)
+{
+    double y[4], v[4], w[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { y[t] = L.W[4 * i + t]; v[t] = L.V[4 * i + t]; }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double z = 0.0, h = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { z = fma(y[a], L.small[kTm + 4 * a + b], z); h = fma(v[a], L.small[kGm + 4 * a + b], h); }
+        w[b] = fma(-0.5, h, z);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) L.W[4 * i + t] = w[t];
+}
+
 // Which worker holds tile (I, J) of the lower triangle.  Column J is dealt round-robin from a per-column offset, and diagonal
 // tile (J, J) sits with the tile left of it, (J, J - 1): in the factorisation that wave solves (J, J - 1) first, applies it
 // to the diagonal tile at once and hands that to the factor wave, which then works beside everything else of the step.
@@ -308,6 +547,217 @@ constexpr size_t kFacL = 0, kFacMinv = (size_t)kFacTiles * 256, kFacV = kFacMinv
                  kFacSmall = kFacB21 + 4 * kRows, kFacMeta = kFacSmall + kSmallDoubles, kFacDoubles = kFacMeta + 8;
 // meta: [0] amax, [1] coincident centres, [2] singular (pivot / rank of P / spin time-out), [3] smallest pivot, [4] largest pivot
 
+// ---- the parallel front end (round 4).  Up to the projected matrix B = Q^T K Q nothing in the build is sequential: 136 tiles of
+// phi, Y = K V and the rank-8 rotation are 70 of k_build_reg's 197 us on ONE CU -- chains of LDS round trips per tile -- while in
+// the unpipelined cook 236 CUs idle.  Two short launches over (tiles, models) do that part; the factorisation, the substitutions, the
+// recovery and the packing stay in the register-resident workgroup (k_build_reg<false>), which starts from the B tiles in L2.
+//   k_reg_front1  (ceil(tiles / 7), 1, models) x 512 threads: control table; waves 0..6 ONE tile of K each -> the staging buffer
+//                 (slot.A: [tile][register][lane], as ever) + the tile's largest |element| and coincidence flag; wave 7 the
+//                 reflectors (every workgroup for itself: 4 us of latency, not of throughput); then the tile's two 16 x 4 shares
+//                 of Y = K V on the matrix pipe -> front buffer.  Workgroup 0 also leaves V, Q^T f and the small matrices there.
+//   k_reg_front2  (ceil(tiles / 8), 1, models) x 512 threads: Y summed in a fixed order (deterministic), G and W = Y Tm - V G / 2
+//                 (every workgroup for itself), then a tile per wave: B = K - V W^T - W V^T in place, B21 aside, identity padding.
+// The front buffer is the context's null-space scratch (slot.ns), which this path does not otherwise use.
+constexpr int kFront1Tiles = kWorkers;     // tiles per workgroup of k_reg_front1 (wave 7 runs the reflectors)
+constexpr int kFront2Tiles = kRegWaves;    // ... of k_reg_front2
+constexpr size_t kFrV = 0, kFrF = 4 * kRows, kFrB21 = 7 * kRows, kFrSmall = 11 * kRows, kFrMeta = kFrSmall + kSmallDoubles,
+                 kFrTile = kFrMeta + 8, kFrY = kFrTile + 2 * (size_t)(kMaxBlocks * (kMaxBlocks + 1) / 2);
+// meta: [0] largest |element| of K, [1] coincident centres, [2] P rank-deficient
+__host__ __device__ inline size_t reg_front_doubles(int M)
+{
+    const int nbk = (M + 15) / 16;
+    return kFrY + (size_t)(nbk * (nbk + 1) / 2) * 128;
+}
+__device__ __forceinline__ int tile_number(int I, int J, int nbk) { return J * nbk - J * (J - 1) / 2 + (I - J); }     // column-major, lower triangle
+
+__global__ __launch_bounds__(kRegThreads) void k_reg_front1(const BatchSlot *tab, const PointSrc src, int use_src, int M, int T, int kind,
+                                                             double lambda, double gauss_R)
+{
+    const BatchSlot &slot = tab[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) double s_mem[10 * kRows + kSmallDoubles + 8 + kWorkers * kTileLds];
+    RegLds L{};
+    L.cen = s_mem; L.V = L.cen + 3 * kRows; L.F = L.V + 4 * kRows; L.small = L.F + 3 * kRows; L.stat = L.small + kSmallDoubles; L.scr = L.stat + 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int nbk = (M + 15) / 16, ntiles = nbk * (nbk + 1) / 2;
+    const bool first = blockIdx.x == 0;
+    {
+        // control table (reference :268-287, widened to fp64); workgroup 0 leaves the context its copies
+        const float *rest = use_src ? src.rest[blockIdx.z] : slot.rest;
+        const float *delta = use_src ? src.delta[blockIdx.z] : slot.delta;
+        for (int i = tid; i < M; i += kRegThreads) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float r = rest[3 * i + q], d = delta[3 * i + q];
+                L.cen[3 * i + q] = (double)r;
+                L.F[q * kRows + i] = (double)d;
+                if (first) {
+                    slot.centres[3 * i + q] = (double)r;
+                    if (use_src) { slot.rest[3 * i + q] = r; slot.delta[3 * i + q] = d; }
+                }
+            }
+            if (first) slot.radii[i] = gauss_R;
+        }
+        for (int e = tid; e < 4 * kRows; e += kRegThreads) {
+            if (e >= 4 * M || T == 0) L.V[e] = 0.0;
+            if (e < 3 * kRows && e % kRows >= M) L.F[e] = 0.0;
+            if (e < 3 * kRows && e >= 3 * M) L.cen[e] = 0.0;
+        }
+        if (tid < kSmallDoubles) L.small[tid] = 0.0;
+        if (tid == 0) L.stat[3] = 0.0;
+    }
+    __syncthreads();
+    gdouble *fr = as_global(slot.ns);
+    double e[4] = {0.0, 0.0, 0.0, 0.0};
+    int I = 0, J = 0;
+    const int q = (int)blockIdx.x * kFront1Tiles + wave;
+    const bool have = wave < kWorkers && q < ntiles;
+    if (have) {
+        int r = q;
+        while (r >= nbk - J) { r -= nbk - J; ++J; }
+        I = J + r;
+        double amax_w = 0.0;
+        bool dup = false;
+        assemble_tile(L.cen, I, J, c, g, M, kind, lambda, 1.0 / (gauss_R * gauss_R), e, amax_w, dup);
+        gdouble *stage = as_global(slot.A);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage[((size_t)q * 4 + i) * 64 + lane] = e[i];
+        amax_w = wave_max(amax_w);
+        const bool any_dup = __any(dup);
+        if (lane == 0) { fr[kFrTile + 2 * q] = amax_w; fr[kFrTile + 2 * q + 1] = any_dup ? 1.0 : 0.0; }
+    } else if (wave == kWorkers && T > 0) {
+        reflect_wave(L, M, T, lane);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (have && T > 0) {
+        // the tile's shares of Y = K V.  In the accumulator layout it IS the A operand of K_IJ^T Z (slice s = rows 4 s .. 4 s + 3):
+        // block J's share from block I; block I's share from block J needs the tile itself as the operand: through LDS.
+        gdouble *yq = fr + kFrY + (size_t)q * 128;
+        double *sb = L.scr + (size_t)wave * kTileLds;
+        if (I != J) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sb[(g + 4 * i) * kPitch + c] = e[i];
+        }
+        {
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double b = c < 4 ? L.V[4 * (16 * I + 4 * s + g) + c] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[s], b, acc, 0, 0, 0);
+            }
+            if (c < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yq[(g + 4 * i) * 4 + c] = acc[i];
+            }
+        }
+        if (I != J) {
+            wave_lds_sync();
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double a = sb[c * kPitch + 4 * s + g];
+                const double b = c < 4 ? L.V[4 * (16 * J + 4 * s + g) + c] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            if (c < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yq[64 + (g + 4 * i) * 4 + c] = acc[i];
+            }
+        }
+    }
+    if (first && wave == kWorkers) {
+        for (int x = lane; x < 4 * kRows; x += 64) fr[kFrV + x] = L.V[x];
+        for (int x = lane; x < 3 * kRows; x += 64) fr[kFrF + x] = L.F[x];
+        for (int x = lane; x < kSmallDoubles; x += 64) fr[kFrSmall + x] = L.small[x];
+        if (lane == 0) fr[kFrMeta + 2] = L.stat[3];
+    }
+}
+
+__global__ __launch_bounds__(kRegThreads) void k_reg_front2(const BatchSlot *tab, int M, int T)
+{
+    const BatchSlot &slot = tab[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) double s_mem[8 * kRows + kSmallDoubles];
+    RegLds L{};
+    L.V = s_mem; L.W = L.V + 4 * kRows; L.small = L.W + 4 * kRows;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int n1 = M - T;
+    const int nbk = (M + 15) / 16, ntiles = nbk * (nbk + 1) / 2;
+    gdouble *fr = as_global(slot.ns);
+    for (int x = tid; x < 4 * kRows; x += kRegThreads) {
+        L.V[x] = fr[kFrV + x];
+        // Y, a fixed order of the tiles' shares per row: the tiles of tile row r left of the diagonal, the diagonal, those below it
+        const int i = x >> 2, t = x & 3, r = i >> 4, row = i & 15;
+        double y = 0.0;
+        if (T > 0 && r < nbk) {
+            // (all sixteen loads requested before the first add: one round trip to L2, not sixteen)
+            gcdouble *yp = fr + kFrY + row * 4 + t;
+            double v[kMaxBlocks];
+#pragma unroll
+            for (int k = 0; k < kMaxBlocks; ++k) {
+                const int kk = k < nbk ? k : nbk - 1;
+                const size_t at = kk < r ? (size_t)tile_number(r, kk, nbk) * 128 + 64 : (size_t)tile_number(kk, r, nbk) * 128;
+                v[k] = yp[at];
+            }
+#pragma unroll
+            for (int k = 0; k < kMaxBlocks; ++k) y += k < nbk ? v[k] : 0.0;
+        }
+        L.W[x] = y;
+    }
+    if (tid < kSmallDoubles) L.small[tid] = fr[kFrSmall + tid];
+    if (blockIdx.x == 0 && wave == 1) {
+        // the matrix' largest |element| and the coincidence flag from the tiles' (maxima: the order does not matter)
+        double amax = 0.0, dup = 0.0;
+        for (int q = lane; q < ntiles; q += 64) {
+            const double a = fr[kFrTile + 2 * q], d = fr[kFrTile + 2 * q + 1];
+            amax = a > amax ? a : amax; dup = d > dup ? d : dup;
+        }
+        amax = wave_max(amax); dup = wave_max(dup);
+        if (lane == 0) { fr[kFrMeta + 0] = amax; fr[kFrMeta + 1] = dup; }
+    }
+    __syncthreads();
+    if (T > 0) {
+        if (wave == 0) gram_wave(L, M, lane);
+        __syncthreads();
+        if (tid < kRows) w_row(L, tid);
+        __syncthreads();
+    }
+    const int q = (int)blockIdx.x * kFront2Tiles + wave;
+    if (q >= ntiles) return;
+    int I = 0, J = 0;
+    {
+        int r = q;
+        while (r >= nbk - J) { r -= nbk - J; ++J; }
+        I = J + r;
+    }
+    gdouble *stage = as_global(slot.A);
+    double4_t S;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[i] = stage[((size_t)q * 4 + i) * 64 + lane];
+    if (T > 0) {
+        // B = K - V W^T - W V^T (two K = 4 matrix instructions)
+        const int ri = 16 * I + c, rj = 16 * J + c;
+        const double vi = L.V[4 * ri + g], wi = L.W[4 * ri + g];
+        const double vj = L.V[4 * rj + g], wj = L.W[4 * rj + g];
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-vi, wj, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi, vj, S, 0, 0, 0);
+    }
+    // B21 aside (pivot row M-1-k = equation of polynomial coefficient k), identity padding beyond n1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 16 * I + g + 4 * i, col = 16 * J + c;
+        if (row >= n1 && row < M && col < n1) fr[kFrB21 + 4 * col + (M - 1 - row)] = S[i];
+        if (row >= n1 || col >= n1) S[i] = row == col ? 1.0 : 0.0;
+        stage[((size_t)q * 4 + i) * 64 + lane] = S[i];
+    }
+}
+
+// FRONT: the whole build in this one workgroup (the round-3 form; the shared-factor group's first frame and hosts that ask for it);
+// !FRONT: behind k_reg_front1 / k_reg_front2 -- the tiles of B, V, Q^T f, B21 and the small matrices come from L2.
+template <bool FRONT>
 __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab, const PointSrc src, int use_src, int M, int T, int npad,
                                                             int kind, int Mpad, double lambda, double gauss_R, unsigned long long *stamps,
                                                             double *fac)
@@ -349,7 +799,16 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         }
         nmine = __builtin_amdgcn_readfirstlane(nmine);
     }
-    {
+    if constexpr (!FRONT) {
+        // V, Q^T f, B21 and the small matrices as the front end left them (k_reg_front1 / k_reg_front2)
+        gcdouble *fr = as_global(slot.ns);
+        for (int e = tid; e < 4 * kRows; e += kRegThreads) {
+            L.V[e] = fr[kFrV + e];
+            L.B21[e] = fr[kFrB21 + e];
+            if (e < 3 * kRows) L.F[e] = fr[kFrF + e];
+            if (e < kSmallDoubles) L.small[e] = fr[kFrSmall + e];
+        }
+    } else {
         const float *rest = use_src ? src.rest[blockIdx.z] : slot.rest;
         const float *delta = use_src ? src.delta[blockIdx.z] : slot.delta;
         for (int i = tid; i < M; i += kRegThreads) {
@@ -370,7 +829,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             if (e < 3 * kRows && e >= 3 * M) L.cen[e] = 0.0;
         }
     }
-    if (tid == 0) { L.stat[0] = INFINITY; L.stat[1] = 0.0; L.stat[2] = 0.0; L.stat[3] = 0.0; L.flag[0] = 0; L.flag[1] = 0; L.flag[2] = 0; L.flag[3] = 0; }
+    if (tid == 0) { L.stat[0] = INFINITY; L.stat[1] = 0.0; L.stat[2] = 0.0; L.stat[3] = FRONT ? 0.0 : as_global(slot.ns)[kFrMeta + 2]; L.flag[0] = 0; L.flag[1] = 0; L.flag[2] = 0; L.flag[3] = 0; }
     __syncthreads();
     // Lane t of `ijv` holds the coordinates of the wave's slot t (I | J << 8; 0xffff: no tile).  Which slots a phase touches
     // is ONE ballot over that register (a bit mask, then a bit test per slot); a slot's coordinates come out with one
@@ -388,6 +847,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
 #define FD_SLOT(m, t) (((m) >> (t)) & 1u)
     FD_RSTAMP()
 
+    if constexpr (FRONT) {
     if (worker) {
         // ---- K, tile by tile: element (16 I + g + 4 i, 16 J + c) = phi(|c_row - c_col|^2) (+ lambda on the diagonal).  A ROLLED
         // loop (one copy of the logarithm) that writes the tiles to a staging area -- the context's matrix buffer, which this
@@ -402,37 +862,10 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         for (int t = 0; t < nmine; ++t) {
             const int ij = __builtin_amdgcn_readfirstlane(L.tab[wave * kSlots + t]);
             const int I = ij & 0xff, J = (ij >> 8) & 0xff, q = ij >> 16;
-            const int col = 16 * J + c;
-            const double cx = L.cen[3 * col], cy = L.cen[3 * col + 1], cz = L.cen[3 * col + 2];
-            double d2[4], e[4];
+            double e[4];
+            assemble_tile(L.cen, I, J, c, g, M, kind, lambda, inv_r2, e, amax_w, dup);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = 16 * I + g + 4 * i;
-                const double dx = L.cen[3 * row] - cx, dy = L.cen[3 * row + 1] - cy, dz = L.cen[3 * row + 2] - cz;
-                d2[i] = dx * dx + dy * dy + dz * dz;
-            }
-            if (kind == FD_KERNEL_THIN_PLATE) {
-                // (no branch around the logarithm: four independent chains the scheduler can interleave; d2 = 0 -- the
-                // diagonal, padding, coincident centres -- goes through as 1 and is zeroed by the select)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool pos = d2[i] > 0.0;
-                    const double lg = log_pos(pos ? d2[i] : 1.0);
-                    e[i] = pos ? 0.5 * d2[i] * lg : 0.0;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) e[i] = phi_reg(kind, d2[i], inv_r2);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 16 * I + g + 4 * i;
-                const bool real = row < M && col < M;
-                if (row == col) e[i] += lambda;
-                else if (d2[i] == 0.0 && real) dup = true;                 // coincident centres -> -5
-                if (!real) e[i] = 0.0;
-                const double ae = fabs(e[i]);
-                amax_w = ae > amax_w ? ae : amax_w;
                 stage[((size_t)q * 4 + i) * 64 + lane] = e[i];
             }
         }
@@ -440,138 +873,21 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         const bool any_dup = __any(dup);
         if (lane == 0) { L.ypart[wave] = amax_w; L.ypart[kRegWaves + wave] = any_dup ? 1.0 : 0.0; }      // (the overlay is free until Y = K V)
     } else if (T > 0) {
-        // ---- meanwhile, wave 7: reflectors of P = [1 x y z] (dlarfg upside down: reflector k acts on rows 0 .. M-1-k, beta in
-        // row M-1-k) with f <- Q^T f folded into the same sweep: four rows per lane, every sum a DPP reduction, no barrier.
-        bool singular = false;
-        double cn[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = lane + 64 * q;
-            if (i < M) {
-                const double p[4] = {1.0, L.cen[3 * i], L.cen[3 * i + 1], L.cen[3 * i + 2]};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const double v = t < T ? p[t] : 0.0;
-                    L.V[4 * i + t] = v;
-                    cn[t] = fma(v, v, cn[t]);
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) cn[t] = wave_sum(cn[t]);
-        wave_lds_sync();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k >= T) break;
-            const int piv = M - 1 - k;
-            // sigma, x . column c (c > k), x . f_c over the rows above the pivot
-            double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            double x[4], fr[4][3];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = lane + 64 * q;
-                x[q] = 0.0; fr[q][0] = fr[q][1] = fr[q][2] = 0.0;
-                if (i < piv) {
-                    x[q] = L.V[4 * i + k];
-                    acc[0] = fma(x[q], x[q], acc[0]);
-#pragma unroll
-                    for (int cc = k + 1; cc < 4; ++cc) if (cc < T) acc[cc - k] = fma(x[q], L.V[4 * i + cc], acc[cc - k]);
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) { fr[q][e] = L.F[e * kRows + i]; acc[4 + e] = fma(x[q], fr[q][e], acc[4 + e]); }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 7; ++e) acc[e] = wave_sum(acc[e]);
-            const double xp = L.V[4 * piv + k];
-            const double sigma = acc[0];
-            const double norm = sqrt(fma(xp, xp, sigma));
-            double beta = xp, tau = 0.0, scale = 0.0;
-            if (sigma > 0.0) {
-                beta = xp >= 0.0 ? -norm : norm;
-                tau = (beta - xp) / beta;
-                scale = 1.0 / (xp - beta);
-            }
-            if (!(norm > 64.0 * (double)M * kEps * sqrt(cn[k]))) singular = true;   // P has no full column rank (NaN too)
-            double sc[4] = {0.0, 0.0, 0.0, 0.0}, prow[4] = {0.0, 0.0, 0.0, 0.0}, df[3];
-#pragma unroll
-            for (int cc = k + 1; cc < 4; ++cc) if (cc < T) { prow[cc] = L.V[4 * piv + cc]; sc[cc] = fma(scale, acc[cc - k], prow[cc]); }
-#pragma unroll
-            for (int e = 0; e < 3; ++e) df[e] = fma(scale, acc[4 + e], L.F[e * kRows + piv]);       // v . f_e (v_piv = 1)
-            wave_lds_sync();                      // everyone has read the pivot row
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = lane + 64 * q;
-                if (i < piv) {
-                    const double v = x[q] * scale;
-                    L.V[4 * i + k] = v;
-#pragma unroll
-                    for (int cc = k + 1; cc < 4; ++cc) if (cc < T) L.V[4 * i + cc] = fma(-tau * sc[cc], v, L.V[4 * i + cc]);
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) L.F[e * kRows + i] = fma(-tau * df[e], v, fr[q][e]);
-                }
-            }
-            if (lane == 0) {
-                L.small[kTau + k] = tau;
-                L.small[kR + 4 * k + k] = beta;
-                L.V[4 * piv + k] = 1.0;
-#pragma unroll
-                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) {
-                    L.small[kR + 4 * k + cc] = fma(-tau, sc[cc], prow[cc]);
-                    L.V[4 * piv + cc] = 0.0;
-                }
-                // the pivot row's share of Q^T f belongs to the polynomial equations: aside, and zero in the Cholesky's right-hand side
-#pragma unroll
-                for (int e = 0; e < 3; ++e) { L.small[kG + 3 * k + e] = fma(-tau, df[e], L.F[e * kRows + piv]); L.F[e * kRows + piv] = 0.0; }
-            }
-            wave_lds_sync();
-        }
-        // compact WY factor from the Gram matrix of V
-        double gram[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = lane + 64 * q;
-            if (i < M) {
-                const double v0 = L.V[4 * i], v1 = L.V[4 * i + 1], v2 = L.V[4 * i + 2], v3 = L.V[4 * i + 3];
-                gram[0] = fma(v0, v1, gram[0]); gram[1] = fma(v0, v2, gram[1]); gram[2] = fma(v0, v3, gram[2]);
-                gram[3] = fma(v1, v2, gram[3]); gram[4] = fma(v1, v3, gram[4]); gram[5] = fma(v2, v3, gram[5]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 6; ++e) gram[e] = wave_sum(gram[e]);
-        {
-            // (fully unrolled on purpose: a small matrix indexed by run-time loop counters lives in scratch memory)
-            const double G[4][4] = {{0.0, gram[0], gram[1], gram[2]}, {0.0, 0.0, gram[3], gram[4]}, {0.0, 0.0, 0.0, gram[5]}, {0.0, 0.0, 0.0, 0.0}};
-            double Tm[4][4] = {};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double tau = k < T ? L.small[kTau + k] : 0.0;
-                Tm[k][k] = tau;
-#pragma unroll
-                for (int a = 0; a < k; ++a) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int b = a; b < k; ++b) v = fma(Tm[a][b], G[b][k], v);
-                    Tm[a][k] = -tau * v;
-                }
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) L.small[kTm + 4 * a + b] = Tm[a][b];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (k >= T) L.small[kTau + k] = 0.0;
-                L.stat[3] = singular ? 1.0 : 0.0;
-            }
-        }
+        reflect_wave(L, M, T, lane);
     }
     __threadfence_block();
     __syncthreads();
+    }
     FD_RSTAMP()
     double amax = 0.0;
     bool dup_any = false;
+    if constexpr (FRONT) {
 #pragma unroll
-    for (int w = 0; w < kWorkers; ++w) { amax = L.ypart[w] > amax ? L.ypart[w] : amax; dup_any = dup_any || L.ypart[kRegWaves + w] != 0.0; }
+        for (int w = 0; w < kWorkers; ++w) { amax = L.ypart[w] > amax ? L.ypart[w] : amax; dup_any = dup_any || L.ypart[kRegWaves + w] != 0.0; }
+    } else {
+        amax = as_global(slot.ns)[kFrMeta + 0];
+        dup_any = as_global(slot.ns)[kFrMeta + 1] != 0.0;
+    }
     double4_t S[kSlots];
     {
         gcdouble *stage = as_global(slot.A);
@@ -585,6 +901,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             }
         }
     }
+    if constexpr (FRONT) {
     __syncthreads();                                 // (everybody has read the assembly's statistics out of the overlay)
     // per-wave partial sums of Y (every worker its own)
     double *yp = L.ypart + (size_t)wave * 4 * kRows;
@@ -649,69 +966,10 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
 
         // ---- G = Tm^T sym(V^T Y) Tm on wave 7; then W = Y Tm - (1/2) V G, a row per thread
         if (!worker) {
-            double Sm[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) Sm[q] = 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = lane + 64 * q;
-                if (i < M) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) Sm[4 * a + b] = fma(L.V[4 * i + a], L.W[4 * i + b], Sm[4 * a + b]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) Sm[q] = wave_sum(Sm[q]);
-            double Tm[16], ST[16], Gm[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) Tm[q] = L.small[kTm + q];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) v = fma(0.5 * (Sm[4 * a + cc] + Sm[4 * cc + a]), Tm[4 * cc + b], v);
-                    ST[4 * a + b] = v;
-                }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) v = fma(Tm[4 * cc + a], ST[4 * cc + b], v);
-                    Gm[4 * a + b] = v;
-                }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = a + 1; b < 4; ++b) { const double m = 0.5 * (Gm[4 * a + b] + Gm[4 * b + a]); Gm[4 * a + b] = m; Gm[4 * b + a] = m; }
-            if (lane < 16) {
-                double v = 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) v = lane == q ? Gm[q] : v;
-                L.small[kGm + lane] = v;
-            }
+            gram_wave(L, M, lane);
         }
         __syncthreads();
-        if (tid < kRows) {
-            const int i = tid;
-            double y[4], v[4], w[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { y[t] = L.W[4 * i + t]; v[t] = L.V[4 * i + t]; }
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                double z = 0.0, h = 0.0;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) { z = fma(y[a], L.small[kTm + 4 * a + b], z); h = fma(v[a], L.small[kGm + 4 * a + b], h); }
-                w[b] = fma(-0.5, h, z);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) L.W[4 * i + t] = w[t];
-        }
+        if (tid < kRows) w_row(L, tid);
         __syncthreads();
 
         // ---- B = K - V W^T - W V^T on the tiles in place (two K = 4 matrix instructions per tile)
@@ -737,6 +995,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 if (row >= n1 || col >= n1) S[t][i] = row == col ? 1.0 : 0.0;
             }
         }
+    }
     }
     {
         const unsigned m_d0 = slots_where(ivI == 0 && ivJ == 0);
@@ -1304,8 +1563,11 @@ hipError_t reg_build_init()
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
-    e = hipFuncSetAttribute((const void *)k_build_reg, hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute((const void *)k_build_reg<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(double) * reg_lds_doubles(16 * kMaxBlocks)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_build_reg<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(double) * reg_lds_doubles(16 * kMaxBlocks)));
     if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return e;
 }
@@ -1318,7 +1580,7 @@ hipError_t launch_build_reg_shared(const BuildBuffers &b, hipStream_t stream, co
     static const PointSrc none{};
     if (ev_mid) (void)hipEventRecord(ev_mid, stream);
     const size_t lds = sizeof(double) * reg_lds_doubles(b.M);
-    hipLaunchKernelGGL(k_build_reg, dim3(1, 1, 1), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,
+    hipLaunchKernelGGL(k_build_reg<true>, dim3(1, 1, 1), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,
                        b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, (unsigned long long *)nullptr, fac);
     if (b.nbatch > 1)
         hipLaunchKernelGGL(k_resolve_reg, dim3(1, 1, (unsigned)b.nbatch - 1), dim3(256), 0, stream, b.d_slots, src ? *src : none, src ? 1 : 0,
@@ -1339,7 +1601,20 @@ hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const Poi
     static const bool stamps_late = stamps_env && atoi(tuning_env("FD_REG_STAMPS")) == 2;      // 2: no read-back per launch (the pipeline stays a pipeline); the last launch's stamps at exit
     const bool want_stamps = stamps_env && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
     if (want_stamps && !d_stamps) { (void)hipMalloc((void **)&d_stamps, 96 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 96 * sizeof(unsigned long long)); }
-    hipLaunchKernelGGL(k_build_reg, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,
+    // The front end over all CUs (k_reg_front1 / k_reg_front2), then the factorisation in one workgroup per model.  (Tuning builds:
+    // FD_REG_SPLIT=0 keeps the whole build in the one workgroup, round 3's form.)
+    static const bool split_env = [] { const char *e = tuning_env("FD_REG_SPLIT"); return e == nullptr || atoi(e) != 0; }();
+    const bool split = split_env && b.reg_front != 0 && reg_front_doubles(b.M) <= ns_doubles(b.M);
+    if (split) {
+        const int nbk = (b.M + 15) / 16, ntiles = nbk * (nbk + 1) / 2;
+        hipLaunchKernelGGL(k_reg_front1, dim3((unsigned)((ntiles + kFront1Tiles - 1) / kFront1Tiles), 1, nbatch), dim3(kRegThreads), 0, stream, b.d_slots,
+                           src ? *src : none, src ? 1 : 0, b.M, b.T, b.kind, b.lambda, b.gauss_R);
+        hipLaunchKernelGGL(k_reg_front2, dim3((unsigned)((ntiles + kFront2Tiles - 1) / kFront2Tiles), 1, nbatch), dim3(kRegThreads), 0, stream, b.d_slots,
+                           b.M, b.T);
+        hipLaunchKernelGGL(k_build_reg<false>, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, none, 0, b.M, b.T,
+                           b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, want_stamps ? d_stamps : nullptr, (double *)nullptr);
+    } else
+    hipLaunchKernelGGL(k_build_reg<true>, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T,
                        b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, want_stamps ? d_stamps : nullptr, (double *)nullptr);
     if (want_stamps && d_stamps && stamps_late) {
         static bool registered = false;

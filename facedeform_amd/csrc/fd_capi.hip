@@ -158,6 +158,12 @@ struct fd_batch {
     bool prep_has_fall = false;
     hipEvent_t fallback_ev = nullptr;    // behind the per-frame launches when the shared launch does not apply
     hipEvent_t group_ev = nullptr;       // fd_batch_cook_group: behind the group's builds, for the evaluation stream
+    // fd_batch_cook_group with the evaluation on the build stream itself (one unpipelined group): stream order does what the
+    // events between build, packing and evaluation do across streams, and every event record is a barrier packet that keeps the
+    // queue idle for ~4 us.  `lean`: the build's end (ev1) and the packing's are not recorded where they happen; ev1 goes behind
+    // the evaluation (later than needed, never earlier), and "the models are consumed" is the evaluation's own event.
+    bool lean = false;
+    hipEvent_t consumed_override = nullptr;
     char err[512] = {0};
 };
 
@@ -637,6 +643,7 @@ static void fill_build_buffers(const fd_ctx *ctx, BuildBuffers &b)
     b.spd = use_spd(ctx) ? 1 : 0;
     b.small = ctx->solver == FD_SOLVER_ONE_WORKGROUP ? 1 : 0;
     b.reg = (b.spd && use_reg(ctx)) ? 1 : 0;
+    b.reg_front = 1;
     b.nopivot = use_nopivot(ctx) ? 1 : 0;
     b.aux_stream = nullptr;
     for (hipEvent_t &e : b.aux_events) e = nullptr;
@@ -1561,6 +1568,9 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     for (int i = 0; i < b->n; ++i)
         if (!use_nopivot(b->ctxs[i])) bb.nopivot = 0;
     if (bb.reg && reg_build_init() != hipSuccess) { (void)hipGetLastError(); bb.reg = 0; }
+    // a caller that leaves CUs to the builds (fd_batch_set_eval_cus below the device's count) runs them BESIDE evaluation launches:
+    // one workgroup per model then stays on those CUs; the front end's short wide launches would queue for CUs the evaluation holds
+    bb.reg_front = (b->eval_cus <= 0 || b->eval_cus >= (int)device_cus()) ? 1 : 0;
     static const bool no_groups = tuning_env("FD_NO_PANEL_PAIRS") != nullptr;
     bb.group_panels = (b->n >= 4 && !no_groups && !tuning_env("FD_LOOKAHEAD")) ? 1 : 0;
     if (make_lookahead(&b->lu_stream, b->lu_events)) {
@@ -1604,11 +1614,11 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
     b->last_shared_factor = shared_fac ? 1 : 0;
     FD_BHIP(hipEventRecord(b->ev0, stream));
     if (shared_fac) {
-        FD_BHIP(launch_build_reg_shared(bb, stream, &b->src, b->ev_mid, b->d_fac));
+        FD_BHIP(launch_build_reg_shared(bb, stream, &b->src, nullptr, b->d_fac));
         b->have_src = false;
     } else if (bb.reg) {
         // one launch, one workgroup per model, control table included
-        FD_BHIP(launch_build_reg(bb, stream, b->have_src ? &b->src : nullptr, b->ev_mid));
+        FD_BHIP(launch_build_reg(bb, stream, b->have_src ? &b->src : nullptr, nullptr));      // (no phases to split: the report's assembly time is 0)
         b->have_src = false;
     } else {
     // the control points are kernel arguments (they change every call), so k_prepare stays
@@ -1622,7 +1632,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         FD_BHIP(launch_build(bb, stream, b->ev_mid));
     }
     }
-    FD_BHIP(hipEventRecord(b->ev1, stream));
+    if (!b->lean) FD_BHIP(hipEventRecord(b->ev1, stream));      // (lean: fd_batch_cook_group records it behind the evaluation)
     b->waited_stream = nullptr;
 #undef FD_BHIP
     static uint64_t build_ids = 0;
@@ -1631,7 +1641,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         fd_ctx *c = b->ctxs[i];
         c->rig_build_id = this_build;
         c->wait_event = b->ev1; c->wait_stream = stream; c->wait_batch = b;
-        c->tev0 = b->ev0; c->tev_mid = b->ev_mid; c->tev1 = b->ev1;
+        c->tev0 = b->ev0; c->tev_mid = bb.reg ? b->ev0 : b->ev_mid; c->tev1 = b->ev1;
         c->have_factor = bb.ml_layers == 0;   // a batched build leaves a factorisation fd_set_deltas can reuse (not the multilayer model)
         c->factor_grouped = bb.group_panels != 0;
         c->last_spd = bb.spd != 0;
@@ -1803,7 +1813,9 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
     a.N = 1; a.Mpad = round_up(c0->M, kRecPad); a.nF = b->n; a.kind = ek; a.ctiles = c0->d_tiles16;
     a.falloff_out = d_falloff_out;
     int rc;
-    if ((rc = batch_poll(b))) return rc;           // before the ordering: a repaired model's rebuild is ordered with the rest
+    // (lean: the build's event is recorded behind the evaluation -- a query now would see the PREVIOUS build's completion; the
+    //  status arrives with the next call, and an evaluation of an unbuilt model passes its frame through: header)
+    if (!b->lean && (rc = batch_poll(b))) return rc;           // before the ordering: a repaired model's rebuild is ordered with the rest
     for (int i = 0; i < b->n; ++i) {
         fd_ctx *c = b->ctxs[i];
         a.rec32[i] = c->d_rec32; a.model[i] = c->d_model; a.P_out[i] = d_P_out[i]; a.centres[i] = c->d_centres;
@@ -1836,14 +1848,15 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
     }
     st.eval_pending = false;
     a.wtiles = st.d_wtiles; a.frames = st.d_frames;
-    a.packed_ev = make_event(&st.packed_ev) ? st.packed_ev : nullptr;
+    a.packed_ev = b->lean ? nullptr : (make_event(&st.packed_ev) ? st.packed_ev : nullptr);
+    b->consumed_override = nullptr;
     a.mode = 1;
     a.M = c0->M;
     if (b->h_mismatch && hipHostGetDevicePointer((void **)&a.mismatch, b->h_mismatch, 0) != hipSuccess) { (void)hipGetLastError(); a.mismatch = nullptr; }
     hipError_t e = launch_deform_shared(a, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_shared (pack) failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
     b->cur_set = si;
-    b->packed_valid = st.packed_ev != nullptr;
+    b->packed_valid = b->lean || st.packed_ev != nullptr;
     b->prepared = true;
     for (int i = 0; i < b->n; ++i) {
         b->prep_P_out[i] = d_P_out[i]; b->prep_fall[i] = d_falloff_out ? d_falloff_out[i] : nullptr;
@@ -1893,6 +1906,7 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
         if (rc == FD_OK && make_event(&b->fallback_ev)) {
             if (hipEventRecord(b->fallback_ev, stream) != hipSuccess) { (void)hipGetLastError(); rc = FD_E_DEVICE; }
             b->packed_valid = false;
+            b->consumed_override = nullptr;
         }
         return rc;
     }
@@ -1902,14 +1916,14 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
         reuse = b->prep_P_out[i] == d_P_out[i] && (!d_falloff_out || b->prep_fall[i] == d_falloff_out[i]) &&
                 b->prep_gen[i] == b->ctxs[i]->model_gen;          // a context rebuilt or re-imported on its own since: pack again
     if (reuse) {
-        if ((rc = batch_poll(b))) return rc;
+        if (!b->lean && (rc = batch_poll(b))) return rc;
         if (!b->prepared) reuse = false;         // the poll repaired a model: pack again (shared_pack orders the stream)
         for (int i = 0; reuse && i < b->n; ++i)
             if ((rc = order_after_batch(b->ctxs[i], stream))) { batch_err(b, "context %d: %s", i, b->ctxs[i]->err); return rc; }
     }
     if (reuse) {
         fd_batch::SharedSet &ps = b->sets[b->cur_set];
-        if (ps.packed_ev && hipStreamWaitEvent(stream, ps.packed_ev, 0) != hipSuccess) {
+        if (!b->lean && ps.packed_ev && hipStreamWaitEvent(stream, ps.packed_ev, 0) != hipSuccess) {
             batch_err(b, "fd_batch_deform_shared_dev: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
             return FD_E_DEVICE;
         }
@@ -1945,7 +1959,7 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
 int fd_batch_wait_consumed(fd_batch *b, void *hip_stream)
 {
     if (!b) return FD_E_INVALID;
-    hipEvent_t ev = b->packed_valid ? b->sets[b->cur_set].packed_ev : b->fallback_ev;
+    hipEvent_t ev = b->consumed_override ? b->consumed_override : (b->packed_valid ? b->sets[b->cur_set].packed_ev : b->fallback_ev);
     if (!ev) return FD_OK;          // no shared-rig evaluation enqueued: nothing reads the models beyond stream order
     fd_ctx *c0 = b->ctxs[0];
     int rc = use_device(c0);
@@ -1972,8 +1986,22 @@ int fd_batch_cook_group(fd_batch *b, void *build_stream, void *eval_stream, cons
     const float *rest[kMaxBatch];
     for (int i = 0; i < b->n; ++i) rest[i] = d_rest_xyz;
     if ((rc = fd_batch_set_points_dev(b, rest, d_delta_xyz, M))) return rc;
+    // one stream for everything: no event between the build, the packing and the evaluation (see fd_batch::lean)
+    const bool lean = es == bs;
+    struct LeanScope {
+        fd_batch *b; hipStream_t s; bool on, built = false;
+        ~LeanScope() {
+            if (!on) return;
+            // the build's end, as every waiter and the status poll know it: behind whatever of the group was enqueued
+            if (built && hipEventRecord(b->ev1, s) != hipSuccess) (void)hipGetLastError();
+            b->prepared = false;          // the set was packed without its event: a later call on another stream packs again
+            b->lean = false;
+        }
+    } scope{b, bs, lean};
+    b->lean = lean;
     if (events) mark(events->before_build, bs);
     if ((rc = fd_batch_build_async(b, build_stream))) return rc;
+    scope.built = true;
     if (events) mark(events->after_build, bs);
     if ((rc = fd_batch_prepare_shared(b, build_stream, d_P_out, d_falloff_out))) return rc;
     if (es != bs) {
@@ -1987,6 +2015,7 @@ int fd_batch_cook_group(fd_batch *b, void *build_stream, void *eval_stream, cons
     if (events) mark(events->before_eval, es);
     rc = fd_batch_deform_shared_dev(b, es, N, d_P_in, d_P_out, nullptr, d_falloff_out, nullptr, nullptr, nullptr, 1.0f, 1.0f);
     if (events) mark(events->after_eval, es);
+    if (lean && rc == FD_OK && b->packed_valid && b->sets[b->cur_set].eval_pending) b->consumed_override = b->sets[b->cur_set].eval_ev;
     return rc;
 }
 

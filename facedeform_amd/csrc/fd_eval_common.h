@@ -7,19 +7,7 @@
 namespace fd {
 namespace {
 
-// compute units of the current device (hipDeviceProp_t::multiProcessorCount: 256 on MI355X), looked up once per device
 constexpr unsigned kMaxCUs = 1024;     // bound of the diagnostics' per-CU tables
-inline unsigned device_cus()
-{
-    static unsigned cached[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256u; }
-    if (dev >= 0 && dev < 64 && cached[dev]) return cached[dev];
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
-    if (dev >= 0 && dev < 64) cached[dev] = (unsigned)n;
-    return (unsigned)n;
-}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

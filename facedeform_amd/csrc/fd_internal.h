@@ -130,6 +130,19 @@ struct BatchSlot {
                                       // posts terminationtype there itself, so a one-launch build needs no status kernel behind it
 };
 
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount: 256 on MI355X), looked up once per device
+inline unsigned device_cus()
+{
+    static unsigned cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256u; }
+    if (dev >= 0 && dev < 64 && cached[dev]) return cached[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    if (dev >= 0 && dev < 64) cached[dev] = (unsigned)n;
+    return (unsigned)n;
+}
+
 // Caller-owned device arrays of control points, one pair per model of a batch (kernel argument).
 struct PointSrc {
     const float *rest[kMaxBatch];
@@ -154,6 +167,10 @@ struct BuildBuffers {
     // -- no pivot search, so the panel is no longer one workgroup's serial chain.
     int small;                        // FD_SOLVER_ONE_WORKGROUP: k_build_small where it applies
     int reg;                          // the register-resident one-launch build (fd_build_reg.hip) where it applies: M <= 256 on the definite path
+    // ... with its parallel front end (k_reg_front1 / k_reg_front2 over all CUs, then the factorisation in one workgroup per model):
+    // shorter alone; 0 keeps the whole build in its one workgroup -- what a pipeline wants whose evaluation launches hold most CUs
+    // (fd_batch_set_eval_cus below the device's count: the builds then stay on the CUs left to them)
+    int reg_front;
     int spd;
     // QNN model, order <= 1024: the LU of its kernel block WITHOUT pivot search (fd_build.hip k_lu_panel_np); a multiplier
     // above kMaxMultiplier or a pivot below the threshold ends the build with -4 and the host repeats it with the pivoted LU.
