@@ -284,6 +284,24 @@ __device__ __forceinline__ double4_t factor_invert_tile(double4_t Tt, int lane, 
     return U;
 }
 
+// The packing's inputs out of this workgroup's LDS (fd_pack.h: PackGlobal reads the same doubles from global memory).  dlt == nullptr:
+// the deltas from the context's global copy (the one-workgroup form has no LDS left for them).
+constexpr int kAff = 64;                 // L.small[kAff + 3 k + e]: polynomial coefficient k of right-hand side e (recovery -> packing)
+struct PackLds {
+    const double *cen, *dlt, *sol, *aff;
+    const float *dl_global;
+    double R;
+    int sing, dup;
+    __device__ __forceinline__ double centre(int j, int q) const { return cen[3 * j + q]; }
+    __device__ __forceinline__ bool has_delta() const { return true; }
+    __device__ __forceinline__ double delta(int j, int q) const { return dlt ? dlt[3 * j + q] : (double)dl_global[3 * j + q]; }
+    __device__ __forceinline__ double weight(int j, int c) const { return sol[c * 256 + j]; }
+    __device__ __forceinline__ double affine(int cc, int k, int, int T) const { return k < T ? aff[3 * k + cc] : 0.0; }
+    __device__ __forceinline__ double radius(int) const { return R; }
+    __device__ __forceinline__ int sing_flag() const { return sing; }
+    __device__ __forceinline__ int dup_flag() const { return dup; }
+};
+
 // ---- one 16 x 16 tile of K in the accumulator layout: e[i] of lane (c, g) = phi(|c_row - c_col|^2) (+ lambda on the diagonal) at
 // row 16 I + g + 4 i, column 16 J + c; zero outside the M x M matrix.  Beside it the largest |element| and whether two different
 // centres coincide (-> -5).
@@ -570,8 +588,9 @@ __host__ __device__ inline size_t reg_front_doubles(int M)
 }
 __device__ __forceinline__ int tile_number(int I, int J, int nbk) { return J * nbk - J * (J - 1) / 2 + (I - J); }     // column-major, lower triangle
 
+constexpr int kFrontMaxTpw = 4;           // tiles per wave of the front-end launches: as many as keep the grid within the device's CUs
 __global__ __launch_bounds__(kRegThreads) void k_reg_front1(const BatchSlot *tab, const PointSrc src, int use_src, int M, int T, int kind,
-                                                             double lambda, double gauss_R)
+                                                             double lambda, double gauss_R, int tpw)
 {
     const BatchSlot &slot = tab[blockIdx.z];
     __shared__ __attribute__((aligned(16))) double s_mem[10 * kRows + kSmallDoubles + 8 + kWorkers * kTileLds];
@@ -609,61 +628,82 @@ __global__ __launch_bounds__(kRegThreads) void k_reg_front1(const BatchSlot *tab
     }
     __syncthreads();
     gdouble *fr = as_global(slot.ns);
-    double e[4] = {0.0, 0.0, 0.0, 0.0};
-    int I = 0, J = 0;
-    const int q = (int)blockIdx.x * kFront1Tiles + wave;
-    const bool have = wave < kWorkers && q < ntiles;
-    if (have) {
-        int r = q;
-        while (r >= nbk - J) { r -= nbk - J; ++J; }
-        I = J + r;
-        double amax_w = 0.0;
-        bool dup = false;
-        assemble_tile(L.cen, I, J, c, g, M, kind, lambda, 1.0 / (gauss_R * gauss_R), e, amax_w, dup);
+    // worker wave w takes tiles (blockIdx.x * tpw + t) * 7 + w, t < tpw (the batch's launches keep their grid within the device's
+    // CUs: a second workgroup on a CU shares its SIMDs with the first one's reflector wave, the launch's critical path)
+    double e[kFrontMaxTpw][4];
+    int tI[kFrontMaxTpw], tJ[kFrontMaxTpw];
+    bool have[kFrontMaxTpw];
+    if (wave < kWorkers) {
         gdouble *stage = as_global(slot.A);
+        const double inv_r2 = 1.0 / (gauss_R * gauss_R);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stage[((size_t)q * 4 + i) * 64 + lane] = e[i];
-        amax_w = wave_max(amax_w);
-        const bool any_dup = __any(dup);
-        if (lane == 0) { fr[kFrTile + 2 * q] = amax_w; fr[kFrTile + 2 * q + 1] = any_dup ? 1.0 : 0.0; }
-    } else if (wave == kWorkers && T > 0) {
-        reflect_wave(L, M, T, lane);
+        for (int t = 0; t < kFrontMaxTpw; ++t) {
+            const int q = ((int)blockIdx.x * tpw + t) * kFront1Tiles + wave;
+            have[t] = t < tpw && q < ntiles;
+            tI[t] = tJ[t] = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[t][i] = 0.0;
+            if (have[t]) {
+                int r = q, J = 0;
+                while (r >= nbk - J) { r -= nbk - J; ++J; }
+                tI[t] = J + r; tJ[t] = J;
+                double amax_w = 0.0;
+                bool dup = false;
+                assemble_tile(L.cen, tI[t], tJ[t], c, g, M, kind, lambda, inv_r2, e[t], amax_w, dup);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) stage[((size_t)q * 4 + i) * 64 + lane] = e[t][i];
+                amax_w = wave_max(amax_w);
+                const bool any_dup = __any(dup);
+                if (lane == 0) { fr[kFrTile + 2 * q] = amax_w; fr[kFrTile + 2 * q + 1] = any_dup ? 1.0 : 0.0; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < kFrontMaxTpw; ++t) have[t] = false;
+        if (T > 0) reflect_wave(L, M, T, lane);
     }
     __threadfence_block();
     __syncthreads();
-    if (have && T > 0) {
-        // the tile's shares of Y = K V.  In the accumulator layout it IS the A operand of K_IJ^T Z (slice s = rows 4 s .. 4 s + 3):
-        // block J's share from block I; block I's share from block J needs the tile itself as the operand: through LDS.
-        gdouble *yq = fr + kFrY + (size_t)q * 128;
-        double *sb = L.scr + (size_t)wave * kTileLds;
-        if (I != J) {
+    if (T > 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sb[(g + 4 * i) * kPitch + c] = e[i];
-        }
-        {
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < kFrontMaxTpw; ++t) {
+            if (!have[t]) continue;
+            // the tile's shares of Y = K V.  In the accumulator layout it IS the A operand of K_IJ^T Z (slice s = rows 4 s .. 4 s + 3):
+            // block J's share from block I; block I's share from block J needs the tile itself as the operand: through LDS.
+            const int q = ((int)blockIdx.x * tpw + t) * kFront1Tiles + wave;
+            const int I = tI[t], J = tJ[t];
+            gdouble *yq = fr + kFrY + (size_t)q * 128;
+            double *sb = L.scr + (size_t)wave * kTileLds;
+            if (I != J) {
+                wave_lds_sync();                     // (the previous tile's reads of the buffer)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double b = c < 4 ? L.V[4 * (16 * I + 4 * s + g) + c] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[s], b, acc, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) sb[(g + 4 * i) * kPitch + c] = e[t][i];
             }
-            if (c < 4) {
+            {
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) yq[(g + 4 * i) * 4 + c] = acc[i];
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const double b = c < 4 ? L.V[4 * (16 * I + 4 * s2 + g) + c] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[t][s2], b, acc, 0, 0, 0);
+                }
+                if (c < 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) yq[(g + 4 * i) * 4 + c] = acc[i];
+                }
             }
-        }
-        if (I != J) {
-            wave_lds_sync();
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            if (I != J) {
+                wave_lds_sync();
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double a = sb[c * kPitch + 4 * s + g];
-                const double b = c < 4 ? L.V[4 * (16 * J + 4 * s + g) + c] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
-            if (c < 4) {
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const double a = sb[c * kPitch + 4 * s2 + g];
+                    const double b = c < 4 ? L.V[4 * (16 * J + 4 * s2 + g) + c] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+                if (c < 4) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) yq[64 + (g + 4 * i) * 4 + c] = acc[i];
+                    for (int i = 0; i < 4; ++i) yq[64 + (g + 4 * i) * 4 + c] = acc[i];
+                }
             }
         }
     }
@@ -675,7 +715,7 @@ __global__ __launch_bounds__(kRegThreads) void k_reg_front1(const BatchSlot *tab
     }
 }
 
-__global__ __launch_bounds__(kRegThreads) void k_reg_front2(const BatchSlot *tab, int M, int T)
+__global__ __launch_bounds__(kRegThreads) void k_reg_front2(const BatchSlot *tab, int M, int T, int tpw)
 {
     const BatchSlot &slot = tab[blockIdx.z];
     __shared__ __attribute__((aligned(16))) double s_mem[8 * kRows + kSmallDoubles];
@@ -725,33 +765,35 @@ __global__ __launch_bounds__(kRegThreads) void k_reg_front2(const BatchSlot *tab
         if (tid < kRows) w_row(L, tid);
         __syncthreads();
     }
-    const int q = (int)blockIdx.x * kFront2Tiles + wave;
-    if (q >= ntiles) return;
-    int I = 0, J = 0;
-    {
-        int r = q;
-        while (r >= nbk - J) { r -= nbk - J; ++J; }
-        I = J + r;
-    }
     gdouble *stage = as_global(slot.A);
-    double4_t S;
+    for (int t = 0; t < tpw; ++t) {
+        const int q = ((int)blockIdx.x * tpw + t) * kFront2Tiles + wave;
+        if (q >= ntiles) break;
+        int I = 0, J = 0;
+        {
+            int r = q;
+            while (r >= nbk - J) { r -= nbk - J; ++J; }
+            I = J + r;
+        }
+        double4_t S;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) S[i] = stage[((size_t)q * 4 + i) * 64 + lane];
-    if (T > 0) {
-        // B = K - V W^T - W V^T (two K = 4 matrix instructions)
-        const int ri = 16 * I + c, rj = 16 * J + c;
-        const double vi = L.V[4 * ri + g], wi = L.W[4 * ri + g];
-        const double vj = L.V[4 * rj + g], wj = L.W[4 * rj + g];
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-vi, wj, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi, vj, S, 0, 0, 0);
-    }
-    // B21 aside (pivot row M-1-k = equation of polynomial coefficient k), identity padding beyond n1
+        for (int i = 0; i < 4; ++i) S[i] = stage[((size_t)q * 4 + i) * 64 + lane];
+        if (T > 0) {
+            // B = K - V W^T - W V^T (two K = 4 matrix instructions)
+            const int ri = 16 * I + c, rj = 16 * J + c;
+            const double vi = L.V[4 * ri + g], wi = L.W[4 * ri + g];
+            const double vj = L.V[4 * rj + g], wj = L.W[4 * rj + g];
+            S = __builtin_amdgcn_mfma_f64_16x16x4f64(-vi, wj, S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi, vj, S, 0, 0, 0);
+        }
+        // B21 aside (pivot row M-1-k = equation of polynomial coefficient k), identity padding beyond n1
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 16 * I + g + 4 * i, col = 16 * J + c;
-        if (row >= n1 && row < M && col < n1) fr[kFrB21 + 4 * col + (M - 1 - row)] = S[i];
-        if (row >= n1 || col >= n1) S[i] = row == col ? 1.0 : 0.0;
-        stage[((size_t)q * 4 + i) * 64 + lane] = S[i];
+        for (int i = 0; i < 4; ++i) {
+            const int row = 16 * I + g + 4 * i, col = 16 * J + c;
+            if (row >= n1 && row < M && col < n1) fr[kFrB21 + 4 * col + (M - 1 - row)] = S[i];
+            if (row >= n1 || col >= n1) S[i] = row == col ? 1.0 : 0.0;
+            stage[((size_t)q * 4 + i) * 64 + lane] = S[i];
+        }
     }
 }
 
@@ -807,6 +849,8 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             L.B21[e] = fr[kFrB21 + e];
             if (e < 3 * kRows) L.F[e] = fr[kFrF + e];
             if (e < kSmallDoubles) L.small[e] = fr[kFrSmall + e];
+            // (for the packing, in the same round trip: the centres, and the deltas where the transposition buffers would be)
+            if (e < 3 * M) { L.cen[e] = slot.centres[e]; L.scr[e] = (double)slot.delta[e]; }
         }
     } else {
         const float *rest = use_src ? src.rest[blockIdx.z] : slot.rest;
@@ -1297,6 +1341,16 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         for (int q = 0; q < 4; ++q) {
             const int i = lane + 64 * q;
             if (i < M) { X[i] = xr[q][0]; X[(size_t)npad + i] = xr[q][1]; X[2 * (size_t)npad + i] = xr[q][2]; }
+            // ... and where the packing reads it (y itself is used up: every lane has its rows in registers)
+            if (i < M) { L.Y[i] = xr[q][0]; L.Y[256 + i] = xr[q][1]; L.Y[512 + i] = xr[q][2]; }
+        }
+        if (lane < 12) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) v = lane == 3 * k + e ? a[k][e] : v;
+            L.small[kAff + lane] = v;
         }
         for (int r = M + lane; r < npad; r += 64) {
 #pragma unroll
@@ -1311,6 +1365,8 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             model->terminationtype = 0;
             model->dup_flag = dup_any ? 1 : 0;
             model->sing_flag = (L.stat[2] != 0.0 || L.stat[3] != 0.0) ? 1 : 0;
+            L.stat[4] = (L.stat[2] != 0.0 || L.stat[3] != 0.0) ? 1.0 : 0.0;
+            L.stat[5] = dup_any ? 1.0 : 0.0;
             model->iterations = M + T;
             model->amax_bits = (unsigned long long)__double_as_longlong(amax);
             model->pivmin_bits = (unsigned long long)__double_as_longlong(L.stat[0]);
@@ -1323,7 +1379,11 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     // ---- evaluation records, centre tiles, status: the packing code every build shares (written for 256 threads; the other
     // four waves are done -- a barrier counts the waves that have not ended)
     if (tid >= 256) return;
-    packing::pack_body(slot, npad, M, Mpad, T, kind, 0, 0);
+    {
+        const PackLds in{L.cen, FRONT ? nullptr : L.scr, L.Y, L.small + kAff, slot.delta, gauss_R, L.stat[4] != 0.0 ? 1 : 0, L.stat[5] != 0.0 ? 1 : 0};
+        packing::pack_body_from(in, slot, npad, M, Mpad, T, kind, 0, 0);
+    }
+    FD_RSTAMP()
     if (kind == FD_KERNEL_THIN_PLATE) {
         __syncthreads();
         for (int tile = tid >> 6; tile < Mpad / 16; tile += 4) packing::pack_tiles_body(slot, Mpad, tile, lane);
@@ -1607,10 +1667,19 @@ hipError_t launch_build_reg(const BuildBuffers &b, hipStream_t stream, const Poi
     const bool split = split_env && b.reg_front != 0 && reg_front_doubles(b.M) <= ns_doubles(b.M);
     if (split) {
         const int nbk = (b.M + 15) / 16, ntiles = nbk * (nbk + 1) / 2;
-        hipLaunchKernelGGL(k_reg_front1, dim3((unsigned)((ntiles + kFront1Tiles - 1) / kFront1Tiles), 1, nbatch), dim3(kRegThreads), 0, stream, b.d_slots,
-                           src ? *src : none, src ? 1 : 0, b.M, b.T, b.kind, b.lambda, b.gauss_R);
-        hipLaunchKernelGGL(k_reg_front2, dim3((unsigned)((ntiles + kFront2Tiles - 1) / kFront2Tiles), 1, nbatch), dim3(kRegThreads), 0, stream, b.d_slots,
-                           b.M, b.T);
+        // tiles per wave: the fewest that keep a launch's workgroups within the CUs (batches: a workgroup alone on its CU runs its
+        // serial wave -- reflectors, the 4 x 4 algebra -- at full speed; 20 models: 2 tiles per wave, 32: 3)
+        const int cus = (int)device_cus();
+        auto tiles_per_wave = [&](int per_wg) {
+            int tpw = 1;
+            while (tpw < kFrontMaxTpw && ((ntiles + per_wg * tpw - 1) / (per_wg * tpw)) * (int)nbatch > cus) ++tpw;
+            return tpw;
+        };
+        const int tpw1 = tiles_per_wave(kFront1Tiles), tpw2 = tiles_per_wave(kFront2Tiles);
+        hipLaunchKernelGGL(k_reg_front1, dim3((unsigned)((ntiles + kFront1Tiles * tpw1 - 1) / (kFront1Tiles * tpw1)), 1, nbatch), dim3(kRegThreads), 0, stream,
+                           b.d_slots, src ? *src : none, src ? 1 : 0, b.M, b.T, b.kind, b.lambda, b.gauss_R, tpw1);
+        hipLaunchKernelGGL(k_reg_front2, dim3((unsigned)((ntiles + kFront2Tiles * tpw2 - 1) / (kFront2Tiles * tpw2)), 1, nbatch), dim3(kRegThreads), 0, stream,
+                           b.d_slots, b.M, b.T, tpw2);
         hipLaunchKernelGGL(k_build_reg<false>, dim3(1, 1, nbatch), dim3(kRegThreads), lds, stream, b.d_slots, none, 0, b.M, b.T,
                            b.npad, b.kind, b.Mpad, b.lambda, b.gauss_R, want_stamps ? d_stamps : nullptr, (double *)nullptr);
     } else

@@ -44,6 +44,9 @@ __device__ __forceinline__ double block_max(double v, double *scratch, int tid)
 template <int N, bool MAX>
 __device__ __forceinline__ void block_reduce_many(double (&v)[N], double *scratch /* 4 N */, int tid)
 {
+    // (tried in round 4: the six butterfly steps outermost with all N exchanges of a step requested together, swizzles and quad
+    //  permutations instead of permutes -- the arrays went to scratch memory and the phase doubled; the values' chains below are
+    //  independent and the scheduler interleaves them as they stand)
 #pragma unroll
     for (int q = 0; q < N; ++q)
         for (int off = 32; off >= 1; off >>= 1) {
@@ -68,11 +71,34 @@ __device__ __forceinline__ void block_reduce_many(double (&v)[N], double *scratc
     }
 }
 
+// Where the packing reads its inputs.  PackGlobal: the build's arrays in global memory (every launch-chain build, imports).
+// PackLds (fd_build_reg.hip): the register build's workgroup has the same doubles in LDS when its last phase starts -- centres,
+// solution, polynomial coefficients, flags -- and every read from global memory there is a round trip to L2 on the build's
+// critical path (eight of them in a row, 2 000 cycles each, were half of that phase).  Same values, same order of operations:
+// the outputs are bit-identical whichever source is read.
+struct PackGlobal {
+    const double *X, *W, *centres, *radii;
+    const float *dl;
+    const DevModel *model;
+    int npad, from_w;
+    __device__ __forceinline__ double centre(int j, int q) const { return centres[3 * j + q]; }
+    __device__ __forceinline__ bool has_delta() const { return dl != nullptr; }
+    __device__ __forceinline__ double delta(int j, int q) const { return (double)dl[3 * j + q]; }
+    __device__ __forceinline__ double weight(int j, int c) const { return from_w ? W[3 * j + c] : X[(size_t)c * npad + j]; }
+    __device__ __forceinline__ double affine(int cc, int k, int M, int T) const
+    {
+        if (from_w) return W[3 * (M + k) + cc];
+        return k < T ? X[(size_t)cc * npad + M + k] : 0.0;
+    }
+    __device__ __forceinline__ double radius(int j) const { return radii[j]; }
+    __device__ __forceinline__ int sing_flag() const { return model->sing_flag; }
+    __device__ __forceinline__ int dup_flag() const { return model->dup_flag; }
+};
+
 // (256 threads; a kernel of its own in fd_build.hip, the last phase of the one-launch build in fd_nullspace.hip)
-__device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M, int Mpad, int T, int kind, int from_w, int layers)
+template <class Src>
+__device__ __forceinline__ void pack_body_from(const Src &in, const BatchSlot &slot, int npad, int M, int Mpad, int T, int kind, int from_w, int layers)
 {
-    const double *X = from_w ? nullptr : slot.X;
-    const double *centres = slot.centres, *radii = slot.radii;
     double *W = slot.W;
     Rec32 *rec32 = slot.rec32;
     Rec64 *rec64 = slot.rec64;
@@ -89,23 +115,23 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
     // ---- normalisation: x0 = centroid of the centres (0 if they already sit around the
     //      origin), s = power of two nearest to their largest distance from x0
     double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int j = tid; j < M; j += 256) { sx += centres[3 * j]; sy += centres[3 * j + 1]; sz += centres[3 * j + 2]; }
+    for (int j = tid; j < M; j += 256) { sx += in.centre(j, 0); sy += in.centre(j, 1); sz += in.centre(j, 2); }
     double csum[3] = {sx, sy, sz};
     block_reduce_many<3, false>(csum, s_red, tid);
     double cenx = csum[0] / M, ceny = csum[1] / M, cenz = csum[2] / M;
     double r2 = 0.0, r2o = 0.0;
     // (beside the extent: the largest and the smallest |delta_i| of the control table, for the fp32 estimate below;
     //  the smallest as a maximum of its negative)
-    const float *dl = from_w ? nullptr : slot.delta;
+    const bool dl = in.has_delta();
     double dmax2 = 0.0, ndmin2 = -INFINITY;
     for (int j = tid; j < M; j += 256) {
-        const double x = centres[3 * j], y = centres[3 * j + 1], z = centres[3 * j + 2];
+        const double x = in.centre(j, 0), y = in.centre(j, 1), z = in.centre(j, 2);
         const double d = (x - cenx) * (x - cenx) + (y - ceny) * (y - ceny) + (z - cenz) * (z - cenz);
         r2 = d > r2 ? d : r2;
         const double o = x * x + y * y + z * z;
         r2o = o > r2o ? o : r2o;
         if (dl) {
-            const double a = dl[3 * j], b = dl[3 * j + 1], c2 = dl[3 * j + 2];
+            const double a = in.delta(j, 0), b = in.delta(j, 1), c2 = in.delta(j, 2);
             const double dd = a * a + b * b + c2 * c2;
             dmax2 = dd > dmax2 ? dd : dmax2;
             ndmin2 = -dd > ndmin2 ? -dd : ndmin2;
@@ -121,7 +147,7 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
         const double moving2 = 1e-2 * ext[2];
         double nmin[1] = {-INFINITY};
         for (int j = tid; j < M; j += 256) {
-            const double a = dl[3 * j], b = dl[3 * j + 1], c2 = dl[3 * j + 2];
+            const double a = in.delta(j, 0), b = in.delta(j, 1), c2 = in.delta(j, 2);
             const double dd = a * a + b * b + c2 * c2;
             if (dd >= moving2 && dd > 0.0 && -dd > nmin[0]) nmin[0] = -dd;
         }
@@ -156,12 +182,11 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
         Rec32 r32 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         Rec64 r64 = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (j < M) {
-            const double w[3] = {from_w ? W[3 * j] : X[j], from_w ? W[3 * j + 1] : X[npad + j],
-                                 from_w ? W[3 * j + 2] : X[2 * (size_t)npad + j]};
+            const double w[3] = {in.weight(j, 0), in.weight(j, 1), in.weight(j, 2)};
             bad |= !(isfinite(w[0]) && isfinite(w[1]) && isfinite(w[2]));
             if (!from_w) { W[3 * j] = w[0]; W[3 * j + 1] = w[1]; W[3 * j + 2] = w[2]; }
-            const double R = radii[j];
-            r64.cx = centres[3 * j]; r64.cy = centres[3 * j + 1]; r64.cz = centres[3 * j + 2];
+            const double R = in.radius(j);
+            r64.cx = in.centre(j, 0); r64.cy = in.centre(j, 1); r64.cz = in.centre(j, 2);
             r64.s = gauss ? -1.0 / (R * R) : 0.0;
             r64.wx = w[0] * w64; r64.wy = w[1] * w64; r64.wz = w[2] * w64;
             const double cn[3] = {(r64.cx - x0[0]) * inv_s, (r64.cy - x0[1]) * inv_s, (r64.cz - x0[2]) * inv_s};
@@ -195,9 +220,7 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
     __shared__ double s_aff[12];
     if (tid < 12) {
         const int cc = tid / 4, k = tid % 4;
-        double v = 0.0;
-        if (from_w) v = W[3 * (M + k) + cc];
-        else if (k < T) v = X[(size_t)cc * npad + M + k];
+        const double v = in.affine(cc, k, M, T);
         bad |= !isfinite(v);
         if (!from_w) W[3 * (M + k) + cc] = v;
         model->affine64[tid] = v;
@@ -205,21 +228,17 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
     }
     if (bad) s_bad = 1;
     __syncthreads();
-    if (tid < 3) {
-        const int c = tid;
-        const double *a = s_aff + 4 * c;   // {v0, Vx, Vy, Vz}
-        model->poly32[5 * c + 0] = (float)(a[0] + a[1] * x0[0] + a[2] * x0[1] + a[3] * x0[2] + kappa * m[5 * c + 4]);
-        model->poly32[5 * c + 1] = (float)(a[1] * sc - 2.0 * kappa * m[5 * c + 1]);
-        model->poly32[5 * c + 2] = (float)(a[2] * sc - 2.0 * kappa * m[5 * c + 2]);
-        model->poly32[5 * c + 3] = (float)(a[3] * sc - 2.0 * kappa * m[5 * c + 3]);
-        model->poly32[5 * c + 4] = (float)(kappa * m[5 * c]);
-        model->norm32[c] = (float)x0[c];
-    }
     // (threads 0..2 sit in one wave: the largest polynomial coefficient joins the largest weight without a barrier)
     float pmax = 0.f;
     if (tid < 3) {
+        const int c = tid;
+        const double *a = s_aff + 4 * c;   // {v0, Vx, Vy, Vz}
+        const float p5[5] = {(float)(a[0] + a[1] * x0[0] + a[2] * x0[1] + a[3] * x0[2] + kappa * m[5 * c + 4]),
+                             (float)(a[1] * sc - 2.0 * kappa * m[5 * c + 1]), (float)(a[2] * sc - 2.0 * kappa * m[5 * c + 2]),
+                             (float)(a[3] * sc - 2.0 * kappa * m[5 * c + 3]), (float)(kappa * m[5 * c])};
 #pragma unroll
-        for (int e = 0; e < 5; ++e) pmax = fmaxf(pmax, fabsf(model->poly32[5 * tid + e]));
+        for (int e = 0; e < 5; ++e) { model->poly32[5 * c + e] = p5[e]; pmax = fmaxf(pmax, fabsf(p5[e])); }
+        model->norm32[c] = (float)x0[c];
     }
     pmax = fmaxf(pmax, fmaxf(__shfl(pmax, 1), __shfl(pmax, 2)));
     if (tid == 0) {
@@ -250,12 +269,18 @@ __device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M
         if (from_w == 1) {
             if (s_bad) tt = -4;
         } else {
-            if (model->sing_flag || s_bad) tt = -4;
-            if (model->dup_flag) tt = -5;
+            if (in.sing_flag() || s_bad) tt = -4;
+            if (in.dup_flag()) tt = -5;
         }
         model->terminationtype = tt;
         if (slot.host_status) *slot.host_status = tt;        // page-locked: the host polls it behind the build's event (fd_capi.hip)
     }
+}
+
+__device__ __forceinline__ void pack_body(const BatchSlot &slot, int npad, int M, int Mpad, int T, int kind, int from_w, int layers)
+{
+    const PackGlobal in{from_w ? nullptr : slot.X, slot.W, slot.centres, slot.radii, from_w ? nullptr : slot.delta, slot.model, npad, from_w};
+    pack_body_from(in, slot, npad, M, Mpad, T, kind, from_w, layers);
 }
 
 // ---- thin-plate only: centre tiles for the matrix-pipe evaluation ------------------------

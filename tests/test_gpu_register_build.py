@@ -114,3 +114,39 @@ def test_a_cook_through_the_register_build_holds_the_displacement_parity(hip_lib
     ref, _ = oracle.deform(table, fo.KERNEL_THIN_PLATE, radii, W, P)
     assert parity_ratio(out, ref, P, 1e-5) <= 1.0
     e.close()
+
+
+@pytest.mark.parametrize("M", [20, 100, 241, 256])
+def test_the_parallel_front_end_and_the_one_workgroup_form_agree(hip_lib, oracle, M):
+    """Round 4: a build that has the device to itself (single fd_build; a batch whose evaluations take every CU) assembles K, forms
+    Y = K V and rotates to B in two short launches over all CUs (k_reg_front1 / k_reg_front2) and factorises in one workgroup per
+    model; a batch that leaves CUs to its builds (fd_batch_set_eval_cus below the device's count: the pipeline) keeps the whole build
+    in that workgroup.  Same model either way: weights to rounding, both against the oracle, for every (kernel, term) of the path
+    and batches whose front-end launches take 1, 2 and 3 tiles per wave (1, 20 and 32 models)."""
+    dev = torch.device("cuda", 0)
+    rest = synth.control_points(M, "head")
+    d_rest = torch.from_numpy(rest).to(dev)
+    for F in (1, 20, 32):
+        deforms = [synth.deformed_rig(rest, f % 5) for f in range(F)]
+        deltas = np.stack([(d - rest).astype(np.float32) for d in deforms])
+        d_del = torch.from_numpy(deltas).to(dev)
+        for kind, okind, params, term in (CASES if F == 20 else CASES[:1]):
+            got = {}
+            for form, cus in (("front", 0), ("one-workgroup", 224)):
+                engines = [_engine(kind, params, term, capi.SOLVER_AUTO) for _ in range(F)]
+                batch = capi.Batch(engines)
+                batch.set_eval_cus(cus)
+                batch.set_points_dev([d_rest.data_ptr()] * F, [d_del.data_ptr() + f * M * 12 for f in range(F)], M)
+                batch.build_async()
+                reps = batch.build_result()
+                assert [r.terminationtype for r in reps] == [1] * F, (form, kind, term)
+                assert all(r.solver_used == capi.SOLVER_REGISTER for r in reps)
+                got[form] = [e.get_weights()[0] for e in engines]
+                batch.close()
+                for e in engines:
+                    e.close()
+            for f in (0, F // 2, F - 1):
+                rc, tt, W, radii = oracle.build(oracle.control_table(rest, deforms[f]), okind, params, term)
+                scale = np.abs(W).max()
+                assert np.abs(got["front"][f] - W).max() <= 1e-8 * scale, (F, kind, term, f)
+                assert np.abs(got["front"][f] - got["one-workgroup"][f]).max() <= 1e-10 * scale, (F, kind, term, f)
