@@ -203,3 +203,47 @@ def test_the_default_pipeline_of_three_lanes_matches_the_oracle(hip_lib, oracle,
         for e in ln["engines"]:
             e.set_stream(None)
             e.close()
+
+
+def test_a_group_on_one_stream_with_a_rig_that_cannot_be_built_passes_its_frames_through_and_says_so(hip_lib, oracle, c2):
+    """Round 4: with the evaluation on the build stream, fd_batch_cook_group records no event between build, packing and
+    evaluation, and polls no status inside the call (the build's event is recorded behind the evaluation: a query would see the
+    previous build's completion).  A build that fails -- coincident control points, -5 -- is then handled as the header documents
+    for asynchronous builds: the group's evaluation passes every frame through (P_out = P_in, what the reference's cook leaves
+    behind an error, src/SOP_FaceDeform.cpp:364-368), fd_batch_build_result reports -5 for every frame, and the NEXT group on the
+    batch, built on the sound rig, is correct again (oracle parity) -- nothing sticks to the batch."""
+    dev, d_P, d_deltas = c2["dev"], c2["d_P"], c2["d_deltas"]
+    F = 20
+    n = 200_000
+    stream = torch.cuda.Stream(device=dev)
+    engines = _engines(F, stream)
+    batch = capi.Batch(engines)
+    outs = [torch.full((n, 3), float("nan"), device=dev, dtype=torch.float32) for _ in range(F)]
+    falls = [torch.zeros(n, device=dev, dtype=torch.float32) for _ in range(F)]
+    bad = c2["rest"].copy(); bad[40] = bad[3]
+    d_bad = torch.from_numpy(bad).to(dev)
+    d_Pn = d_P[:n].contiguous()
+    stride = M * 12
+    tabs = batch.group_tables([d_deltas.data_ptr() + f * stride for f in range(F)], [o.data_ptr() for o in outs], [f.data_ptr() for f in falls])
+    torch.cuda.synchronize()
+    batch.cook_group(stream.cuda_stream, stream.cuda_stream, d_bad.data_ptr(), M, n, d_Pn.data_ptr(), tabs)       # enqueued: no error yet
+    torch.cuda.synchronize()
+    assert [r.terminationtype for r in batch.build_result(check=False)] == [-5] * F
+    for o in outs:
+        assert torch.equal(o, d_Pn)                                    # passed through, every vertex written
+    # the next group, sound rig, same batch and stream
+    for o in outs:
+        o.fill_(float("nan"))
+    torch.cuda.synchronize()
+    batch.cook_group(stream.cuda_stream, stream.cuda_stream, c2["d_rest"].data_ptr(), M, n, d_Pn.data_ptr(), tabs)
+    torch.cuda.synchronize()
+    assert [r.terminationtype for r in batch.build_result()] == [1] * F
+    idx = np.unique(np.concatenate([np.arange(0, 8), np.arange(0, n, 97), [n - 1]]))
+    lines = []
+    sub = {"P": c2["P"][:n], "rest": c2["rest"], "deltas": c2["deltas"], "dev": dev}
+    worst = _check_frames(oracle, sub, list(range(F)), outs, falls, idx, "after-a-failed-group", lines)
+    assert worst <= 1.0
+    batch.close()
+    for e in engines:
+        e.set_stream(None)
+        e.close()
