@@ -904,13 +904,13 @@ def main():
         def measured_traffic(kernel):
             """HBM bytes of one launch from the COMMITTED counter passes -- not a measurement of this run, and only quoted when
             this run's launches carry as many frames as the profiled ones did (no extrapolation to another frame count)."""
-            k = tj.get(kernel)
+            k = tj.get(f"{kernel}@{frames_per_launch}") or tj.get(kernel)       # (a kernel profiled at several frame counts: one entry each)
             if not k or k.get("frames_per_launch", 1) != frames_per_launch:
                 return None
             return k.get("hbm_bytes_per_launch", k["hbm_bytes_fixed_per_launch"] + k["hbm_bytes_per_frame"] * frames_per_launch)
 
         def committed_pmc(kernel):
-            k = tj.get(kernel)
+            k = tj.get(f"{kernel}@{frames_per_launch}") or tj.get(kernel)
             if not k:
                 return None
             return {"source": f"profiles/traffic_{args.config}.json", "round": k.get("round"), "frames_measured": k.get("frames_per_launch"),

@@ -206,7 +206,7 @@ int fd_set_points_dev(fd_ctx *ctx, const float *d_rest_xyz, const float *d_delta
  * a full build: the weights are bit-identical to fd_set_points + fd_build with the same data).
  * Exception: where FD_SOLVER_AUTO takes the register-resident one-launch build (thin-plate, cubic, biharmonic, fixed-radius
  * Gaussian with a term that makes them definite, up to 256 control points) no factorisation is stored -- the matrix never leaves
- * the registers -- and the next fd_build* simply builds again, in one launch (0.19 ms at M = 256, less than the stored-factor
+ * the registers -- and the next fd_build* simply builds again (0.18 ms at M = 256, less than the stored-factor
  * path's launch chain); the weights are the same bits either way.  FD_SOLVER_CHAIN keeps and reuses the factorisation.
  * FD_E_NOT_BUILT when there is no factorisation to reuse (no build yet, or fd_set_points /
  * fd_set_kernel / fd_set_term / fd_import_model since); M must match; order <= 2048. */

@@ -97,6 +97,24 @@ def main():
               "valu_active_frac": m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
               "wait_inst_frac": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]})
 
+    # ---- the same kernel at the driver's 20 frames per launch: bytes and pipe activity (its own entry: bench.py quotes traffic only
+    #      for the frame count that was measured)
+    m20, n20, _ = counters(("pmc_fetch20", "pmc_write20", "pmc_mfma20"), "k_deform32_shared_w1")
+    if "FETCH_SIZE" in m20 and "WRITE_SIZE" in m20:
+        f20, w20 = m20["FETCH_SIZE"] * 1024 * 2, m20["WRITE_SIZE"] * 1024
+        c20 = m20.get("GRBM_GUI_ACTIVE", 0.0) / 8
+        tj["kernels"][kname + "@20"] = {"round": 4, "frames_per_launch": 20, "FETCH_SIZE_KiB_raw": m20["FETCH_SIZE"], "WRITE_SIZE_KiB": m20["WRITE_SIZE"],
+                                        "hbm_bytes_per_launch": f20 + w20, "hbm_bytes_fixed_per_launch": f20, "hbm_bytes_per_frame": w20 / 20,
+                                        "mfma_busy_frac": (m20["SQ_VALU_MFMA_BUSY_CYCLES"] / (c20 * 1024)) if c20 and "SQ_VALU_MFMA_BUSY_CYCLES" in m20 else None,
+                                        "wait_inst_frac": (m20["SQ_WAIT_INST_ANY"] / m20["SQ_WAVE_CYCLES"]) if m20.get("SQ_WAVE_CYCLES") else None}
+        with open(f"{DST}/r04_pmc_shared_c2_20frames.txt", "w") as f:
+            f.write(f"{kname}, C2 (N=1e6, M=256), 20 thin-plate frames per launch (the driver's `--steps 20`); rocprofv3 --pmc, one counter group per pass, mean over {n20['FETCH_SIZE']} launches\n\n")
+            for kk in sorted(m20):
+                f.write(f"{kk:28s} {m20[kk]:16.1f}\n")
+            f.write(f"\nHBM read = FETCH_SIZE KiB x 1024 x 2 = {f20 / 1e6:.2f} MB, write = {w20 / 1e6:.2f} MB; algorithmic 12 + 20 x 16 = 332.00 MB; traffic / algorithmic = {(f20 + w20) / 332e6:.4f}\n")
+            if c20:
+                f.write(f"matrix pipe busy = {m20['SQ_VALU_MFMA_BUSY_CYCLES'] / (c20 * 1024):.3f}; MFMA instructions {m20['SQ_INSTS_MFMA']:.0f}\n")
+
     # ---- the register-resident build: PMC
     r, rn, _ = counters(("pmc_reg_mfma", "pmc_reg_sq", "pmc_reg_fetch", "pmc_reg_write"), "k_build_reg")
     rows, _ = kernel_stats(f"{DST}/r04_build_reg_kernel_stats.csv")
