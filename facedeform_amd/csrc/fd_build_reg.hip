@@ -302,6 +302,16 @@ struct PackLds {
     __device__ __forceinline__ int dup_flag() const { return dup; }
 };
 
+// An operand that only some lanes carry (three right-hand sides, four reflector columns): read UNCONDITIONALLY from a clamped
+// address and selected afterwards.  Written as `cond ? lds[i] : 0.0` the read sits in an exec-masked block of its own, and the four
+// operand reads of a tile are then issued one at a time, each behind a full LDS round trip (seen in the ISA: 4 x ~130 cycles in
+// front of every tile's matrix instructions, in the right-hand sides' updates of both substitutions).
+__device__ __forceinline__ double lds_where(bool cond, const double *p, int i_true)
+{
+    const double v = p[cond ? i_true : 0];
+    return cond ? v : 0.0;
+}
+
 // ---- one 16 x 16 tile of K in the accumulator layout: e[i] of lane (c, g) = phi(|c_row - c_col|^2) (+ lambda on the diagonal) at
 // row 16 I + g + 4 i, column 16 J + c; zero outside the M x M matrix.  Beside it the largest |element| and whether two different
 // centres coincide (-> -5).
@@ -683,7 +693,7 @@ __global__ __launch_bounds__(kRegThreads) void k_reg_front1(const BatchSlot *tab
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
-                    const double b = c < 4 ? L.V[4 * (16 * I + 4 * s2 + g) + c] : 0.0;
+                    const double b = lds_where(c < 4, L.V, 4 * (16 * I + 4 * s2 + g) + c);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(e[t][s2], b, acc, 0, 0, 0);
                 }
                 if (c < 4) {
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(kRegThreads) void k_reg_front1(const BatchSlot *tab
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) {
                     const double a = sb[c * kPitch + 4 * s2 + g];
-                    const double b = c < 4 ? L.V[4 * (16 * J + 4 * s2 + g) + c] : 0.0;
+                    const double b = lds_where(c < 4, L.V, 4 * (16 * J + 4 * s2 + g) + c);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                 }
                 if (c < 4) {
@@ -973,7 +983,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const double b = c < 4 ? L.V[4 * (16 * I + 4 * s + g) + c] : 0.0;
+                    const double b = lds_where(c < 4, L.V, 4 * (16 * I + 4 * s + g) + c);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[t][s], b, acc, 0, 0, 0);
                 }
                 if (c < 4) {
@@ -988,7 +998,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const double a = sb[c * kPitch + 4 * s + g];
-                    const double b = c < 4 ? L.V[4 * (16 * J + 4 * s + g) + c] : 0.0;
+                    const double b = lds_where(c < 4, L.V, 4 * (16 * J + 4 * s + g) + c);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                 }
                 if (c < 4) {
@@ -1081,11 +1091,16 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                         const int I = tI(t);
                         const double *pb = L.P + (size_t)I * kTileLds;
                         double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                        double za[4], zb[4];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const double a = c < 3 ? L.Z[c * 256 + 16 * Kp + 4 * s + g] : 0.0;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[c * kPitch + 4 * s + g], acc, 0, 0, 0);
-                        }
+                        for (int s = 0; s < 4; ++s) { za[s] = lds_where(c < 3, L.Z, c * 256 + 16 * Kp + 4 * s + g); zb[s] = pb[c * kPitch + 4 * s + g]; }
+                        // (every operand read of the tile in flight, ONE wait, then the matrix instructions: left to itself the scheduler
+                        //  -- at the register limit here -- reads one operand, waits, issues, reads the next)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[s], zb[s], acc, 0, 0, 0);
                         if (g < 3) L.F[g * kRows + 16 * I + c] -= acc[0];
                     }
                 }
@@ -1095,9 +1110,14 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 for (int t = 0; t < kSlots; ++t) {
                     if (FD_SLOT(m_upd, t)) {
                         const double *pa = L.P + (size_t)tI(t) * kTileLds, *pb = L.P + (size_t)tJ(t) * kTileLds;
+                        double ua[4], ub[4];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[c * kPitch + 4 * s + g], pb[c * kPitch + 4 * s + g], S[t], 0, 0, 0);
+                        for (int s = 0; s < 4; ++s) { ua[s] = -pa[c * kPitch + 4 * s + g]; ub[s] = pb[c * kPitch + 4 * s + g]; }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) S[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[s], ub[s], S[t], 0, 0, 0);
                     }
                 }
             }
@@ -1182,8 +1202,13 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 if (FD_SLOT(m_panel, t)) {
                     const double *sb = L.P + (size_t)tI(t) * kTileLds;
                     double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                    double sa[4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[c * kPitch + 4 * s + g], bop[s], acc, 0, 0, 0);
+                    for (int s = 0; s < 4; ++s) sa[s] = sb[c * kPitch + 4 * s + g];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[s], bop[s], acc, 0, 0, 0);
                     S[t] = acc;
                 }
             }
@@ -1267,11 +1292,14 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         for (int t = 0; t < kSlots; ++t) {
             if (FD_SLOT(m_row, t)) {
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                double ya[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double a = c < 3 ? L.Y[c * 256 + 16 * I + 4 * s + g] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, S[t][s], acc, 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s) ya[s] = lds_where(c < 3, L.Y, c * 256 + 16 * I + 4 * s + g);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[s], S[t][s], acc, 0, 0, 0);
                 if (g < 3) L.Z[g * 256 + 16 * tJ(t) + c] -= acc[0];
             }
         }
