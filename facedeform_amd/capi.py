@@ -19,6 +19,7 @@ FD_E_INVALID, FD_E_NOMEM, FD_E_DEVICE, FD_E_SINGULAR, FD_E_DUPLICATE, FD_E_NOT_B
 KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_QNN, KERNEL_THIN_PLATE, KERNEL_BIHARMONIC, KERNEL_CUBIC, KERNEL_GAUSSIAN_ML = range(6)
 TERM_LINEAR, TERM_CONST, TERM_ZERO = range(3)
 EVAL_FP32, EVAL_FP64 = 0, 1
+ABI_VERSION = 9            # FD_ABI_VERSION of include/facedeform_hip.h this binding's structures are laid out for
 SOLVER_AUTO, SOLVER_LU, SOLVER_ONE_WORKGROUP, SOLVER_REGISTER, SOLVER_CHAIN = 0, 1, 2, 3, 4
 SOLVER_LU_NOPIVOT = 5          # a value of fd_report.solver_used only
 OUTPUT_POSITION, OUTPUT_DISPLACEMENT = 0, 1
@@ -96,6 +97,11 @@ def load() -> C.CDLL:
     L.fd_destroy.argtypes = [vp]; L.fd_destroy.restype = None
     L.fd_last_error.argtypes = [vp]; L.fd_last_error.restype = C.c_char_p
     L.fd_abi_version.argtypes = []; L.fd_abi_version.restype = i32
+    # fd_report / fdsop_geo are written whole into the caller's memory and carry no size field: a binding laid out for another ABI
+    # would be overwritten past its end -- refuse the library instead
+    if L.fd_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path} speaks ABI {L.fd_abi_version()}, this binding is laid out for {ABI_VERSION}: rebuild "
+                           "(`python -c 'import __graft_entry__ as g; g.build()'`)")
     L.fd_set_stream.argtypes = [vp, vp]; L.fd_set_stream.restype = i32
     L.fd_set_eval_precision.argtypes = [vp, i32]; L.fd_set_eval_precision.restype = i32
     L.fd_set_output.argtypes = [vp, i32]; L.fd_set_output.restype = i32

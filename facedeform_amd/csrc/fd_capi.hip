@@ -1490,7 +1490,16 @@ int fd_batch_set_points_dev(fd_batch *b, const float *const *d_rest_xyz, const f
     if (!b || !d_rest_xyz || !d_delta_xyz) return FD_E_INVALID;
     if (M <= 0 || M + 4 > kMaxOrder) { batch_err(b, "fd_batch_set_points_dev: M = %d outside 1..%d", M, kMaxOrder - 4); return FD_E_INVALID; }
     b->prepared = false;
-    if (b->h_mismatch) *b->h_mismatch = 0;
+    if (b->h_mismatch && *b->h_mismatch != 0) {
+        // The pack kernel of the batch's PREVIOUS evaluation found a context built on other rest points than context 0 (same
+        // address, other contents) and passed its frame through.  It posts the word asynchronously; a pipeline comes through
+        // here before it ever polls (the word was cleared unseen): report it now, once, then start clean.
+        const int who = *b->h_mismatch - 1;
+        *b->h_mismatch = 0;
+        batch_err(b, "shared-rig evaluation of the previous group: context %d was built on other rest points than context 0 (same "
+                     "address, other contents); its frame was passed through", who);
+        return FD_E_INVALID;
+    }
     for (int i = 0; i < b->n; ++i)
         if (!d_rest_xyz[i] || !d_delta_xyz[i]) { batch_err(b, "fd_batch_set_points_dev: null array for context %d", i); return FD_E_INVALID; }
     for (int i = 0; i < b->n; ++i) {

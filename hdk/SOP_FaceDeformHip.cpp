@@ -246,7 +246,9 @@ public:
     SOP_FaceDeformHip(OP_Network *net, const char *name, OP_Operator *op) : SOP_Node(net, name, op)
     {
         mySopFlags.setManagesDataIDs(true);     // as the reference: it bumps P's data ID itself
-        myNode = fdsop_create(nullptr);
+        // fdsop_geo and fd_report are plain structs without a size field, written whole by the library: a wrapper compiled
+        // against another header must not call into it (the node then cooks to an error, as with no device)
+        myNode = fd_abi_version() == FD_ABI_VERSION ? fdsop_create(nullptr) : nullptr;
     }
     ~SOP_FaceDeformHip() override { fdsop_destroy(myNode); }
 

@@ -387,6 +387,17 @@ def test_one_rest_rig_is_checked_by_content_not_by_address_alone(hip_lib, oracle
     with pytest.raises(capi.FdError) as ei:
         batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])
     assert ei.value.code == capi.FD_E_INVALID and "context 2" in str(ei.value)
+    # a pipeline never polls between groups: it sets the next group's points first -- that call reports the word (once) instead of
+    # clearing it unseen, and the one after starts clean
+    d_rest.copy_(torch.from_numpy(rest).to(dev)); torch.cuda.synchronize()
+    with pytest.raises(capi.FdError) as ei:
+        batch.set_points_dev([d_rest.data_ptr()] * 3, [d_del[k].data_ptr() for k in range(3)], M)
+    assert ei.value.code == capi.FD_E_INVALID and "previous group" in str(ei.value)
+    batch.set_points_dev([d_rest.data_ptr()] * 3, [d_del[k].data_ptr() for k in range(3)], M)
+    batch.build_async(); assert [r.terminationtype for r in batch.build_result()] == [1, 1, 1]
+    batch.deform_shared_dev(N, d_P.data_ptr(), [o.data_ptr() for o in outs])
+    torch.cuda.synchronize()
+    assert not torch.equal(outs[2], d_P)
     for b in (pair, lone, batch):
         b.close()
     for e in engines:
