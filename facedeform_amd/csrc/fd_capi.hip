@@ -819,8 +819,8 @@ int fd_build_result(fd_ctx *ctx, fd_report *report)
         float ms = 0.f;
         r.fp32_error = ctx->h_model->fp32_error; r.cancellation = ctx->h_model->cancellation;
         r.delta_min = ctx->h_model->delta_min; r.delta_max = ctx->h_model->delta_max; r.extent = ctx->h_model->extent;
-        if (hipEventElapsedTime(&ms, ctx->tev0, ctx->tev_mid) == hipSuccess) r.t_assemble_ms = ms;
-        if (hipEventElapsedTime(&ms, ctx->tev_mid, ctx->tev1) == hipSuccess) r.t_solve_ms = ms;
+        if (ctx->tev0 && ctx->tev_mid && hipEventElapsedTime(&ms, ctx->tev0, ctx->tev_mid) == hipSuccess) r.t_assemble_ms = ms;
+        if (ctx->tev_mid && ctx->tev1 && hipEventElapsedTime(&ms, ctx->tev_mid, ctx->tev1) == hipSuccess) r.t_solve_ms = ms;
         ctx->report = r;
         ctx->have_report = true;
         ctx->build_pending = false;
@@ -1621,7 +1621,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         (void)hipGetLastError(); b->d_fac = nullptr; shared_fac = false;
     }
     b->last_shared_factor = shared_fac ? 1 : 0;
-    FD_BHIP(hipEventRecord(b->ev0, stream));
+    if (!b->lean) FD_BHIP(hipEventRecord(b->ev0, stream));      // (lean: the group's first packet is its first kernel; the reports carry no phase times)
     if (shared_fac) {
         FD_BHIP(launch_build_reg_shared(bb, stream, &b->src, nullptr, b->d_fac));
         b->have_src = false;
@@ -1650,7 +1650,7 @@ int fd_batch_build_async(fd_batch *b, void *hip_stream)
         fd_ctx *c = b->ctxs[i];
         c->rig_build_id = this_build;
         c->wait_event = b->ev1; c->wait_stream = stream; c->wait_batch = b;
-        c->tev0 = b->ev0; c->tev_mid = bb.reg ? b->ev0 : b->ev_mid; c->tev1 = b->ev1;
+        c->tev0 = b->lean ? nullptr : b->ev0; c->tev_mid = b->lean ? nullptr : (bb.reg ? b->ev0 : b->ev_mid); c->tev1 = b->lean ? nullptr : b->ev1;
         c->have_factor = bb.ml_layers == 0;   // a batched build leaves a factorisation fd_set_deltas can reuse (not the multilayer model)
         c->factor_grouped = bb.group_panels != 0;
         c->last_spd = bb.spd != 0;
@@ -1990,8 +1990,23 @@ int fd_batch_cook_group(fd_batch *b, void *build_stream, void *eval_stream, cons
     hipStream_t bs = build_stream ? (hipStream_t)build_stream : cur_stream(c0);
     hipStream_t es = eval_stream ? (hipStream_t)eval_stream : bs;
     auto mark = [&](void *ev, hipStream_t st) { if (ev && hipEventRecord((hipEvent_t)ev, st) != hipSuccess) (void)hipGetLastError(); };
+#ifdef FD_TUNING
+    // FD_COOK_TIMING=1: host time of the call's pieces on stderr (us): wait_consumed | set_points | build (launches) | packing | evaluation
+    static const bool cook_timing = tuning_env("FD_COOK_TIMING") != nullptr;
+    struct CookClock {
+        bool on; double t[6]; int n = 0;
+        static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+        void tick() { if (on && n < 6) t[n++] = now(); }
+        ~CookClock() { if (on && n == 6) fprintf(stderr, "[cook_group host us] wait_consumed %.1f | set_points %.1f | build %.1f | packing %.1f | evaluation %.1f\n", t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]); }
+    } clk{cook_timing};
+#define FD_COOK_TICK() clk.tick()
+#else
+#define FD_COOK_TICK()
+#endif
+    FD_COOK_TICK();
     int rc = fd_batch_wait_consumed(b, build_stream);
     if (rc) return rc;
+    FD_COOK_TICK();
     const float *rest[kMaxBatch];
     for (int i = 0; i < b->n; ++i) rest[i] = d_rest_xyz;
     if ((rc = fd_batch_set_points_dev(b, rest, d_delta_xyz, M))) return rc;
@@ -2008,11 +2023,14 @@ int fd_batch_cook_group(fd_batch *b, void *build_stream, void *eval_stream, cons
         }
     } scope{b, bs, lean};
     b->lean = lean;
+    FD_COOK_TICK();
     if (events) mark(events->before_build, bs);
     if ((rc = fd_batch_build_async(b, build_stream))) return rc;
     scope.built = true;
     if (events) mark(events->after_build, bs);
+    FD_COOK_TICK();
     if ((rc = fd_batch_prepare_shared(b, build_stream, d_P_out, d_falloff_out))) return rc;
+    FD_COOK_TICK();
     if (es != bs) {
         // (the evaluation waits for the pack kernel's event inside fd_batch_deform_shared_dev when the set was prepared; the
         // per-frame fallback -- other kernels -- needs the builds themselves)
@@ -2024,6 +2042,7 @@ int fd_batch_cook_group(fd_batch *b, void *build_stream, void *eval_stream, cons
     if (events) mark(events->before_eval, es);
     rc = fd_batch_deform_shared_dev(b, es, N, d_P_in, d_P_out, nullptr, d_falloff_out, nullptr, nullptr, nullptr, 1.0f, 1.0f);
     if (events) mark(events->after_eval, es);
+    FD_COOK_TICK();
     if (lean && rc == FD_OK && b->packed_valid && b->sets[b->cur_set].eval_pending) b->consumed_override = b->sets[b->cur_set].eval_ev;
     return rc;
 }

@@ -439,7 +439,8 @@ const char *fd_shared_kernel_name(int M, int frames, int kind);
  * events (may be NULL): four caller-owned hipEvent_t handles recorded around the builds (on build_stream) and around the
  * evaluation launch (on eval_stream), for callers that time the pieces; NULL members are skipped.
  * With the evaluation on build_stream itself (eval_stream NULL or equal: one group, nothing to overlap) the call records NO event
- * of its own between the builds, the packing and the evaluation -- stream order does what they do across streams, and every
+ * of its own in front of the builds, between them and the packing or before the evaluation (the build's reports then carry no
+ * phase times) -- stream order does what they do across streams, and every
  * record is a barrier packet the queue idles ~4 us for.  The batch's "build done" event is then recorded BEHIND the evaluation:
  * fd_batch_build_result and any other stream ordered after the builds wait a little longer than needed, never too little, and a
  * failed build's status arrives with the NEXT call on the batch (the evaluation of an unbuilt model passes its frame through,
