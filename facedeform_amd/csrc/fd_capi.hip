@@ -138,6 +138,7 @@ struct fd_batch {
         size_t cap_wtiles = 0, cap_frames = 0;
         hipEvent_t packed_ev = nullptr;  // behind the pack kernel that filled the set
         hipEvent_t eval_ev = nullptr;    // behind the last evaluation that read it
+        hipEvent_t eval_done = nullptr;  // the event that says so: eval_ev, or -- a lean group call -- the batch's ev1, recorded right behind
         bool eval_pending = false;
     } sets[2];
     // "One rest rig" is decided on the host by the address the rest points were read from; an address does not identify
@@ -1851,7 +1852,7 @@ static int shared_pack(fd_batch *b, hipStream_t stream, int ek, float *const *d_
         st.cap_wtiles = wb; st.cap_frames = fb;
     }
     // the evaluation that last read this set must be through with it
-    if (st.eval_pending && st.eval_ev && hipStreamWaitEvent(stream, st.eval_ev, 0) != hipSuccess) {
+    if (st.eval_pending && st.eval_done && hipStreamWaitEvent(stream, st.eval_done, 0) != hipSuccess) {
         batch_err(b, "shared-rig evaluation: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
         return FD_E_DEVICE;
     }
@@ -1955,7 +1956,14 @@ int fd_batch_deform_shared_dev(fd_batch *b, void *hip_stream, int64_t N, const f
     a.max_wgs = b->eval_cus;
     hipError_t e = launch_deform_shared(a, stream);
     if (e != hipSuccess) { batch_err(b, "launch_deform_shared failed: %s", hipGetErrorString(e)); return FD_E_DEVICE; }
-    if (make_event(&st.eval_ev)) {
+    if (b->lean) {
+        // (one stream for the whole group: fd_batch_cook_group records the batch's ev1 right behind this launch -- that record says
+        //  "evaluated" as well as "built"; one trailing packet fewer in front of the caller's wait.  A later re-record of ev1 belongs to
+        //  a build that was itself ordered behind this evaluation by fd_batch_wait_consumed: waiting for it still implies this.)
+        st.eval_done = b->ev1;
+        st.eval_pending = true;
+    } else if (make_event(&st.eval_ev)) {
+        st.eval_done = st.eval_ev;
         if (hipEventRecord(st.eval_ev, stream) != hipSuccess) { (void)hipGetLastError(); st.eval_pending = false; }
         else st.eval_pending = true;
     } else {
@@ -2043,7 +2051,7 @@ int fd_batch_cook_group(fd_batch *b, void *build_stream, void *eval_stream, cons
     rc = fd_batch_deform_shared_dev(b, es, N, d_P_in, d_P_out, nullptr, d_falloff_out, nullptr, nullptr, nullptr, 1.0f, 1.0f);
     if (events) mark(events->after_eval, es);
     FD_COOK_TICK();
-    if (lean && rc == FD_OK && b->packed_valid && b->sets[b->cur_set].eval_pending) b->consumed_override = b->sets[b->cur_set].eval_ev;
+    if (lean && rc == FD_OK && b->packed_valid && b->sets[b->cur_set].eval_pending) b->consumed_override = b->ev1;      // (recorded by `scope` on the way out)
     return rc;
 }
 
