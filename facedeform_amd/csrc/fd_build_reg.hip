@@ -87,13 +87,19 @@ __device__ __forceinline__ double dpp_f64(double v)
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// (round 4: on the matrix pipe.  The DPP form -- row_ror 1, 2, 4, 8, then four v_readlane pairs -- is a chain of ~25 dependent
+//  instructions with DPP and SGPR hazards between them: ~450 cycles a sum as measured in the reflector wave, whose seven sums per
+//  reflector were most of its time.  v as the A operand against ones: D[i][j] = sum_g v(c = i, g) for every j, and a lane's four
+//  result registers hold the row sums of c = g, g + 4, g + 8, g + 12; their sum t depends on g alone, and t against ones again gives
+//  sum_g t_g -- the total -- in every lane.  Two matrix instructions and three adds; independent sums follow each other down the
+//  pipe.  Called with the whole wave active (the matrix instructions read every lane whatever EXEC says).  Fixed order: deterministic.)
 __device__ __forceinline__ double wave_sum(double v)
 {
-    v += dpp_f64<0x121>(v);
-    v += dpp_f64<0x122>(v);
-    v += dpp_f64<0x124>(v);
-    v += dpp_f64<0x128>(v);
-    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+    const double4_t zero = {0.0, 0.0, 0.0, 0.0};
+    const double4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, zero, 0, 0, 0);
+    const double t = (d[0] + d[1]) + (d[2] + d[3]);
+    const double4_t e = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, zero, 0, 0, 0);
+    return e[0];
 }
 __device__ __forceinline__ double wave_max(double v)
 {
@@ -357,49 +363,62 @@ __device__ __forceinline__ void assemble_tile(const double *cen, int I, int J, i
 // (reflectors), L.F (Q^T f with the pivot rows' shares aside in L.small[kG..]), L.small (tau, R, Tm), L.stat[3] (P rank-deficient).
 __device__ __forceinline__ void reflect_wave(const RegLds &L, int M, int T, int lane)
 {
-    // ---- meanwhile, wave 7: reflectors of P = [1 x y z] (dlarfg upside down: reflector k acts on rows 0 .. M-1-k, beta in
-    // row M-1-k) with f <- Q^T f folded into the same sweep: four rows per lane, every sum a DPP reduction, no barrier.
+    // ---- reflectors of P = [1 x y z] (dlarfg upside down: reflector k acts on rows 0 .. M-1-k, beta in row M-1-k) with
+    // f <- Q^T f folded into the same sweep.  Each lane keeps its four rows (lane + 64 q) of [V | f] -- 28 doubles -- IN REGISTERS from
+    // the first reflector to the last: a pivot row comes out by v_readlane, nothing else crosses lanes but the sums (DPP), and LDS
+    // sees the rows once, at the end.  (Round 3 read and wrote them in LDS around every reflector, each `if (i < piv)` read an
+    // exec-masked round trip: 24 k cycles -- hidden beside the assembly then, the critical path of k_reg_front1 now.  Same
+    // operations in the same order: the same bits.)
     bool singular = false;
     double cn[4] = {0.0, 0.0, 0.0, 0.0};
+    double v[4][4], f[4][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = lane + 64 * q;
-        if (i < M) {
-            const double p[4] = {1.0, L.cen[3 * i], L.cen[3 * i + 1], L.cen[3 * i + 2]};
+        const bool in = i < M;
+        const int ic = in ? i : 0;
+        const double p[4] = {1.0, L.cen[3 * ic], L.cen[3 * ic + 1], L.cen[3 * ic + 2]};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const double v = t < T ? p[t] : 0.0;
-                L.V[4 * i + t] = v;
-                cn[t] = fma(v, v, cn[t]);
-            }
+        for (int t = 0; t < 4; ++t) {
+            v[q][t] = (in && t < T) ? p[t] : 0.0;
+            if (in) cn[t] = fma(v[q][t], v[q][t], cn[t]);
         }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { const double d = L.F[e * kRows + ic]; f[q][e] = in ? d : 0.0; }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) cn[t] = wave_sum(cn[t]);
-    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= T) break;
         const int piv = M - 1 - k;
+        const int pl = __builtin_amdgcn_readfirstlane(piv & 63), pq = __builtin_amdgcn_readfirstlane(piv >> 6);
+        // the pivot row as it stands: register set pq of lane pl
+        // (a scalar branch on the register set, then plain v_readlanes: as a chain of selects in front of them the seven values
+        //  cost 1 500 cycles of the reflector's 4 500)
+        double rowv[4], rowf[3];
+#define FD_PIVOT_ROW(Q) { _Pragma("unroll") for (int t = 0; t < 4; ++t) rowv[t] = readlane_f64(v[Q][t], pl); \
+                          _Pragma("unroll") for (int e = 0; e < 3; ++e) rowf[e] = readlane_f64(f[Q][e], pl); }
+        if (pq == 0) FD_PIVOT_ROW(0) else if (pq == 1) FD_PIVOT_ROW(1) else if (pq == 2) FD_PIVOT_ROW(2) else FD_PIVOT_ROW(3)
+#undef FD_PIVOT_ROW
         // sigma, x . column c (c > k), x . f_c over the rows above the pivot
         double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double x[4], fr[4][3];
+        double x[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = lane + 64 * q;
-            x[q] = 0.0; fr[q][0] = fr[q][1] = fr[q][2] = 0.0;
+            x[q] = i < piv ? v[q][k] : 0.0;
             if (i < piv) {
-                x[q] = L.V[4 * i + k];
                 acc[0] = fma(x[q], x[q], acc[0]);
 #pragma unroll
-                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) acc[cc - k] = fma(x[q], L.V[4 * i + cc], acc[cc - k]);
+                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) acc[cc - k] = fma(x[q], v[q][cc], acc[cc - k]);
 #pragma unroll
-                for (int e = 0; e < 3; ++e) { fr[q][e] = L.F[e * kRows + i]; acc[4 + e] = fma(x[q], fr[q][e], acc[4 + e]); }
+                for (int e = 0; e < 3; ++e) acc[4 + e] = fma(x[q], f[q][e], acc[4 + e]);
             }
         }
 #pragma unroll
         for (int e = 0; e < 7; ++e) acc[e] = wave_sum(acc[e]);
-        const double xp = L.V[4 * piv + k];
+        const double xp = rowv[k];
         const double sigma = acc[0];
         const double norm = sqrt(fma(xp, xp, sigma));
         double beta = xp, tau = 0.0, scale = 0.0;
@@ -411,44 +430,55 @@ __device__ __forceinline__ void reflect_wave(const RegLds &L, int M, int T, int 
         if (!(norm > 64.0 * (double)M * kEps * sqrt(cn[k]))) singular = true;   // P has no full column rank (NaN too)
         double sc[4] = {0.0, 0.0, 0.0, 0.0}, prow[4] = {0.0, 0.0, 0.0, 0.0}, df[3];
 #pragma unroll
-        for (int cc = k + 1; cc < 4; ++cc) if (cc < T) { prow[cc] = L.V[4 * piv + cc]; sc[cc] = fma(scale, acc[cc - k], prow[cc]); }
+        for (int cc = k + 1; cc < 4; ++cc) if (cc < T) { prow[cc] = rowv[cc]; sc[cc] = fma(scale, acc[cc - k], prow[cc]); }
 #pragma unroll
-        for (int e = 0; e < 3; ++e) df[e] = fma(scale, acc[4 + e], L.F[e * kRows + piv]);       // v . f_e (v_piv = 1)
-        wave_lds_sync();                      // everyone has read the pivot row
+        for (int e = 0; e < 3; ++e) df[e] = fma(scale, acc[4 + e], rowf[e]);       // v . f_e (v_piv = 1)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = lane + 64 * q;
             if (i < piv) {
-                const double v = x[q] * scale;
-                L.V[4 * i + k] = v;
+                const double vv = x[q] * scale;
+                v[q][k] = vv;
 #pragma unroll
-                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) L.V[4 * i + cc] = fma(-tau * sc[cc], v, L.V[4 * i + cc]);
+                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) v[q][cc] = fma(-tau * sc[cc], vv, v[q][cc]);
 #pragma unroll
-                for (int e = 0; e < 3; ++e) L.F[e * kRows + i] = fma(-tau * df[e], v, fr[q][e]);
+                for (int e = 0; e < 3; ++e) f[q][e] = fma(-tau * df[e], vv, f[q][e]);
+            } else if (i == piv) {
+                // the pivot row: v = e_piv in column k, zero in the columns right of it; its share of Q^T f belongs to the
+                // polynomial equations (aside, below) and is zero in the Cholesky's right-hand side
+                v[q][k] = 1.0;
+#pragma unroll
+                for (int cc = k + 1; cc < 4; ++cc) if (cc < T) v[q][cc] = 0.0;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) f[q][e] = 0.0;
             }
         }
         if (lane == 0) {
             L.small[kTau + k] = tau;
             L.small[kR + 4 * k + k] = beta;
-            L.V[4 * piv + k] = 1.0;
 #pragma unroll
-            for (int cc = k + 1; cc < 4; ++cc) if (cc < T) {
-                L.small[kR + 4 * k + cc] = fma(-tau, sc[cc], prow[cc]);
-                L.V[4 * piv + cc] = 0.0;
-            }
-            // the pivot row's share of Q^T f belongs to the polynomial equations: aside, and zero in the Cholesky's right-hand side
+            for (int cc = k + 1; cc < 4; ++cc) if (cc < T) L.small[kR + 4 * k + cc] = fma(-tau, sc[cc], prow[cc]);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) { L.small[kG + 3 * k + e] = fma(-tau, df[e], L.F[e * kRows + piv]); L.F[e * kRows + piv] = 0.0; }
+            for (int e = 0; e < 3; ++e) L.small[kG + 3 * k + e] = fma(-tau, df[e], rowf[e]);
         }
-        wave_lds_sync();
     }
+    // the rows go to LDS once (rows M .. 255 are zero in both arrays)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) L.V[4 * i + t] = v[q][t];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) L.F[e * kRows + i] = f[q][e];
+    }
+    wave_lds_sync();
     // compact WY factor from the Gram matrix of V
     double gram[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = lane + 64 * q;
         if (i < M) {
-            const double v0 = L.V[4 * i], v1 = L.V[4 * i + 1], v2 = L.V[4 * i + 2], v3 = L.V[4 * i + 3];
+            const double v0 = v[q][0], v1 = v[q][1], v2 = v[q][2], v3 = v[q][3];
             gram[0] = fma(v0, v1, gram[0]); gram[1] = fma(v0, v2, gram[1]); gram[2] = fma(v0, v3, gram[2]);
             gram[3] = fma(v1, v2, gram[3]); gram[4] = fma(v1, v3, gram[4]); gram[5] = fma(v2, v3, gram[5]);
         }
