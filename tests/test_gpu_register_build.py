@@ -1,7 +1,9 @@
 """GPU: the register-resident one-launch build (csrc/fd_build_reg.hip; what FD_SOLVER_AUTO takes on the definite path up to
 256 control points, and FD_SOLVER_REGISTER asks for by name): control table, kernel-matrix assembly, null-space projection,
 blocked Cholesky with the diagonal blocks factorised in registers beside the trailing updates, both substitutions and the
-packing in ONE launch of one workgroup per model.  Replaces alglib::rbfsetpoints + rbfbuildmodel, reference
+packing by one workgroup per model -- in ONE launch where the batch leaves CUs to its builds (a pipeline), behind two short
+launches over all CUs for the parallel third (assembly, Y = K V, the projection: round 4) where it has the device to itself.
+Replaces alglib::rbfsetpoints + rbfbuildmodel, reference
 src/SOP_FaceDeform.cpp:331-368, in the dense formulation.
 
 Bars: weights against the oracle <= 1e-8 max|W| (observed 1e-11 .. 1e-15) and against the launch chain to rounding, for every
