@@ -929,6 +929,10 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
 #define tI(t) (opaque_s(__builtin_amdgcn_readlane(ijv, t)) & 0xff)
 #define tJ(t) ((opaque_s(__builtin_amdgcn_readlane(ijv, t)) >> 8) & 0xff)
 #define FD_SLOT(m, t) (((m) >> (t)) & 1u)
+    // (The scans of the step loop test the slots FOUR AT A TIME first.  A slot that is not in the mask costs a taken branch over its
+    //  body -- ~35 cycles as measured: an instruction-fetch bubble each -- and a step runs eight scans of twenty: the waves with no
+    //  tile in a panel spent 2 200 cycles of a 5 500-cycle panel phase skipping slots.  Masks are sparse -- a panel's tiles, a row's
+    //  -- or a suffix of the column-major slot order, so most groups of four go in one branch.)
     FD_RSTAMP()
 
     if constexpr (FRONT) {
@@ -1116,7 +1120,9 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 // right-hand sides: f_I -= z_Kp L_I,Kp^T for my panel tiles (A = z_Kp as three rows, B = the panel tile from LDS)
                 if (m_col) FD_SPIN_UNTIL(FD_FLAG(1) >= K)
 #pragma unroll
-                for (int t = 0; t < kSlots; ++t) {
+                for (int tg_ = 0; tg_ < kSlots; tg_ += 4) if ((m_col >> tg_) & 0xfu)      // (four slots at a time: see FD_SLOT)
+#pragma unroll
+                for (int t = tg_; t < tg_ + 4; ++t) {
                     if (FD_SLOT(m_col, t)) {
                         const int I = tI(t);
                         const double *pb = L.P + (size_t)I * kTileLds;
@@ -1137,7 +1143,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 // the trailing matrix: C_IJ -= L_I,Kp L_J,Kp^T.  (Fetching the operands of slot t + 1 before the matrix instructions
                 // of slot t -- two register sets -- was tried: 34 more spilled registers, and every step slower, 198k -> 225k cycles.)
 #pragma unroll
-                for (int t = 0; t < kSlots; ++t) {
+                for (int t = 0; t < kSlots; ++t) {      // (a dense mask: every slot tested on its own)
                     if (FD_SLOT(m_upd, t)) {
                         const double *pa = L.P + (size_t)tI(t) * kTileLds, *pb = L.P + (size_t)tJ(t) * kTileLds;
                         double ua[4], ub[4];
@@ -1184,7 +1190,9 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             if (m_crit) {
                 double *pk = L.P + (size_t)(K + 1) * kTileLds;
 #pragma unroll
-                for (int t = 0; t < kSlots; ++t) {
+                for (int tg_ = 0; tg_ < kSlots; tg_ += 4) if ((m_crit >> tg_) & 0xfu)      // (four slots at a time: see FD_SLOT)
+#pragma unroll
+                for (int t = tg_; t < tg_ + 4; ++t) {
                     if (FD_SLOT(m_crit, t)) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) pk[(g + 4 * i) * kPitch + c] = S[t][i];
@@ -1205,7 +1213,9 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 FD_SPIN_UNTIL(FD_FLAG(2) >= K + 1)
                 const double *pa = L.P + (size_t)(K + 1) * kTileLds;
 #pragma unroll
-                for (int t = 0; t < kSlots; ++t) {
+                for (int tg_ = 0; tg_ < kSlots; tg_ += 4) if ((m_next >> tg_) & 0xfu)      // (four slots at a time: see FD_SLOT)
+#pragma unroll
+                for (int t = tg_; t < tg_ + 4; ++t) {
                     if (FD_SLOT(m_next, t)) {
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
@@ -1219,7 +1229,9 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
                 FD_POST(0, K + 1)
             }
 #pragma unroll
-            for (int t = 0; t < kSlots; ++t) {
+            for (int tg_ = 0; tg_ < kSlots; tg_ += 4) if ((m_panel >> tg_) & 0xfu)      // (four slots at a time: see FD_SLOT)
+#pragma unroll
+            for (int t = tg_; t < tg_ + 4; ++t) {
                 if (FD_SLOT(m_panel, t)) {
                     double *dst = L.P + (size_t)tI(t) * kTileLds;
 #pragma unroll
@@ -1228,7 +1240,9 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             }
             wave_lds_sync();
 #pragma unroll
-            for (int t = 0; t < kSlots; ++t) {
+            for (int tg_ = 0; tg_ < kSlots; tg_ += 4) if ((m_panel >> tg_) & 0xfu)      // (four slots at a time: see FD_SLOT)
+#pragma unroll
+            for (int t = tg_; t < tg_ + 4; ++t) {
                 if (FD_SLOT(m_panel, t)) {
                     const double *sb = L.P + (size_t)tI(t) * kTileLds;
                     double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -1244,7 +1258,9 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
             }
             wave_lds_sync();
 #pragma unroll
-            for (int t = 0; t < kSlots; ++t) {
+            for (int tg_ = 0; tg_ < kSlots; tg_ += 4) if ((m_panel >> tg_) & 0xfu)      // (four slots at a time: see FD_SLOT)
+#pragma unroll
+            for (int t = tg_; t < tg_ + 4; ++t) {
                 if (FD_SLOT(m_panel, t)) {
                     double *dst = L.P + (size_t)tI(t) * kTileLds;
 #pragma unroll
@@ -1319,7 +1335,7 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
         const unsigned m_row = slots_where(ivI == I && ivJ < I);
         const bool next_mine = slots_where(ivI == I && ivJ == I - 1) != 0u;
 #pragma unroll
-        for (int t = 0; t < kSlots; ++t) {
+        for (int t = 0; t < kSlots; ++t) {      // (a dense mask: every slot tested on its own)
             if (FD_SLOT(m_row, t)) {
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
                 double ya[4];
