@@ -884,13 +884,29 @@ __global__ __launch_bounds__(kRegThreads) void k_build_reg(const BatchSlot *tab,
     if constexpr (!FRONT) {
         // V, Q^T f, B21 and the small matrices as the front end left them (k_reg_front1 / k_reg_front2)
         gcdouble *fr = as_global(slot.ns);
-        for (int e = tid; e < 4 * kRows; e += kRegThreads) {
-            L.V[e] = fr[kFrV + e];
-            L.B21[e] = fr[kFrB21 + e];
-            if (e < 3 * kRows) L.F[e] = fr[kFrF + e];
-            if (e < kSmallDoubles) L.small[e] = fr[kFrSmall + e];
+        // (a thread's two entries of each array requested together, stored afterwards: ONE round trip to L2 -- as a loop of
+        //  load-and-store the second entry's loads waited behind the first's LDS stores)
+        static_assert(4 * kRows == 2 * kRegThreads, "two entries per thread");
+        double lv[2], lb[2], lf[2], ls[2], lc[2], ld[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = tid + kRegThreads * h;
+            lv[h] = fr[kFrV + e];
+            lb[h] = fr[kFrB21 + e];
+            lf[h] = fr[kFrF + (e < 3 * kRows ? e : 0)];
+            ls[h] = fr[kFrSmall + (e < kSmallDoubles ? e : 0)];
             // (for the packing, in the same round trip: the centres, and the deltas where the transposition buffers would be)
-            if (e < 3 * M) { L.cen[e] = slot.centres[e]; L.scr[e] = (double)slot.delta[e]; }
+            lc[h] = slot.centres[e < 3 * M ? e : 0];
+            ld[h] = (double)slot.delta[e < 3 * M ? e : 0];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = tid + kRegThreads * h;
+            L.V[e] = lv[h];
+            L.B21[e] = lb[h];
+            if (e < 3 * kRows) L.F[e] = lf[h];
+            if (e < kSmallDoubles) L.small[e] = ls[h];
+            if (e < 3 * M) { L.cen[e] = lc[h]; L.scr[e] = ld[h]; }
         }
     } else {
         const float *rest = use_src ? src.rest[blockIdx.z] : slot.rest;
