@@ -586,11 +586,19 @@ __device__ __forceinline__ void w_row(const RegLds &L, int i)
 // to the diagonal tile at once and hands that to the factor wave, which then works beside everything else of the step.
 // The offsets (three bits per column) balance the load: at 16 x 16 tiles the workers hold 19 or 20 each, and no more than
 // kSlots for any smaller triangle.  Correctness does not rest on the co-location (see the hand-over in the step loop).
+// Round 4: the wave w0(J) that owns (J + 1, J) -- and with it (J + 1, J + 1): the step's critical chain -- gets NO other tile of
+// column J; the column's other tiles go round the six other waves.  In the panel phase that wave then has its two dependent
+// chains and nothing behind them while the others solve their one or two tiles beside it (it had a second panel tile in eight of
+// fifteen columns).  Offsets chosen by search (scored: tiles per wave <= 20; the trailing updates' per-SIMD maxima, waves w and
+// w + 4 sharing a SIMD, summed over the steps: 196 against 203; the panel phases' longest wave: 32 against 39 tile-chains; the back
+// substitution's longest wave per row: 39 against 43).
 __device__ __forceinline__ int tile_owner(int I, int J)
 {
-    constexpr unsigned long long kOffsets = 0x161675511c9bull;
-    if (I == J) return J == 0 ? 0 : (J + (int)((kOffsets >> (3 * (J - 1))) & 7ull)) % kWorkers;
-    return (I + (int)((kOffsets >> (3 * J)) & 7ull)) % kWorkers;
+    constexpr unsigned long long kOffsets = 0x8a3ad602e31bull;
+    auto w0 = [](int K) { return (K + 1 + (int)((kOffsets >> (3 * K)) & 7ull)) % kWorkers; };
+    if (I == J) return J == 0 ? 0 : w0(J - 1);
+    const int j = I - J - 1;
+    return j == 0 ? w0(J) : (w0(J) + 1 + (j - 1) % 6) % kWorkers;
 }
 
 // ---- one factorisation for a group of frames that share the rest rig (fd_batch_set_shared_factor; SURVEY 8e: "factor once and
